@@ -1,0 +1,206 @@
+/*
+ * splatraster.h — C ABI of the MI355X-native differentiable Gaussian tile rasterizer
+ * and of the 3-nearest-neighbour distance kernel used to seed Gaussian scales.
+ *
+ * This is the drop-in boundary for SplatLoc's native hot path.  The reference binds
+ * this path through two CUDA extension modules whose sources are NOT vendored in
+ * /root/reference (empty submodule dirs, .gitmodules:1-9):
+ *
+ *   diff_gauss.GaussianRasterizer.forward / backward
+ *       call site  gaussian_splatting/gaussian_renderer/__init__.py:117-126  (forward)
+ *       settings   gaussian_splatting/gaussian_renderer/__init__.py:42-55
+ *       backward   triggered by train_gaussians.py:229 and :286 (loss.backward())
+ *   simple_knn._C.distCUDA2
+ *       call site  gaussian_splatting/scene/gaussian_model.py:18,206
+ *
+ * Everything here is plain C: raw device pointers, sizes, an opaque stream handle
+ * (hipStream_t passed as void*), int status codes.  No torch types, no exceptions.
+ * All float tensors are fp32, row-major, contiguous, resident in device memory.
+ *
+ * Memory ownership: the caller owns every buffer.  Scratch state that must survive
+ * from forward to backward lives in three caller-allocated opaque buffers
+ * (geometry / binning / image), sized by the *_bytes() queries below, so a framework's
+ * caching allocator owns all device memory and several frames can be alive at once
+ * (train_gaussians.py:195-229 keeps 5 forwards alive before one backward).
+ */
+#ifndef SPLATRASTER_H
+#define SPLATRASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
+
+/* status codes */
+#define SPLATRASTER_OK 0
+#define SPLATRASTER_ERR_BAD_ARG 1      /* null pointer / inconsistent sizes / both-or-neither inputs */
+#define SPLATRASTER_ERR_HIP 2          /* a HIP runtime call or kernel launch failed */
+#define SPLATRASTER_ERR_UNSUPPORTED 3  /* e.g. sh_degree > 3 */
+#define SPLATRASTER_ERR_OVERFLOW 4     /* tile instance count does not fit the binning buffer */
+
+/*
+ * Mirror of diff_gauss.GaussianRasterizationSettings
+ * (gaussian_renderer/__init__.py:42-55) minus the tensors, which are passed as pointers.
+ */
+typedef struct splatraster_settings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;   /* active SH degree (0..3); only used when shs != NULL */
+    int32_t sh_coeffs;   /* M: coefficients per colour channel stored in shs [P, M, 3]; 0 when shs == NULL */
+    int32_t channels;    /* C: composited channels. colors_precomp is [P, C]; with shs, C must be 3 */
+    int32_t bg_channels; /* number of valid floats behind bg; channels >= bg_channels read 0 (train_gaussians.py:70 passes 3 for C = 4) */
+    int32_t prefiltered;
+    int32_t debug;
+} splatraster_settings;
+
+/* ---- buffer sizing ------------------------------------------------------------------ */
+
+/* per-Gaussian forward state: projected centre, depth, conic+opacity, tile counts,
+ * depth-sorted order, instance offsets, SH colours + clamp flags. */
+size_t splatraster_geometry_bytes(int32_t P);
+/* per-tile-instance state for R = num_rendered instances: sorted point list and the
+ * sort's ping-pong buffers, plus the [tiles] range table. */
+size_t splatraster_binning_bytes(int32_t P, int64_t R, int32_t width, int32_t height);
+/* per-pixel forward state needed by backward: final transmittance, last contributor. */
+size_t splatraster_image_bytes(int32_t width, int32_t height);
+
+/* ---- forward ------------------------------------------------------------------------- */
+
+/*
+ * Stage 1 of forward (replaces the preprocess + InclusiveSum part of the reference
+ * extension's forward).  Projects all P Gaussians, depth-sorts them, counts the tiles
+ * each touches, and returns the total number of (tile, Gaussian) instances in
+ * *num_rendered (one stream synchronisation to read a single int64).
+ *
+ * Exactly one of shs / colors_precomp and exactly one of (scales, rotations) /
+ * cov3D_precomp must be non-NULL, as the reference wrapper enforces.
+ *
+ * radii [P] int32 is an output tensor (returned 4th by GaussianRasterizer.forward).
+ */
+int splatraster_forward_geometry(const splatraster_settings* s, int32_t P,
+                                 const float* means3D,       /* [P,3] */
+                                 const float* shs,           /* [P,M,3] or NULL */
+                                 const float* opacities,     /* [P,1] */
+                                 const float* scales,        /* [P,3] or NULL */
+                                 const float* rotations,     /* [P,4] (w,x,y,z) or NULL */
+                                 const float* cov3D_precomp, /* [P,6] or NULL */
+                                 const float* viewmatrix,    /* [4,4] row-vector convention */
+                                 const float* projmatrix,    /* [4,4] view @ proj */
+                                 const float* campos,        /* [3] */
+                                 void* geometry, int32_t* radii, int64_t* num_rendered,
+                                 void* stream);
+
+/*
+ * Stage 2 of forward: instance emission, stable tile-bucket radix sort, tile ranges and
+ * front-to-back alpha compositing.  R must be the value stage 1 returned and `binning`
+ * must hold splatraster_binning_bytes(P, R, W, H) bytes.
+ *
+ * Outputs: out_color [C,H,W], out_depth [1,H,W], out_alpha [1,H,W]
+ * (the first three members of the tuple GaussianRasterizer.forward returns,
+ * gaussian_renderer/__init__.py:117).
+ */
+int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t R,
+                               const float* bg,             /* [bg_channels] */
+                               const float* colors_precomp, /* [P,C] or NULL when shs were given */
+                               void* geometry, void* binning, void* image,
+                               float* out_color, float* out_depth, float* out_alpha,
+                               void* stream);
+
+/* ---- backward ------------------------------------------------------------------------ */
+
+/*
+ * Full backward (replaces the reference extension's rasterize_gaussians_backward).
+ * Gradient outputs are OVERWRITTEN (zeroed inside).  dL_dmeans2D is [P,3] with
+ * z = 0 and xy in NDC units (pixel gradient x 0.5*W / 0.5*H), which is what
+ * GaussianModel.add_densification_stats reads (gaussian_model.py:677-679).
+ * Optional outputs (dL_dshs, dL_dcov3D, dL_dscales, dL_drotations, dL_dcolors) may be
+ * NULL when the matching forward input was NULL.
+ */
+int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R,
+                         const float* bg, const float* means3D, const float* shs,
+                         const float* colors_precomp, const float* opacities,
+                         const float* scales, const float* rotations,
+                         const float* cov3D_precomp, const float* viewmatrix,
+                         const float* projmatrix, const float* campos,
+                         const int32_t* radii,
+                         void* geometry /* read + its backward scratch area is written */,
+                         const void* binning, const void* image,
+                         const float* out_color, const float* out_depth, const float* out_alpha,
+                         const float* dL_dout_color, /* [C,H,W] */
+                         const float* dL_dout_depth, /* [1,H,W] or NULL (= zeros) */
+                         const float* dL_dout_alpha, /* [1,H,W] or NULL (= zeros) */
+                         float* dL_dmeans3D,   /* [P,3] */
+                         float* dL_dmeans2D,   /* [P,3] */
+                         float* dL_dcolors,    /* [P,C] or NULL */
+                         float* dL_dopacities, /* [P,1] */
+                         float* dL_dscales,    /* [P,3] or NULL */
+                         float* dL_drotations, /* [P,4] or NULL */
+                         float* dL_dcov3D,     /* [P,6] or NULL */
+                         float* dL_dshs,       /* [P,M,3] or NULL */
+                         void* stream);
+
+/* ---- auxiliary entry points ---------------------------------------------------------- */
+
+/* present[i] = 1 when Gaussian i passes the near-plane test (view-space z > 0.2).
+ * Mirrors GaussianRasterizer.markVisible of the extension's Python wrapper. */
+int splatraster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
+                             const float* projmatrix, uint8_t* present, void* stream);
+
+/* Debug / test introspection: byte offsets of the arrays inside the opaque buffers. */
+typedef struct splatraster_geometry_layout {
+    size_t rec0;          /* float4[P]: pixel x, pixel y, view depth, radius (float, 0 = culled) */
+    size_t rec1;          /* float4[P]: conic a, b, c, opacity */
+    size_t tiles_touched; /* uint32[P] (original index order) */
+    size_t depth_order;   /* uint32[P]: Gaussian indices, stable-sorted by depth bits (culled last) */
+    size_t offsets;       /* uint32[P]: inclusive scan of tiles_touched in depth_order */
+    size_t rgb;           /* float[3P]: SH colours (only with shs) */
+    size_t clamped;       /* uint8[3P]: SH clamp flags (only with shs) */
+    size_t total;
+} splatraster_geometry_layout;
+typedef struct splatraster_binning_layout {
+    size_t point_list; /* uint32[R]: Gaussian index per instance, sorted by (tile, depth, index) */
+    size_t tile_list;  /* uint32[R]: tile id per sorted instance */
+    size_t ranges;     /* uint32[2*tiles]: [start, end) per tile */
+    size_t total;
+} splatraster_binning_layout;
+typedef struct splatraster_image_layout {
+    size_t final_T;   /* float[H*W] */
+    size_t n_contrib; /* uint32[H*W] */
+    size_t total;
+} splatraster_image_layout;
+int splatraster_get_geometry_layout(int32_t P, splatraster_geometry_layout* out);
+int splatraster_get_binning_layout(int32_t P, int64_t R, int32_t width, int32_t height,
+                                   splatraster_binning_layout* out);
+int splatraster_get_image_layout(int32_t width, int32_t height, splatraster_image_layout* out);
+
+/* Stable LSD radix sort of (key, value) pairs on key bits [0, key_bits); exposed so the
+ * sort can be tested and timed on its own.  tmp must hold splatraster_sort_tmp_bytes(n). */
+size_t splatraster_sort_tmp_bytes(int64_t n);
+int splatraster_sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, int32_t key_bits,
+                               void* tmp, void* stream);
+
+/* ---- simple_knn._C.distCUDA2 (gaussian_model.py:206) ---------------------------------- */
+
+size_t splatknn_workspace_bytes(int32_t N);
+/* out[i] = mean of the squared distances from points[i] to its 3 nearest other points. */
+int splatknn_dist2(int32_t N, const float* points /* [N,3] */, float* out /* [N] */,
+                   void* workspace, void* stream);
+
+/* ---- misc ---------------------------------------------------------------------------- */
+
+const char* splatraster_error_string(int status);
+/* last HIP error text recorded by this thread (empty string when none). */
+const char* splatraster_last_hip_error(void);
+int splatraster_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLATRASTER_H */

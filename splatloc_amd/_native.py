@@ -1,0 +1,105 @@
+"""ctypes binding of libsplatraster.so (C ABI: include/splatraster.h).
+
+Fails loudly when the HIP library is missing and cannot be built: the product path never
+falls back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+OK = 0
+_ERR_NAMES = {1: "bad argument", 2: "HIP runtime error", 3: "unsupported configuration",
+              4: "tile instance count overflow"}
+
+
+class Settings(C.Structure):
+    """struct splatraster_settings"""
+    _fields_ = [
+        ("image_height", C.c_int32),
+        ("image_width", C.c_int32),
+        ("tanfovx", C.c_float),
+        ("tanfovy", C.c_float),
+        ("scale_modifier", C.c_float),
+        ("sh_degree", C.c_int32),
+        ("sh_coeffs", C.c_int32),
+        ("channels", C.c_int32),
+        ("bg_channels", C.c_int32),
+        ("prefiltered", C.c_int32),
+        ("debug", C.c_int32),
+    ]
+
+
+class GeometryLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in
+                ("rec0", "rec1", "tiles_touched", "depth_order", "offsets", "rgb", "clamped", "total")]
+
+
+class BinningLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("point_list", "tile_list", "ranges", "total")]
+
+
+class ImageLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "total")]
+
+
+# every symbol include/splatraster.h declares: (name, restype, argtypes)
+_vp, _i32, _i64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+SYMBOLS = {
+    "splatraster_geometry_bytes": (_sz, [_i32]),
+    "splatraster_binning_bytes": (_sz, [_i32, _i64, _i32, _i32]),
+    "splatraster_image_bytes": (_sz, [_i32, _i32]),
+    "splatraster_forward_geometry": (C.c_int, [C.POINTER(Settings), _i32] + [_vp] * 9 + [_vp, _vp, C.POINTER(_i64), _vp]),
+    "splatraster_forward_render": (C.c_int, [C.POINTER(Settings), _i32, _i64] + [_vp] * 9),
+    "splatraster_backward": (C.c_int, [C.POINTER(Settings), _i32, _i64] + [_vp] * 30),
+    "splatraster_mark_visible": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
+    "splatraster_get_geometry_layout": (C.c_int, [_i32, C.POINTER(GeometryLayout)]),
+    "splatraster_get_binning_layout": (C.c_int, [_i32, _i64, _i32, _i32, C.POINTER(BinningLayout)]),
+    "splatraster_get_image_layout": (C.c_int, [_i32, _i32, C.POINTER(ImageLayout)]),
+    "splatraster_sort_tmp_bytes": (_sz, [_i64]),
+    "splatraster_sort_pairs_u32": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _vp]),
+    "splatknn_workspace_bytes": (_sz, [_i32]),
+    "splatknn_dist2": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
+    "splatraster_error_string": (C.c_char_p, [C.c_int]),
+    "splatraster_last_hip_error": (C.c_char_p, []),
+    "splatraster_abi_version": (C.c_int, []),
+}
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True):
+    """Load (building first when possible) the HIP library; raise if unavailable."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is missing: run `python -m splatloc_amd.build`")
+        try:
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            raise RuntimeError(
+                "splatloc_amd: the HIP extension libsplatraster.so is missing and could not be built "
+                f"({e}). There is no CPU fallback.") from e
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != OK:
+        lib = load()
+        detail = lib.splatraster_last_hip_error().decode() if status == 2 else ""
+        raise RuntimeError(f"{what} failed: {_ERR_NAMES.get(status, status)} {detail}".strip())

@@ -1,0 +1,104 @@
+// binning.hip — depth keys, tile-instance emission and per-tile ranges.
+//
+// The lineage sorts R = sum(tiles_touched) 64-bit (tile | depth) keys with 6 radix passes.
+// Here the same ordering (tile, depth bits, Gaussian index) is produced with far less
+// traffic:
+//   1. stable sort of the P Gaussians by depth bits (32-bit keys, P elements);
+//   2. instances are emitted IN DEPTH ORDER, one thread per instance (coalesced writes);
+//   3. a stable sort of the R instances on the tile id only (<= 16 bits, 2 passes).
+// Because both sorts are stable, ties resolve exactly as in the 64-bit formulation.
+#include "common.h"
+
+namespace sr {
+
+__device__ __forceinline__ int f2i_sat_b(float v)
+{
+    if (!(v > -1.0e9f)) v = -1.0e9f;
+    if (!(v < 1.0e9f)) v = 1.0e9f;
+    return (int)v;
+}
+
+__global__ void __launch_bounds__(256)
+depth_keys_kernel(int P, const float4* __restrict__ rec0, uint32_t* __restrict__ keys,
+                  uint32_t* __restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    // view depth > 0.2 for every visible Gaussian, so its IEEE bits order like the value
+    const float4 r = rec0[i];
+    keys[i] = r.w > 0.f ? __float_as_uint(r.z) : 0xFFFFFFFFu;
+    vals[i] = (uint32_t)i;
+}
+
+int launch_depth_keys(int32_t P, const GeomView& g, hipStream_t stream)
+{
+    if (P == 0) return SPLATRASTER_OK;
+    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.rec0, g.sort_keys,
+                       g.depth_order);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
+// one thread per instance j: rank r = first r with offsets[r] > j (offsets = inclusive scan
+// of tiles_touched in depth order), k = j - offsets[r-1] is the tile slot inside the rect.
+__global__ void __launch_bounds__(256)
+emit_kernel(int64_t R, int P, int W, int H, const uint32_t* __restrict__ offsets,
+            const uint32_t* __restrict__ depth_order, const float4* __restrict__ rec0,
+            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    const uint32_t ju = (uint32_t)j;
+    int lo = 0, hi = P;  // find first r in [0, P) with offsets[r] > j
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] > ju) hi = mid; else lo = mid + 1;
+    }
+    const int r = lo;
+    const uint32_t prev = r > 0 ? offsets[r - 1] : 0u;
+    const uint32_t k = ju - prev;
+    const uint32_t g = depth_order[r];
+    const float4 p = rec0[g];
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const float rf = p.w;  // integer-valued radius stored by preprocess
+    const int rminx = min(gx, max(0, f2i_sat_b((p.x - rf) / (float)TILE)));
+    const int rminy = min(gy, max(0, f2i_sat_b((p.y - rf) / (float)TILE)));
+    const int rmaxx = min(gx, max(0, f2i_sat_b((p.x + rf + (float)(TILE - 1)) / (float)TILE)));
+    const uint32_t w = (uint32_t)(rmaxx - rminx);
+    const uint32_t ty = (uint32_t)rminy + k / w, tx = (uint32_t)rminx + k % w;
+    keys[j] = ty * (uint32_t)gx + tx;
+    vals[j] = g;
+}
+
+int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
+                uint32_t* vals, hipStream_t stream)
+{
+    if (R == 0) return SPLATRASTER_OK;
+    const int64_t blocks = (R + 255) / 256;
+    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, R, P, s.image_width,
+                       s.image_height, g.offsets, g.depth_order, g.rec0, keys, vals);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
+__global__ void __launch_bounds__(256)
+ranges_kernel(int64_t R, const uint32_t* __restrict__ tile_list, uint32_t* __restrict__ ranges)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    const uint32_t t = tile_list[j];
+    if (j == 0 || tile_list[j - 1] != t) ranges[2 * t] = (uint32_t)j;
+    if (j == R - 1 || tile_list[j + 1] != t) ranges[2 * t + 1] = (uint32_t)(j + 1);
+}
+
+int launch_ranges(int64_t R, int32_t tiles, const uint32_t* tile_list, uint32_t* ranges, hipStream_t stream)
+{
+    SR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)tiles, stream));
+    if (R == 0) return SPLATRASTER_OK;
+    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, tile_list,
+                       ranges);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
+}  // namespace sr

@@ -1,0 +1,360 @@
+// capi.hip — the C ABI declared in include/splatraster.h: buffer layouts, argument
+// validation and stage sequencing.  No torch types; everything is raw device pointers.
+#include <string.h>
+
+#include <string>
+
+#include "common.h"
+
+namespace sr {
+
+static thread_local std::string g_last_error;
+
+void set_hip_error(hipError_t e, const char* what)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+
+static inline int tile_bits(int tiles)
+{
+    int b = 1;
+    while ((1 << b) < tiles) ++b;
+    return b;
+}
+
+struct GeomLayout {
+    size_t rec0, rec1, tiles_touched, depth_order, offsets, rgb, clamped, sort_keys, keys_alt, vals_alt,
+        sort_tmp, scan_tmp, total, ggrad, drgb, bytes;
+};
+static GeomLayout geom_layout(int32_t P)
+{
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    GeomLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    L.rec0 = take(16 * n);
+    L.rec1 = take(16 * n);
+    L.tiles_touched = take(4 * n);
+    L.depth_order = take(4 * n);
+    L.offsets = take(4 * n);
+    L.rgb = take(12 * n);
+    L.clamped = take(3 * n);
+    L.sort_keys = take(4 * n);
+    L.keys_alt = take(4 * n);
+    L.vals_alt = take(4 * n);
+    L.sort_tmp = take(sort_tmp_bytes((int64_t)n));
+    L.scan_tmp = take(scan_tmp_bytes((int64_t)n));
+    L.total = take(16);
+    L.ggrad = take(32 * n);
+    L.drgb = take(12 * n);
+    L.bytes = o;
+    return L;
+}
+
+GeomView geom_view(void* base, int32_t P)
+{
+    const GeomLayout L = geom_layout(P);
+    char* b = reinterpret_cast<char*>(base);
+    GeomView g;
+    g.rec0 = reinterpret_cast<float4*>(b + L.rec0);
+    g.rec1 = reinterpret_cast<float4*>(b + L.rec1);
+    g.tiles_touched = reinterpret_cast<uint32_t*>(b + L.tiles_touched);
+    g.depth_order = reinterpret_cast<uint32_t*>(b + L.depth_order);
+    g.offsets = reinterpret_cast<uint32_t*>(b + L.offsets);
+    g.rgb = reinterpret_cast<float*>(b + L.rgb);
+    g.clamped = reinterpret_cast<uint8_t*>(b + L.clamped);
+    g.sort_keys = reinterpret_cast<uint32_t*>(b + L.sort_keys);
+    g.sort_tmp = reinterpret_cast<uint32_t*>(b + L.sort_tmp);
+    g.total = reinterpret_cast<uint32_t*>(b + L.total);
+    g.ggrad = reinterpret_cast<float*>(b + L.ggrad);
+    g.drgb = reinterpret_cast<float*>(b + L.drgb);
+    return g;
+}
+
+struct BinLayout {
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, bytes;
+};
+static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
+{
+    const size_t n = (size_t)(R > 0 ? R : 1);
+    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * (size_t)((H + TILE - 1) / TILE);
+    BinLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    L.valsA = take(4 * n);
+    L.keysA = take(4 * n);
+    L.keysB = take(4 * n);
+    L.valsB = take(4 * n);
+    L.ranges = take(8 * (tiles > 0 ? tiles : 1));
+    L.sort_tmp = take(sort_tmp_bytes((int64_t)n));
+    L.bytes = o;
+    return L;
+}
+
+BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H)
+{
+    (void)P;
+    const BinLayout L = bin_layout(R, W, H);
+    char* b = reinterpret_cast<char*>(base);
+    BinView v;
+    v.point_list = reinterpret_cast<uint32_t*>(b + L.valsA);
+    v.tile_list = reinterpret_cast<uint32_t*>(b + L.keysA);
+    v.keys_tmp = reinterpret_cast<uint32_t*>(b + L.keysB);
+    v.vals_tmp = reinterpret_cast<uint32_t*>(b + L.valsB);
+    v.ranges = reinterpret_cast<uint32_t*>(b + L.ranges);
+    v.sort_tmp = b + L.sort_tmp;
+    return v;
+}
+
+ImgView img_view(void* base, int32_t W, int32_t H)
+{
+    char* b = reinterpret_cast<char*>(base);
+    ImgView v;
+    v.final_T = reinterpret_cast<float*>(b);
+    v.n_contrib = reinterpret_cast<uint32_t*>(b + align_up((size_t)W * H * 4, 256));
+    return v;
+}
+
+static int check_settings(const splatraster_settings* s)
+{
+    if (!s) return SPLATRASTER_ERR_BAD_ARG;
+    if (s->image_width <= 0 || s->image_height <= 0 || s->channels <= 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (s->bg_channels < 0) return SPLATRASTER_ERR_BAD_ARG;
+    return SPLATRASTER_OK;
+}
+
+}  // namespace sr
+
+using namespace sr;
+
+extern "C" {
+
+int splatraster_abi_version(void) { return 1; }
+
+const char* splatraster_error_string(int status)
+{
+    switch (status) {
+        case SPLATRASTER_OK: return "ok";
+        case SPLATRASTER_ERR_BAD_ARG: return "bad argument";
+        case SPLATRASTER_ERR_HIP: return "HIP runtime error";
+        case SPLATRASTER_ERR_UNSUPPORTED: return "unsupported configuration";
+        case SPLATRASTER_ERR_OVERFLOW: return "tile instance count overflow";
+        default: return "unknown status";
+    }
+}
+
+const char* splatraster_last_hip_error(void) { return g_last_error.c_str(); }
+
+size_t splatraster_geometry_bytes(int32_t P) { return geom_layout(P).bytes; }
+size_t splatraster_binning_bytes(int32_t P, int64_t R, int32_t width, int32_t height)
+{
+    (void)P;
+    return bin_layout(R, width, height).bytes;
+}
+size_t splatraster_image_bytes(int32_t width, int32_t height)
+{
+    return 2 * align_up((size_t)width * height * 4, 256);
+}
+
+int splatraster_get_geometry_layout(int32_t P, splatraster_geometry_layout* out)
+{
+    if (!out) return SPLATRASTER_ERR_BAD_ARG;
+    const GeomLayout L = geom_layout(P);
+    out->rec0 = L.rec0; out->rec1 = L.rec1; out->tiles_touched = L.tiles_touched;
+    out->depth_order = L.depth_order; out->offsets = L.offsets; out->rgb = L.rgb;
+    out->clamped = L.clamped; out->total = L.bytes;
+    return SPLATRASTER_OK;
+}
+int splatraster_get_binning_layout(int32_t P, int64_t R, int32_t width, int32_t height,
+                                   splatraster_binning_layout* out)
+{
+    (void)P;
+    if (!out) return SPLATRASTER_ERR_BAD_ARG;
+    const BinLayout L = bin_layout(R, width, height);
+    out->point_list = L.valsA; out->tile_list = L.keysA; out->ranges = L.ranges; out->total = L.bytes;
+    return SPLATRASTER_OK;
+}
+int splatraster_get_image_layout(int32_t width, int32_t height, splatraster_image_layout* out)
+{
+    if (!out) return SPLATRASTER_ERR_BAD_ARG;
+    out->final_T = 0;
+    out->n_contrib = align_up((size_t)width * height * 4, 256);
+    out->total = splatraster_image_bytes(width, height);
+    return SPLATRASTER_OK;
+}
+
+int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const float* means3D,
+                                 const float* shs, const float* opacities, const float* scales,
+                                 const float* rotations, const float* cov3D_precomp,
+                                 const float* viewmatrix, const float* projmatrix, const float* campos,
+                                 void* geometry, int32_t* radii, int64_t* num_rendered, void* stream_)
+{
+    int st = check_settings(s);
+    if (st) return st;
+    if (P < 0 || !num_rendered) return SPLATRASTER_ERR_BAD_ARG;
+    *num_rendered = 0;
+    if (P == 0) return SPLATRASTER_OK;
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !geometry || !radii) return SPLATRASTER_ERR_BAD_ARG;
+    const bool have_sr = scales && rotations;
+    if (have_sr == (cov3D_precomp != nullptr)) return SPLATRASTER_ERR_BAD_ARG;
+    if ((scales == nullptr) != (rotations == nullptr)) return SPLATRASTER_ERR_BAD_ARG;
+    if (shs) {
+        if (s->channels != 3 || !campos) return SPLATRASTER_ERR_BAD_ARG;
+        if (s->sh_degree < 0 || s->sh_degree > 3) return SPLATRASTER_ERR_UNSUPPORTED;
+        if (s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1)) return SPLATRASTER_ERR_BAD_ARG;
+    }
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const GeomLayout L = geom_layout(P);
+    GeomView g = geom_view(geometry, P);
+    char* base = reinterpret_cast<char*>(geometry);
+    st = launch_preprocess(*s, P, means3D, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                           projmatrix, campos, g, radii, stream);
+    if (st) return st;
+    st = launch_depth_keys(P, g, stream);
+    if (st) return st;
+    bool in_alt = false;
+    uint32_t* keys_alt = reinterpret_cast<uint32_t*>(base + L.keys_alt);
+    uint32_t* vals_alt = reinterpret_cast<uint32_t*>(base + L.vals_alt);
+    st = sort_pairs_u32(P, g.sort_keys, g.depth_order, keys_alt, vals_alt, 32, g.sort_tmp, stream, &in_alt);
+    if (st) return st;
+    if (in_alt) return SPLATRASTER_ERR_UNSUPPORTED;  // 4 passes: never
+    st = inclusive_scan_u32(P, g.tiles_touched, g.depth_order, g.offsets, g.total, base + L.scan_tmp, stream);
+    if (st) return st;
+    uint64_t total = 0;
+    SR_HIP_CHECK(hipMemcpyAsync(&total, g.total, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    SR_HIP_CHECK(hipStreamSynchronize(stream));
+    if (total >= ((uint64_t)1 << 31)) return SPLATRASTER_ERR_OVERFLOW;
+    *num_rendered = (int64_t)total;
+    return SPLATRASTER_OK;
+}
+
+int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t R, const float* bg,
+                               const float* colors_precomp, void* geometry, void* binning, void* image,
+                               float* out_color, float* out_depth, float* out_alpha, void* stream_)
+{
+    int st = check_settings(s);
+    if (st) return st;
+    if (P < 0 || R < 0 || !image || !out_color || !out_depth || !out_alpha) return SPLATRASTER_ERR_BAD_ARG;
+    if (s->bg_channels > 0 && !bg) return SPLATRASTER_ERR_BAD_ARG;
+    if (P > 0 && (!geometry || !binning)) return SPLATRASTER_ERR_BAD_ARG;
+    if (R > 0 && !binning) return SPLATRASTER_ERR_BAD_ARG;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int W = s->image_width, H = s->image_height;
+    const int tiles = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    ImgView im = img_view(image, W, H);
+    GeomView g{};
+    if (geometry) g = geom_view(geometry, P);
+    if (!binning) return SPLATRASTER_ERR_BAD_ARG;
+    BinView b = bin_view(binning, P, R, W, H);
+    const float* feat = colors_precomp ? colors_precomp : g.rgb;
+    if (R > 0 && !feat) return SPLATRASTER_ERR_BAD_ARG;
+    const int bits = tile_bits(tiles);
+    const int passes = (bits + 7) / 8;
+    // emit into the buffer pair from which `passes` ping-pongs end in (tile_list, point_list)
+    uint32_t* k0 = (passes & 1) ? b.keys_tmp : b.tile_list;
+    uint32_t* v0 = (passes & 1) ? b.vals_tmp : b.point_list;
+    uint32_t* k1 = (passes & 1) ? b.tile_list : b.keys_tmp;
+    uint32_t* v1 = (passes & 1) ? b.point_list : b.vals_tmp;
+    if (R > 0) {
+        st = launch_emit(*s, P, R, g, k0, v0, stream);
+        if (st) return st;
+        bool in_alt = false;
+        st = sort_pairs_u32(R, k0, v0, k1, v1, bits, b.sort_tmp, stream, &in_alt);
+        if (st) return st;
+    }
+    st = launch_ranges(R, tiles, b.tile_list, b.ranges, stream);
+    if (st) return st;
+    return launch_composite_fwd(*s, R, g, b, im, feat, bg, out_color, out_depth, out_alpha, stream);
+}
+
+int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, const float* bg,
+                         const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* opacities, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                         const float* campos, const int32_t* radii, void* geometry,
+                         const void* binning, const void* image, const float* out_color,
+                         const float* out_depth, const float* out_alpha, const float* dL_dout_color,
+                         const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans3D,
+                         float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
+                         float* dL_drotations, float* dL_dcov3D, float* dL_dshs, void* stream_)
+{
+    (void)bg; (void)opacities; (void)out_alpha;
+    int st = check_settings(s);
+    if (st) return st;
+    if (P < 0 || R < 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (P == 0) return SPLATRASTER_OK;
+    if (!means3D || !viewmatrix || !projmatrix || !radii || !geometry || !binning || !image || !out_color ||
+        !out_depth || !dL_dout_color || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacities)
+        return SPLATRASTER_ERR_BAD_ARG;
+    if (shs && (!dL_dshs || !campos)) return SPLATRASTER_ERR_BAD_ARG;
+    if (!shs && (!colors_precomp || !dL_dcolors)) return SPLATRASTER_ERR_BAD_ARG;
+    if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
+        return SPLATRASTER_ERR_BAD_ARG;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int W = s->image_width, H = s->image_height;
+    GeomView g = geom_view(geometry, P);
+    BinView b = bin_view(const_cast<void*>(binning), P, R, W, H);
+    ImgView im = img_view(const_cast<void*>(image), W, H);
+    const int C = s->channels;
+    const float* feat = shs ? g.rgb : colors_precomp;
+    float* dcol = shs ? g.drgb : dL_dcolors;
+    SR_HIP_CHECK(hipMemsetAsync(g.ggrad, 0, sizeof(float) * 8 * (size_t)P, stream));
+    SR_HIP_CHECK(hipMemsetAsync(dcol, 0, sizeof(float) * (size_t)C * (size_t)P, stream));
+    st = launch_composite_bwd(*s, P, R, g, b, im, feat, C, out_color, out_depth, dL_dout_color, dL_dout_depth,
+                              dL_dout_alpha, g.ggrad, dcol, stream);
+    if (st) return st;
+    return launch_preprocess_bwd(*s, P, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                                 campos, radii, g.clamped, g.ggrad, g.drgb, dL_dmeans3D, dL_dmeans2D,
+                                 dL_dopacities, cov3D_precomp ? nullptr : dL_dscales,
+                                 cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr,
+                                 dL_dshs, stream);
+}
+
+int splatraster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
+                             const float* projmatrix, uint8_t* present, void* stream)
+{
+    (void)projmatrix;
+    if (P < 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (P == 0) return SPLATRASTER_OK;
+    if (!means3D || !viewmatrix || !present) return SPLATRASTER_ERR_BAD_ARG;
+    return launch_mark_visible(P, means3D, viewmatrix, present, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t splatraster_sort_tmp_bytes(int64_t n)
+{
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    return align_up(4 * m, 256) * 2 + sort_tmp_bytes(n);
+}
+
+int splatraster_sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, int32_t key_bits, void* tmp,
+                               void* stream_)
+{
+    if (n < 0 || key_bits < 0 || key_bits > 32) return SPLATRASTER_ERR_BAD_ARG;
+    if (n == 0 || key_bits == 0) return SPLATRASTER_OK;
+    if (!keys || !vals || !tmp) return SPLATRASTER_ERR_BAD_ARG;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    char* t = reinterpret_cast<char*>(tmp);
+    const size_t stride = align_up(4 * (size_t)n, 256);
+    uint32_t* ka = reinterpret_cast<uint32_t*>(t);
+    uint32_t* va = reinterpret_cast<uint32_t*>(t + stride);
+    bool in_alt = false;
+    int st = sort_pairs_u32(n, keys, vals, ka, va, key_bits, t + 2 * stride, stream, &in_alt);
+    if (st) return st;
+    if (in_alt) {
+        SR_HIP_CHECK(hipMemcpyAsync(keys, ka, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream));
+        SR_HIP_CHECK(hipMemcpyAsync(vals, va, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    }
+    return SPLATRASTER_OK;
+}
+
+size_t splatknn_workspace_bytes(int32_t N) { return knn_workspace_bytes(N); }
+
+int splatknn_dist2(int32_t N, const float* points, float* out, void* workspace, void* stream)
+{
+    if (N < 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (N == 0) return SPLATRASTER_OK;
+    if (!points || !out || !workspace) return SPLATRASTER_ERR_BAD_ARG;
+    return knn_dist2(N, points, out, workspace, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// common.h — shared declarations of the gfx950 rasterizer kernels (internal; the public
+// contract is include/splatraster.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/splatraster.h"
+
+namespace sr {
+
+constexpr int TILE = SPLATRASTER_TILE;
+constexpr int TILE_PIX = TILE * TILE;
+constexpr float NEAR_Z = 0.2f;
+constexpr float DILATION = 0.3f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_EPS = 0.0001f;
+constexpr int WAVE = 64;
+
+// thread-local last-error text, filled by SR_HIP_CHECK
+void set_hip_error(hipError_t e, const char* what);
+
+#define SR_HIP_CHECK(expr)                                 \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) {                            \
+            ::sr::set_hip_error(_e, #expr);                \
+            return SPLATRASTER_ERR_HIP;                    \
+        }                                                  \
+    } while (0)
+
+#define SR_LAUNCH_CHECK()                                  \
+    do {                                                   \
+        hipError_t _e = hipGetLastError();                 \
+        if (_e != hipSuccess) {                            \
+            ::sr::set_hip_error(_e, "kernel launch");      \
+            return SPLATRASTER_ERR_HIP;                    \
+        }                                                  \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- opaque buffer views -------------------------------------------------------------
+struct GeomView {
+    float4* rec0;            // px, py, depth, radius (as float; 0 = culled)
+    float4* rec1;            // conic a, b, c, opacity
+    uint32_t* tiles_touched; // [P] original order
+    uint32_t* depth_order;   // [P] gaussian ids sorted by depth
+    uint32_t* offsets;       // [P] inclusive scan of tiles_touched in depth order
+    float* rgb;              // [3P]
+    uint8_t* clamped;        // [3P]
+    uint32_t* sort_keys;     // [P] scratch (depth bits)
+    uint32_t* sort_tmp;      // scratch for the P-sized sort + scan partials
+    uint32_t* total;         // [2] device-side R (uint64 as two words)
+    float* ggrad;            // [8P] backward scratch: per-Gaussian geometric gradient records
+    float* drgb;             // [3P] backward scratch: dL/d(SH colour)
+};
+struct BinView {
+    uint32_t* point_list; // [R] sorted gaussian ids
+    uint32_t* tile_list;  // [R] sorted tile ids
+    uint32_t* ranges;     // [2*tiles]
+    uint32_t* keys_tmp;   // [R] unsorted tile ids
+    uint32_t* vals_tmp;   // [R] unsorted gaussian ids
+    void* sort_tmp;       // radix sort scratch
+};
+struct ImgView {
+    float* final_T;
+    uint32_t* n_contrib;
+};
+
+GeomView geom_view(void* base, int32_t P);
+BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H);
+ImgView img_view(void* base, int32_t W, int32_t H);
+
+// ---- stage launchers (each returns a SPLATRASTER_* status) -----------------------------
+int launch_preprocess(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
+                      const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp, const float* view, const float* proj,
+                      const float* campos, GeomView g, int32_t* radii, hipStream_t stream);
+int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
+                          const float* scales, const float* rotations, const float* cov3D_precomp,
+                          const float* view, const float* proj, const float* campos, const int32_t* radii,
+                          const uint8_t* clamped, const float* ggrad, const float* dcolors_rgb,
+                          float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
+                          float* dL_drotations, float* dL_dcov3D, float* dL_dshs, hipStream_t stream);
+int launch_mark_visible(int32_t P, const float* means3D, const float* view, uint8_t* present,
+                        hipStream_t stream);
+
+size_t sort_tmp_bytes(int64_t n);
+int sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
+                   int key_bits, void* tmp, hipStream_t stream, bool* result_in_alt);
+// inclusive scan of in[perm[i]] (perm may be null) into out[i]; total (u64 as 2 words) optional
+size_t scan_tmp_bytes(int64_t n);
+int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_t* out, uint32_t* total,
+                       void* tmp, hipStream_t stream);
+
+int launch_depth_keys(int32_t P, const GeomView& g, hipStream_t stream);
+int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
+                uint32_t* vals, hipStream_t stream);
+int launch_ranges(int64_t R, int32_t tiles, const uint32_t* tile_list, uint32_t* ranges, hipStream_t stream);
+
+int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b,
+                         const ImgView& im, const float* feat, const float* bg, float* out_color,
+                         float* out_depth, float* out_alpha, hipStream_t stream);
+int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g,
+                         const BinView& b, const ImgView& im, const float* feat, int feat_stride,
+                         const float* out_color, const float* out_depth, const float* dL_dcolor,
+                         const float* dL_ddepth, const float* dL_dalpha,
+                         float* ggrad /*[P,8]: dmean2D.xy, dconic.abc, dopacity, ddepth, pad*/,
+                         float* dcolors /*[P,C]*/, hipStream_t stream);
+
+int knn_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream);
+size_t knn_workspace_bytes(int32_t N);
+
+}  // namespace sr

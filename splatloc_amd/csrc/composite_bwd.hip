@@ -1,0 +1,254 @@
+// composite_bwd.hip — backward of the alpha compositing (SURVEY.md §8a "COMPOSITE bwd").
+//
+// Replaces the render-backward stage of the rasterizer extension whose backward is
+// triggered at train_gaussians.py:229 / :286.
+//
+// Formulation (differs from the lineage's back-to-front accum_rec recurrences, same
+// derivative): with w_i = alpha_i T_i, q_i = f_i . g + z_i g_D  (g = dL/dcolor at the pixel)
+//     S_total = out_color . g + out_depth g_D - T_final g_A
+//     S_i     = S_total - sum_{j<=i} w_j q_j            (suffix sum incl. background/alpha terms)
+//     dL/dalpha_i = T_i q_i - S_i / (1 - alpha_i)
+// so the pass runs FRONT-TO-BACK exactly like the forward (same arithmetic for alpha and
+// T, no division T/(1-alpha) to undo transmittance) and needs one dot product per
+// (pixel, Gaussian) instead of three per-channel recurrences.  Everything is linear in
+// (g, g_D, g_A), so channels can be split over several launches (generic C).
+//
+// Per (wave, Gaussian): 7 geometric partials + NC colour partials are reduced over the 64
+// pixels of the wave's 8x8 quadrant with DPP row reductions (no LDS traffic), gathered
+// into distinct lanes, and flushed with ONE wave-wide float atomic (contiguous addresses:
+// dL_dcolors row + the 32-byte geometric-gradient record of the Gaussian).
+#include "common.h"
+
+namespace sr {
+
+constexpr int CB_THREADS = 256;
+
+template <int NC>
+struct BwdCfg {
+    static constexpr int NCP = (NC + 3) & ~3;
+    static constexpr int BATCH = (NC > 16) ? 128 : 256;
+};
+
+// ---- DPP helpers (wave64 = 4 rows of 16 lanes) -----------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+// full 64-lane sum; the total is valid in lanes 48..63 (row 3)
+__device__ __forceinline__ float wave_sum_row3(float v)
+{
+    v += dpp_get<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_get<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_get<0x140, 0xf>(v);  // row_mirror       -> every lane holds its row's sum
+    v += dpp_get<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_get<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ float lane63(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int NC>
+__global__ void __launch_bounds__(CB_THREADS)
+composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
+                     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                     const float4* __restrict__ rec0, const float4* __restrict__ rec1,
+                     const float* __restrict__ feat, const float* __restrict__ out_color,
+                     const float* __restrict__ out_depth, const float* __restrict__ final_T,
+                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
+                     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
+                     float* __restrict__ ggrad /*[P,8]*/, float* __restrict__ dcolors /*[P,C_total]*/)
+{
+    constexpr int NCP = BwdCfg<NC>::NCP;
+    constexpr int BATCH = BwdCfg<NC>::BATCH;
+    __shared__ __attribute__((aligned(16))) float4 s_rec0[BATCH];
+    __shared__ __attribute__((aligned(16))) float4 s_rec1[BATCH];
+    __shared__ __attribute__((aligned(16))) float s_feat[BATCH * NCP];
+    __shared__ uint32_t s_id[BATCH];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = tid / WAVE;
+    const int gx = (W + TILE - 1) / TILE;
+    const int tile = blockIdx.y * gx + blockIdx.x;
+    const int px = blockIdx.x * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = blockIdx.y * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const size_t plane = (size_t)H * W;
+    const size_t pix = inside ? (size_t)py * W + px : 0;
+
+    const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+
+    // per-pixel constants
+    float g[NC];
+    float S = 0.0f;  // running suffix sum
+    float gD = 0.0f;
+    uint32_t last = 0;
+    if (inside) {
+        last = n_contrib[pix];
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            g[ch] = dL_dcolor[(size_t)(c0 + ch) * plane + pix];
+            S += out_color[(size_t)(c0 + ch) * plane + pix] * g[ch];
+        }
+        if (first_pass) {
+            gD = dL_ddepth ? dL_ddepth[pix] : 0.0f;
+            const float gA = dL_dalpha ? dL_dalpha[pix] : 0.0f;
+            S += out_depth[pix] * gD - final_T[pix] * gA;
+        }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) g[ch] = 0.0f;
+    }
+    // the tile only needs the list up to its deepest contributor
+    uint32_t max_last = last;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) max_last = max(max_last, (uint32_t)__shfl_xor((int)max_last, d, WAVE));
+    __shared__ uint32_t s_max[CB_THREADS / WAVE];
+    if (lane == 0) s_max[wave] = max_last;
+    __syncthreads();
+    const uint32_t tile_last = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    const uint32_t wave_last = max_last;
+    int todo = (int)min(end - beg, tile_last);
+
+    float T = 1.0f;
+    uint32_t contributor = 0;
+    const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
+
+    for (uint32_t base = beg; todo > 0; base += BATCH, todo -= BATCH) {
+        const int nb = todo < BATCH ? todo : BATCH;
+        __syncthreads();
+        if (tid < nb) {
+            const uint32_t gi = point_list[base + tid];
+            s_id[tid] = gi;
+            s_rec0[tid] = rec0[gi];
+            s_rec1[tid] = rec1[gi];
+        }
+        __syncthreads();
+        for (int e = tid; e < nb * NC; e += CB_THREADS) {
+            const int row = e / NC, ch = e - row * NC;
+            s_feat[row * NCP + ch] = feat[(size_t)s_id[row] * C_total + c0 + ch];
+        }
+        __syncthreads();
+        const int nw = (int)min((uint32_t)nb, wave_last > contributor ? wave_last - contributor : 0u);
+        for (int j = 0; j < nw; ++j) {
+            const float4 r0 = s_rec0[j];
+            const float4 r1 = s_rec1[j];
+            const float dx = r0.x - fx, dy = r0.y - fy;
+            const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+            const float G = __expf(power);
+            const float alpha = fminf(ALPHA_MAX, r1.w * G);
+            const bool hit = (contributor + (uint32_t)j < last) && power <= 0.0f && alpha >= ALPHA_MIN;
+            if (!__any(hit)) continue;
+            const float* f = &s_feat[j * NCP];
+            const float w = hit ? alpha * T : 0.0f;
+            float q = r0.z * gD;
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) q += f[ch] * g[ch];
+            const float one_m = 1.0f - alpha;
+            float dL_dalpha_i = 0.0f;
+            if (hit) {
+                S -= w * q;
+                dL_dalpha_i = T * q - S * __frcp_rn(one_m);
+                T *= one_m;
+            }
+            const float dL_dG = r1.w * dL_dalpha_i;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
+            const float dG_ddely = -gdy * r1.z - gdx * r1.y;
+            float v[8];
+            v[0] = dL_dG * dG_ddelx * halfW;
+            v[1] = dL_dG * dG_ddely * halfH;
+            v[2] = -0.5f * gdx * dx * dL_dG;
+            v[3] = -gdx * dy * dL_dG;
+            v[4] = -0.5f * gdy * dy * dL_dG;
+            v[5] = G * dL_dalpha_i;
+            v[6] = w * gD;
+            // reduce over the wave and gather value k into lane k
+            float outv = 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) {
+                const float t = lane63(wave_sum_row3(w * g[ch]));
+                outv = (lane == ch) ? t : outv;
+            }
+            const uint32_t gi = s_id[j];
+            if (NC + 7 <= WAVE) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const float t = lane63(wave_sum_row3(v[k]));
+                    outv = (lane == NC + k) ? t : outv;
+                }
+                float* dst = (lane < NC) ? (dcolors + (size_t)gi * C_total + c0 + lane)
+                                         : (ggrad + (size_t)gi * 8 + (lane - NC));
+                if (lane < NC + 7) atomicAdd(dst, outv);
+            } else {
+                if (lane < NC) atomicAdd(dcolors + (size_t)gi * C_total + c0 + lane, outv);
+                float outg = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const float t = lane63(wave_sum_row3(v[k]));
+                    outg = (lane == k) ? t : outg;
+                }
+                if (lane < 7) atomicAdd(ggrad + (size_t)gi * 8 + lane, outg);
+            }
+        }
+        contributor += (uint32_t)nb;
+    }
+}
+
+template <int NC>
+static int launch_one_bwd(const splatraster_settings& s, int c0, int first, const GeomView& g,
+                          const BinView& b, const ImgView& im, const float* feat, int feat_stride,
+                          const float* out_color, const float* out_depth, const float* dL_dcolor,
+                          const float* dL_ddepth, const float* dL_dalpha, float* ggrad, float* dcolors,
+                          hipStream_t stream)
+{
+    const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
+    hipLaunchKernelGGL(composite_bwd_kernel<NC>, dim3(gx, gy), dim3(CB_THREADS), 0, stream, s.image_width,
+                       s.image_height, feat_stride, c0, first, b.ranges, b.point_list, g.rec0, g.rec1, feat,
+                       out_color, out_depth, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, ggrad,
+                       dcolors);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
+int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g,
+                         const BinView& b, const ImgView& im, const float* feat, int feat_stride,
+                         const float* out_color, const float* out_depth, const float* dL_dcolor,
+                         const float* dL_ddepth, const float* dL_dalpha, float* ggrad, float* dcolors,
+                         hipStream_t stream)
+{
+    (void)P;
+    if (R == 0) return SPLATRASTER_OK;
+    const int C = s.channels;
+#define SR_BWD_ARGS g, b, im, feat, feat_stride, out_color, out_depth, dL_dcolor, dL_ddepth, dL_dalpha, ggrad, dcolors, stream
+#define SR_BWD_CASE(N) \
+    case N: return launch_one_bwd<N>(s, 0, 1, SR_BWD_ARGS);
+    switch (C) {
+        SR_BWD_CASE(1) SR_BWD_CASE(2) SR_BWD_CASE(3) SR_BWD_CASE(4) SR_BWD_CASE(8) SR_BWD_CASE(16)
+        SR_BWD_CASE(32) SR_BWD_CASE(35)
+        default: break;
+    }
+#undef SR_BWD_CASE
+    int c0 = 0, first = 1, st = SPLATRASTER_OK;
+    while (c0 < C && st == SPLATRASTER_OK) {
+        const int left = C - c0;
+        if (left >= 32) { st = launch_one_bwd<32>(s, c0, first, SR_BWD_ARGS); c0 += 32; }
+        else if (left >= 16) { st = launch_one_bwd<16>(s, c0, first, SR_BWD_ARGS); c0 += 16; }
+        else if (left >= 8) { st = launch_one_bwd<8>(s, c0, first, SR_BWD_ARGS); c0 += 8; }
+        else if (left >= 4) { st = launch_one_bwd<4>(s, c0, first, SR_BWD_ARGS); c0 += 4; }
+        else if (left == 3) { st = launch_one_bwd<3>(s, c0, first, SR_BWD_ARGS); c0 += 3; }
+        else if (left == 2) { st = launch_one_bwd<2>(s, c0, first, SR_BWD_ARGS); c0 += 2; }
+        else { st = launch_one_bwd<1>(s, c0, first, SR_BWD_ARGS); c0 += 1; }
+        first = 0;
+    }
+#undef SR_BWD_ARGS
+    return st;
+}
+
+}  // namespace sr

@@ -1,0 +1,282 @@
+// preprocess_bwd.hip — per-Gaussian backward of the projection (SURVEY.md §8a
+// "PREPROCESS bwd"): conic -> cov2D -> (Sigma3, view-space mean) -> scale / quaternion /
+// mean3D, NDC mean2D -> mean3D through the projection, depth -> mean3D, SH -> (sh, mean3D).
+//
+// One thread per Gaussian; reads the 32-byte geometric-gradient record accumulated by the
+// compositing backward plus the forward inputs, writes every gradient tensor once.
+// HBM-bound: ~100 B read, ~70 B written per Gaussian.
+#include "common.h"
+
+namespace sr {
+
+__constant__ float BSH_C0 = 0.28209479177387814f;
+__constant__ float BSH_C1 = 0.4886025119029199f;
+__constant__ float BSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float BSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                -0.5900435899266435f};
+
+__device__ void sh_backward(int deg, int M, const float* sh, float* dsh, const uint8_t* clamped,
+                            const float* drgb_in, float ox, float oy, float oz, float* dmean)
+{
+    const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+    const float x = ox / len, y = oy / len, z = oz / len;
+    float ddir[3] = {0.f, 0.f, 0.f};
+    for (int ch = 0; ch < 3; ++ch) {
+        const float d = clamped[ch] ? 0.f : drgb_in[ch];
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#define SHV(k) sh[(k) * 3 + ch]
+        dsh[0 * 3 + ch] = BSH_C0 * d;
+        if (deg > 0) {
+            dsh[1 * 3 + ch] = -BSH_C1 * y * d;
+            dsh[2 * 3 + ch] = BSH_C1 * z * d;
+            dsh[3 * 3 + ch] = -BSH_C1 * x * d;
+            ddx = -BSH_C1 * SHV(3);
+            ddy = -BSH_C1 * SHV(1);
+            ddz = BSH_C1 * SHV(2);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                dsh[4 * 3 + ch] = BSH_C2[0] * xy * d;
+                dsh[5 * 3 + ch] = BSH_C2[1] * yz * d;
+                dsh[6 * 3 + ch] = BSH_C2[2] * (2.f * zz - xx - yy) * d;
+                dsh[7 * 3 + ch] = BSH_C2[3] * xz * d;
+                dsh[8 * 3 + ch] = BSH_C2[4] * (xx - yy) * d;
+                ddx += BSH_C2[0] * y * SHV(4) + BSH_C2[2] * 2.f * -x * SHV(6) + BSH_C2[3] * z * SHV(7) + BSH_C2[4] * 2.f * x * SHV(8);
+                ddy += BSH_C2[0] * x * SHV(4) + BSH_C2[1] * z * SHV(5) + BSH_C2[2] * 2.f * -y * SHV(6) + BSH_C2[4] * 2.f * -y * SHV(8);
+                ddz += BSH_C2[1] * y * SHV(5) + BSH_C2[2] * 4.f * z * SHV(6) + BSH_C2[3] * x * SHV(7);
+                if (deg > 2) {
+                    dsh[9 * 3 + ch] = BSH_C3[0] * y * (3.f * xx - yy) * d;
+                    dsh[10 * 3 + ch] = BSH_C3[1] * xy * z * d;
+                    dsh[11 * 3 + ch] = BSH_C3[2] * y * (4.f * zz - xx - yy) * d;
+                    dsh[12 * 3 + ch] = BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * d;
+                    dsh[13 * 3 + ch] = BSH_C3[4] * x * (4.f * zz - xx - yy) * d;
+                    dsh[14 * 3 + ch] = BSH_C3[5] * z * (xx - yy) * d;
+                    dsh[15 * 3 + ch] = BSH_C3[6] * x * (xx - 3.f * yy) * d;
+                    ddx += BSH_C3[0] * SHV(9) * 6.f * xy + BSH_C3[1] * SHV(10) * yz + BSH_C3[2] * SHV(11) * -2.f * xy +
+                           BSH_C3[3] * SHV(12) * -6.f * xz + BSH_C3[4] * SHV(13) * (-3.f * xx + 4.f * zz - yy) +
+                           BSH_C3[5] * SHV(14) * 2.f * xz + BSH_C3[6] * SHV(15) * 3.f * (xx - yy);
+                    ddy += BSH_C3[0] * SHV(9) * 3.f * (xx - yy) + BSH_C3[1] * SHV(10) * xz +
+                           BSH_C3[2] * SHV(11) * (-3.f * yy + 4.f * zz - xx) + BSH_C3[3] * SHV(12) * -6.f * yz +
+                           BSH_C3[4] * SHV(13) * -2.f * xy + BSH_C3[5] * SHV(14) * -2.f * yz +
+                           BSH_C3[6] * SHV(15) * -6.f * xy;
+                    ddz += BSH_C3[1] * SHV(10) * xy + BSH_C3[2] * SHV(11) * 8.f * yz +
+                           BSH_C3[3] * SHV(12) * 3.f * (2.f * zz - xx - yy) + BSH_C3[4] * SHV(13) * 8.f * xz +
+                           BSH_C3[5] * SHV(14) * (xx - yy);
+                }
+            }
+        }
+#undef SHV
+        for (int k = (deg + 1) * (deg + 1); k < M; ++k) dsh[k * 3 + ch] = 0.f;
+        ddir[0] += ddx * d;
+        ddir[1] += ddy * d;
+        ddir[2] += ddz * d;
+    }
+    const float dot = x * ddir[0] + y * ddir[1] + z * ddir[2];
+    dmean[0] += (ddir[0] - x * dot) / len;
+    dmean[1] += (ddir[1] - y * dot) / len;
+    dmean[2] += (ddir[2] - z * dot) / len;
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float mod, int sh_degree, int M,
+                      const float* __restrict__ means3D, const float* __restrict__ shs,
+                      const float* __restrict__ scales, const float* __restrict__ rotations,
+                      const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
+                      const float* __restrict__ proj, const float* __restrict__ campos_p,
+                      const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+                      const float* __restrict__ ggrad, const float* __restrict__ drgb,
+                      float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+                      float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
+                      float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D,
+                      float* __restrict__ dL_dshs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float V[16], PM[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = view[k]; PM[k] = proj[k]; }
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float drot[4] = {0.f, 0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dm2x = 0.f, dm2y = 0.f, dop = 0.f;
+    const bool visible = radii[i] > 0;
+    if (visible) {
+        const float4 g0 = reinterpret_cast<const float4*>(ggrad)[2 * i];
+        const float4 g1 = reinterpret_cast<const float4*>(ggrad)[2 * i + 1];
+        dm2x = g0.x; dm2y = g0.y;
+        const float gA = g0.z, gB = g0.w, gC = g1.x;
+        dop = g1.y;
+        const float gdepth = g1.z;
+        const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+        const float tx0 = V[0] * px + V[4] * py + V[8] * pz + V[12];
+        const float ty0 = V[1] * px + V[5] * py + V[9] * pz + V[13];
+        const float tz = V[2] * px + V[6] * py + V[10] * pz + V[14];
+        const float focal_x = (float)W / (2.0f * tanfovx), focal_y = (float)H / (2.0f * tanfovy);
+        const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+        const float txtz = tx0 / tz, tytz = ty0 / tz;
+        const float xg = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float yg = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+        const float itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+        const float J00 = focal_x * itz, J02 = -(focal_x * tx) * itz2;
+        const float J11 = focal_y * itz, J12 = -(focal_y * ty) * itz2;
+        // Wv[r][c] = V[4c + r]
+        float A0[3], A1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            A0[c] = J00 * V[4 * c + 0] + J02 * V[4 * c + 2];
+            A1[c] = J11 * V[4 * c + 1] + J12 * V[4 * c + 2];
+        }
+        // 3D covariance (recomputed; same formula as the forward)
+        float c6[6];
+        float Rm[3][3], sc[3] = {0.f, 0.f, 0.f};
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+        } else {
+            const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
+            const float r = qv.x, x = qv.y, y = qv.z, z = qv.w;
+            Rm[0][0] = 1.f - 2.f * (y * y + z * z); Rm[0][1] = 2.f * (x * y - r * z); Rm[0][2] = 2.f * (x * z + r * y);
+            Rm[1][0] = 2.f * (x * y + r * z); Rm[1][1] = 1.f - 2.f * (x * x + z * z); Rm[1][2] = 2.f * (y * z - r * x);
+            Rm[2][0] = 2.f * (x * z - r * y); Rm[2][1] = 2.f * (y * z + r * x); Rm[2][2] = 1.f - 2.f * (x * x + y * y);
+            sc[0] = mod * scales[3 * i]; sc[1] = mod * scales[3 * i + 1]; sc[2] = mod * scales[3 * i + 2];
+            float L[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) L[j][k] = Rm[j][k] * sc[k];
+            c6[0] = L[0][0] * L[0][0] + L[0][1] * L[0][1] + L[0][2] * L[0][2];
+            c6[1] = L[0][0] * L[1][0] + L[0][1] * L[1][1] + L[0][2] * L[1][2];
+            c6[2] = L[0][0] * L[2][0] + L[0][1] * L[2][1] + L[0][2] * L[2][2];
+            c6[3] = L[1][0] * L[1][0] + L[1][1] * L[1][1] + L[1][2] * L[1][2];
+            c6[4] = L[1][0] * L[2][0] + L[1][1] * L[2][1] + L[1][2] * L[2][2];
+            c6[5] = L[2][0] * L[2][0] + L[2][1] * L[2][1] + L[2][2] * L[2][2];
+        }
+        const float S3[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float SA0[3], SA1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            SA0[j] = S3[j][0] * A0[0] + S3[j][1] * A0[1] + S3[j][2] * A0[2];
+            SA1[j] = S3[j][0] * A1[0] + S3[j][1] * A1[1] + S3[j][2] * A1[2];
+        }
+        const float a = A0[0] * SA0[0] + A0[1] * SA0[1] + A0[2] * SA0[2] + DILATION;
+        const float b = A0[0] * SA1[0] + A0[1] * SA1[1] + A0[2] * SA1[2];
+        const float c = A1[0] * SA1[0] + A1[1] * SA1[1] + A1[2] * SA1[2] + DILATION;
+        const float det = a * c - b * b;
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (det != 0.f) {
+            const float d2 = 1.0f / (det * det);
+            dL_da = (-c * c * gA + b * c * gB - b * b * gC) * d2;
+            dL_db = (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC) * d2;
+            dL_dc = (-b * b * gA + a * b * gB - a * a * gC) * d2;
+        }
+        const float G2[2][2] = {{dL_da, 0.5f * dL_db}, {0.5f * dL_db, dL_dc}};
+        // dL/dSigma3 (full symmetric) = A^T G2 A
+        float GA0[3], GA1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            GA0[k] = G2[0][0] * A0[k] + G2[0][1] * A1[k];
+            GA1[k] = G2[1][0] * A0[k] + G2[1][1] * A1[k];
+        }
+        float G3[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) G3[j][k] = A0[j] * GA0[k] + A1[j] * GA1[k];
+        if (cov3D_precomp) {
+            dcov[0] = G3[0][0]; dcov[1] = 2.f * G3[0][1]; dcov[2] = 2.f * G3[0][2];
+            dcov[3] = G3[1][1]; dcov[4] = 2.f * G3[1][2]; dcov[5] = G3[2][2];
+        } else {
+            // Sigma3 = L L^T, L = R diag(s)  =>  dL/dL = 2 G3 L
+            float dR[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float ds = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float dLjk = 2.f * (G3[j][0] * Rm[0][k] + G3[j][1] * Rm[1][k] + G3[j][2] * Rm[2][k]) * sc[k];
+                    ds += dLjk * Rm[j][k];
+                    dR[j][k] = dLjk * sc[k];
+                }
+                dscale[k] = ds * mod;
+            }
+            const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
+            const float r = qv.x, x = qv.y, y = qv.z, z = qv.w;
+            drot[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            drot[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+            drot[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+            drot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        }
+        // dL/dJ = 2 G2 J Sigma_v with J Sigma_v = (A Sigma3) Wv^T ; (A Sigma3)[r][k] = SA_r[k]
+        float JS0[3], JS1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // column k of Sigma_v side: sum_c SA[c] * Wv[k][c]
+            JS0[k] = SA0[0] * V[0 + k] + SA0[1] * V[4 + k] + SA0[2] * V[8 + k];
+            JS1[k] = SA1[0] * V[0 + k] + SA1[1] * V[4 + k] + SA1[2] * V[8 + k];
+        }
+        const float dJ00 = 2.f * (G2[0][0] * JS0[0] + G2[0][1] * JS1[0]);
+        const float dJ02 = 2.f * (G2[0][0] * JS0[2] + G2[0][1] * JS1[2]);
+        const float dJ11 = 2.f * (G2[1][0] * JS0[1] + G2[1][1] * JS1[1]);
+        const float dJ12 = 2.f * (G2[1][0] * JS0[2] + G2[1][1] * JS1[2]);
+        const float dtx = xg * (-focal_x * itz2 * dJ02);
+        const float dty = yg * (-focal_y * itz2 * dJ12);
+        const float dtz = -focal_x * itz2 * dJ00 - focal_y * itz2 * dJ11 + 2.f * focal_x * tx * itz3 * dJ02 +
+                          2.f * focal_y * ty * itz3 * dJ12;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)  // Wv^T [dtx dty dtz]: Wv[r][k] = V[4k + r]
+            dmean[k] += V[4 * k + 0] * dtx + V[4 * k + 1] * dty + V[4 * k + 2] * (dtz + gdepth);
+        // NDC mean2D -> mean3D
+        const float hx = PM[0] * px + PM[4] * py + PM[8] * pz + PM[12];
+        const float hy = PM[1] * px + PM[5] * py + PM[9] * pz + PM[13];
+        const float hw = PM[3] * px + PM[7] * py + PM[11] * pz + PM[15];
+        const float mw = 1.0f / (hw + 0.0000001f);
+        const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+        dmean[0] += (PM[0] * mw - PM[3] * mul1) * dm2x + (PM[1] * mw - PM[3] * mul2) * dm2y;
+        dmean[1] += (PM[4] * mw - PM[7] * mul1) * dm2x + (PM[5] * mw - PM[7] * mul2) * dm2y;
+        dmean[2] += (PM[8] * mw - PM[11] * mul1) * dm2x + (PM[9] * mw - PM[11] * mul2) * dm2y;
+        if (shs) {
+            sh_backward(sh_degree, M, shs + (size_t)i * 3 * M, dL_dshs + (size_t)i * 3 * M, clamped + 3 * (size_t)i,
+                        drgb + 3 * (size_t)i, px - campos_p[0], py - campos_p[1], pz - campos_p[2], dmean);
+        }
+    } else if (shs && dL_dshs) {
+        for (int k = 0; k < 3 * M; ++k) dL_dshs[(size_t)i * 3 * M + k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = dmean[k];
+    dL_dmeans2D[3 * i] = dm2x;
+    dL_dmeans2D[3 * i + 1] = dm2y;
+    dL_dmeans2D[3 * i + 2] = 0.f;
+    dL_dopacities[i] = dop;
+    if (dL_dscales) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dscales[3 * i + k] = dscale[k];
+    }
+    if (dL_drotations) reinterpret_cast<float4*>(dL_drotations)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    if (dL_dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = dcov[k];
+    }
+}
+
+int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
+                          const float* scales, const float* rotations, const float* cov3D_precomp,
+                          const float* view, const float* proj, const float* campos, const int32_t* radii,
+                          const uint8_t* clamped, const float* ggrad, const float* dcolors_rgb,
+                          float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
+                          float* dL_drotations, float* dL_dcov3D, float* dL_dshs, hipStream_t stream)
+{
+    if (P == 0) return SPLATRASTER_OK;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, s.image_width,
+                       s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs, means3D,
+                       shs, scales, rotations, cov3D_precomp, view, proj, campos, radii, clamped, ggrad,
+                       dcolors_rgb, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscales, dL_drotations,
+                       dL_dcov3D, dL_dshs);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
+}  // namespace sr

@@ -1,0 +1,282 @@
+// scan_sort.hip — device-wide prefix sum and stable LSD radix sort, hand-written for
+// wave64 (no rocPRIM / hipCUB).  Replaces cub::DeviceScan::InclusiveSum and
+// cub::DeviceRadixSort::SortPairs of the rasterizer lineage.
+//
+// Sort: 8-bit digits, 256-thread blocks (4 wave64), 4096 keys per block.
+//   pass = histogram kernel  -> [digit][block] table
+//          exclusive scan of the table (the scan below)
+//          scatter kernel: wave-level multi-way match (8 ballots) gives each key its
+//          stable rank among equal digits; per-wave digit counters live in LDS.
+// Stability: keys are consumed in (block, wave, iteration, lane) order == memory order.
+// Both kernels are HBM-bound: per pass 2 key reads + 1 value read + 1 key/value write.
+#include "common.h"
+
+namespace sr {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096
+constexpr int SORT_WAVES = SORT_THREADS / WAVE;
+constexpr int RADIX = 256;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// scan
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_reduce_kernel(int64_t n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ perm,
+                   uint64_t* __restrict__ partial)
+{
+    __shared__ uint64_t wsum[SCAN_THREADS / WAVE];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + (int64_t)k * SCAN_THREADS + threadIdx.x;
+        if (i < n) s += perm ? in[perm[i]] : in[i];
+    }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) s += __shfl_down(s, d, WAVE);
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    if (lane == 0) wsum[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int k = 0; k < SCAN_THREADS / WAVE; ++k) t += wsum[k];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// one block: exclusive scan of partial[0..nb) in place; total written as u64
+__global__ void __launch_bounds__(1024)
+scan_partials_kernel(int64_t nb, uint64_t* __restrict__ partial, uint64_t* __restrict__ total)
+{
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry_s;
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t start = 0; start < nb; start += 1024) {
+        const int64_t i = start + threadIdx.x;
+        const uint64_t v = i < nb ? partial[i] : 0;
+        uint64_t s = v;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint64_t t = __shfl_up(s, d, WAVE);
+            if (lane >= d) s += t;
+        }
+        if (lane == WAVE - 1) wsum[w] = s;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        const uint64_t carry = carry_s;
+        if (i < nb) partial[i] = carry + woff + s - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + s;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
+template <bool EXCLUSIVE>
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_apply_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ perm,
+                  const uint64_t* __restrict__ partial, uint32_t* out)  // in may alias out
+{
+    __shared__ uint32_t wsum[SCAN_THREADS / WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    // blocked arrangement: thread t owns items [t*ITEMS, (t+1)*ITEMS)
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + k;
+        v[k] = i < n ? (perm ? in[perm[i]] : in[i]) : 0u;
+        s += v[k];
+    }
+    const uint32_t incl = wave_inclusive_scan(s, lane);
+    if (lane == WAVE - 1) wsum[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    uint32_t run = (uint32_t)partial[blockIdx.x] + woff + incl - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + k;
+        if (EXCLUSIVE) {
+            if (i < n) out[i] = run;
+            run += v[k];
+        } else {
+            run += v[k];
+            if (i < n) out[i] = run;
+        }
+    }
+}
+
+size_t scan_tmp_bytes(int64_t n)
+{
+    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    return align_up((size_t)(nb + 2) * sizeof(uint64_t), 256);
+}
+
+template <bool EXCLUSIVE>
+static int scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_t* out, uint32_t* total,
+                    void* tmp, hipStream_t stream)
+{
+    uint64_t* partial = reinterpret_cast<uint64_t*>(tmp);
+    if (n <= 0) {
+        if (total) SR_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(uint64_t), stream));
+        return SPLATRASTER_OK;
+    }
+    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, n, in, perm, partial);
+    SR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(1024), 0, stream, nb, partial,
+                       reinterpret_cast<uint64_t*>(total));
+    SR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_apply_kernel<EXCLUSIVE>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, n, in,
+                       perm, partial, out);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
+int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_t* out, uint32_t* total,
+                       void* tmp, hipStream_t stream)
+{
+    return scan_u32<false>(n, in, perm, out, total, tmp, stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// radix sort
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SORT_THREADS)
+sort_hist_kernel(int64_t n, const uint32_t* __restrict__ keys, int shift, uint32_t nblocks,
+                 uint32_t* __restrict__ table)
+{
+    __shared__ uint32_t hist[RADIX];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) {
+        const int64_t i = base + (int64_t)k * SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(keys[i] >> shift) & (RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+sort_scatter_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
+                    uint32_t nblocks, const uint32_t* __restrict__ table)
+{
+    __shared__ uint32_t wave_hist[SORT_WAVES][RADIX];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+#pragma unroll
+    for (int k = 0; k < SORT_WAVES; ++k) wave_hist[k][threadIdx.x] = 0;
+    __syncthreads();
+
+    const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)w * (SORT_ITEMS * WAVE);
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) {
+        const int64_t i = wbase + (int64_t)k * WAVE + lane;
+        const bool valid = i < n;
+        key[k] = valid ? keys_in[i] : 0u;
+        val[k] = valid ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) {
+        const int64_t i = wbase + (int64_t)k * WAVE + lane;
+        const bool valid = i < n;
+        const uint32_t digit = (key[k] >> shift) & (RADIX - 1);
+        uint64_t mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (digit >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            mask &= bit ? bal : ~bal;
+        }
+        uint32_t prev = 0;
+        if (valid) prev = wave_hist[w][digit];
+        rank[k] = prev + (uint32_t)__popcll(mask & lt_mask);
+        // lowest lane of each equal-digit group publishes the new count
+        if (valid && (mask & lt_mask) == 0) wave_hist[w][digit] = prev + (uint32_t)__popcll(mask);
+    }
+    __syncthreads();
+    {
+        const int d = threadIdx.x;
+        uint32_t run = table[(size_t)d * nblocks + blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < SORT_WAVES; ++k) {
+            const uint32_t c = wave_hist[k][d];
+            wave_hist[k][d] = run;  // becomes the global base of (wave k, digit d)
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) {
+        const int64_t i = wbase + (int64_t)k * WAVE + lane;
+        if (i < n) {
+            const uint32_t digit = (key[k] >> shift) & (RADIX - 1);
+            const uint32_t dst = wave_hist[w][digit] + rank[k];
+            keys_out[dst] = key[k];
+            vals_out[dst] = val[k];
+        }
+    }
+}
+
+size_t sort_tmp_bytes(int64_t n)
+{
+    const int64_t nb = (n + SORT_TILE - 1) / SORT_TILE;
+    const size_t table = align_up((size_t)(nb > 0 ? nb : 1) * RADIX * sizeof(uint32_t), 256);
+    return table + scan_tmp_bytes((int64_t)(nb > 0 ? nb : 1) * RADIX);
+}
+
+int sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
+                   int key_bits, void* tmp, hipStream_t stream, bool* result_in_alt)
+{
+    *result_in_alt = false;
+    if (n <= 0 || key_bits <= 0) return SPLATRASTER_OK;
+    if (n >= (int64_t)1 << 32) return SPLATRASTER_ERR_OVERFLOW;
+    const int64_t nb = (n + SORT_TILE - 1) / SORT_TILE;
+    uint32_t* table = reinterpret_cast<uint32_t*>(tmp);
+    void* scan_tmp = reinterpret_cast<char*>(tmp) + align_up((size_t)nb * RADIX * sizeof(uint32_t), 256);
+    uint32_t *kin = keys, *vin = vals, *kout = keys_alt, *vout = vals_alt;
+    const int passes = (key_bits + 7) / 8;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * 8;
+        hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, n, kin, shift,
+                           (uint32_t)nb, table);
+        SR_LAUNCH_CHECK();
+        int st = scan_u32<true>(nb * RADIX, table, nullptr, table, nullptr, scan_tmp, stream);
+        if (st != SPLATRASTER_OK) return st;
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, n, kin, vin,
+                           kout, vout, shift, (uint32_t)nb, table);
+        SR_LAUNCH_CHECK();
+        uint32_t* t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+    *result_in_alt = (passes & 1) != 0;
+    return SPLATRASTER_OK;
+}
+
+}  // namespace sr

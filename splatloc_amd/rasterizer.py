@@ -1,0 +1,202 @@
+"""Host-side mirror of the `diff_gauss` extension API.
+
+Names, argument meaning and error behaviour follow what SplatLoc calls at
+gaussian_splatting/gaussian_renderer/__init__.py:42-57,117-126 (the extension's own
+Python wrapper is un-vendored): `GaussianRasterizationSettings`
+(12-field NamedTuple), `GaussianRasterizer(nn.Module)` whose forward returns the 4-tuple
+`(color[C,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32)`, `rasterize_gaussians` and the
+`_RasterizeGaussians` autograd.Function.
+
+All compute is in the HIP library behind include/splatraster.h; tensors must live on a
+ROCm device.  No CPU fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _native
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _prep(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    """contiguous fp32 on `device`, 16-byte aligned (kernels use 128-bit loads)."""
+    if t is None or t.numel() == 0:
+        return None
+    t = t.detach()
+    if t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"splatloc_amd rasterizer: `{name}` is on {t.device}; tensors must be on a ROCm device "
+            "(the HIP kernels are the only implementation, there is no CPU fallback)")
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings: GaussianRasterizationSettings):
+        lib = _native.load()
+        _require_gpu(means3D, "means3D")
+        dev = means3D.device
+        rs = raster_settings
+        P = int(means3D.shape[0])
+        H, W = int(rs.image_height), int(rs.image_width)
+
+        m3 = _prep(means3D, dev)
+        shs = _prep(sh, dev)
+        col = _prep(colors_precomp, dev)
+        opa = _prep(opacities, dev)
+        sca = _prep(scales, dev)
+        rot = _prep(rotations, dev)
+        cov = _prep(cov3Ds_precomp, dev)
+        bg = _prep(rs.bg, dev)
+        view = _prep(rs.viewmatrix, dev)
+        proj = _prep(rs.projmatrix, dev)
+        campos = _prep(rs.campos, dev)
+
+        if shs is not None:
+            Cn, M = 3, int(shs.shape[1])
+        elif col is not None:
+            Cn, M = int(col.shape[1]), 0
+        else:
+            Cn, M = (3, 0)
+        st = _native.Settings(H, W, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
+                              int(rs.sh_degree), M, Cn, 0 if bg is None else int(bg.numel()),
+                              int(bool(rs.prefiltered)), int(bool(rs.debug)))
+
+        color = torch.empty((Cn, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        geom = torch.empty((lib.splatraster_geometry_bytes(P),), dtype=torch.uint8, device=dev)
+        img = torch.empty((lib.splatraster_image_bytes(W, H),), dtype=torch.uint8, device=dev)
+        stream = _stream(dev)
+        R = C.c_int64(0)
+        with torch.cuda.device(dev):
+            _native.check(lib.splatraster_forward_geometry(
+                C.byref(st), P, _ptr(m3), _ptr(shs), _ptr(opa), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(view),
+                _ptr(proj), _ptr(campos), _ptr(geom), _ptr(radii), C.byref(R), stream), "forward_geometry")
+            binning = torch.empty((lib.splatraster_binning_bytes(P, R.value, W, H),), dtype=torch.uint8,
+                                  device=dev)
+            _native.check(lib.splatraster_forward_render(
+                C.byref(st), P, R.value, _ptr(bg), _ptr(col), _ptr(geom), _ptr(binning), _ptr(img),
+                _ptr(color), _ptr(depth), _ptr(alpha), stream), "forward_render")
+
+        ctx.raster_settings = rs
+        ctx.st = st
+        ctx.num_rendered = int(R.value)
+        ctx.shapes = (tuple(means3D.shape), None if sh is None else tuple(sh.shape))
+        ctx.have = (shs is not None, col is not None, sca is not None, cov is not None)
+        ctx.save_for_backward(*[t if t is not None else torch.empty(0, device=dev) for t in
+                                (m3, shs, col, opa, sca, rot, cov, bg, view, proj, campos)],
+                              radii, geom, binning, img, color, depth, alpha)
+        ctx.mark_non_differentiable(radii)
+        return color, depth, alpha, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_depth, grad_alpha, _grad_radii=None):
+        lib = _native.load()
+        (m3, shs, col, opa, sca, rot, cov, bg, view, proj, campos, radii, geom, binning, img, color, depth,
+         alpha) = ctx.saved_tensors
+        dev = m3.device
+        opt = lambda t: t if t.numel() else None  # noqa: E731
+        shs, col, sca, rot, cov, bg, campos = map(opt, (shs, col, sca, rot, cov, bg, campos))
+        st = ctx.st
+        P = int(m3.shape[0])
+        Cn = st.channels
+        g_color = _prep(grad_color, dev)
+        if g_color is None:
+            g_color = torch.zeros_like(color)
+        g_depth = _prep(grad_depth, dev) if grad_depth is not None else None
+        g_alpha = _prep(grad_alpha, dev) if grad_alpha is not None else None
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_m3 = torch.empty((P, 3), **f32)
+        d_m2 = torch.empty((P, 3), **f32)
+        d_op = torch.empty((P, 1), **f32)
+        d_col = torch.empty((P, Cn), **f32) if col is not None else None
+        d_sca = torch.empty((P, 3), **f32) if sca is not None else None
+        d_rot = torch.empty((P, 4), **f32) if rot is not None else None
+        d_cov = torch.empty((P, 6), **f32) if cov is not None else None
+        d_sh = torch.empty(tuple(shs.shape), **f32) if shs is not None else None
+        with torch.cuda.device(dev):
+            _native.check(lib.splatraster_backward(
+                C.byref(st), P, ctx.num_rendered, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(opa),
+                _ptr(sca), _ptr(rot), _ptr(cov), _ptr(view), _ptr(proj), _ptr(campos), _ptr(radii),
+                _ptr(geom), _ptr(binning), _ptr(img), _ptr(color), _ptr(depth), _ptr(alpha), _ptr(g_color),
+                _ptr(g_depth), _ptr(g_alpha), _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sca),
+                _ptr(d_rot), _ptr(d_cov), _ptr(d_sh), _stream(dev)), "backward")
+        # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings)
+        return d_m3, d_m2, d_sh, d_col, d_op, d_sca, d_rot, d_cov, None
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Boolean mask of points in front of the near plane (view z > 0.2)."""
+        lib = _native.load()
+        _require_gpu(positions, "positions")
+        rs = self.raster_settings
+        dev = positions.device
+        with torch.no_grad():
+            pos = _prep(positions, dev)
+            P = int(positions.shape[0])
+            present = torch.zeros((P,), dtype=torch.uint8, device=dev)
+            if P:
+                view, proj = _prep(rs.viewmatrix, dev), _prep(rs.projmatrix, dev)
+                with torch.cuda.device(dev):
+                    _native.check(lib.splatraster_mark_visible(P, _ptr(pos), _ptr(view), _ptr(proj),
+                                                               _ptr(present), _stream(dev)), "mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs)
