@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — fwd+bwd frames/s of the MI355X-native Gaussian rasterizer (BASELINE.json metric).
+
+One "step" = one forward + one backward pass of the rasterizer hot path
+(diff_gauss.GaussianRasterizer forward/backward through the C ABI) over one frame of the
+synthetic workload S2 (500k Gaussians, 1920x1080, 35 channels: RGB + 32 feature channels,
++ depth + alpha), inputs resident in HBM, on every rank.  With N > 1 ranks (one process
+per GPU, RCCL) every rank renders its own frame of a full scene replica and the parameter
+gradients are SUM-all-reduced inside the timed region (the frame-parallel map() step of
+SURVEY.md §8e): weak scaling, value = N frames per step / max-over-ranks step time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline`
+(dominant kernel, HIP events measured live on the launch stream) and `cpu_baseline`
+(the CPU oracle timed on this host's cores on one frame of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(P, R, W, H, C, tiles):
+    """Compulsory bytes: per stage and per fwd+bwd frame."""
+    tile_bits = max(1, (tiles - 1).bit_length())
+    n_pass = (32 + tile_bits + 7) // 8
+    stage = {
+        "preprocess": P * (44 + 4 * C + 60),
+        "depth_sort": 0,  # not part of the lineage formulation (its sort is the R-sized one)
+        "scan": P * 8,
+        "emit": R * 12,
+        "tile_sort": R * 24 * n_pass,
+        "ranges": R * 8,
+        "composite_fwd": R * (32 + 4 * C) + W * H * (4 * C + 16),
+        "composite_bwd": R * (32 + 4 * C) + W * H * (4 * C + 16) + P * (28 + 4 * C),
+        "preprocess_bwd": P * (100 + 4 * C + 56 + 4 * C),
+    }
+    frame = P * (296 + 16 * C) + R * (20 + 24 * n_pass + 2 * (32 + 4 * C)) + W * H * (8 * C + 32)
+    return stage, frame, n_pass
+
+
+def cpu_baseline(workload):
+    """The oracle (OpenMP build, all host cores) on ONE fwd+bwd frame of the same workload."""
+    from oracle import oracle
+    from splatloc_amd.synthetic import make_workload
+    from tests.helpers import oracle_backward, oracle_forward
+    sc = make_workload(workload)
+    oracle.build()
+    t0 = time.perf_counter()
+    f = oracle_forward(sc, omp=True)
+    t1 = time.perf_counter()
+    oracle_backward(f, sc, omp=True)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "frames/s", "cores": oracle.num_threads(True), "kind": "port",
+            "sample": f"1 fwd+bwd frame of {workload} (fwd {t1 - t0:.2f} s, bwd {t2 - t1:.2f} s), "
+                      f"oracle/splat_oracle.c built with -fopenmp",
+            "host_cpu_count": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="S2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer, _native
+    from splatloc_amd.frame_parallel import allreduce_grads
+    from splatloc_amd.synthetic import WORKLOADS, make_workload
+
+    wl = WORKLOADS[args.workload]
+    sc = make_workload(args.workload).to(dev)
+    cam = sc.camera
+    P, W, H, C = wl["P"], wl["W"], wl["H"], wl["C"]
+    leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
+    means3D, colors, opac = leaf(sc.means3D), leaf(sc.features), leaf(sc.opacities)
+    scales, rots = leaf(sc.scales), leaf(sc.rotations)
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    params = [means3D, means2D, colors, opac, scales, rots]
+    rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, sc.bg, 1.0, cam.world_view_transform,
+                                       cam.full_proj_transform, 0, cam.camera_center, False, False)
+    rast = GaussianRasterizer(raster_settings=rs)
+    g_out = (sc.dL_dcolor, sc.dL_ddepth, sc.dL_dalpha)
+    info = {}
+
+    def step():
+        for p in params:
+            p.grad = None
+        color, depth, alpha, radii = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors,
+                                          opacities=opac, scales=scales, rotations=rots, cov3D_precomp=None)
+        info["R"] = color.grad_fn.num_rendered
+        if not args.fwd_only:
+            torch.autograd.backward((color, depth, alpha), g_out)
+            if world > 1:
+                allreduce_grads([p.grad for p in params])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _native.timing_enable(True)
+    _native.timing_collect()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _native.timing_enable(False)
+    stages = _native.timing_collect()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        R = int(info["R"])
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        st_bytes, frame_bytes, n_pass = algorithmic_bytes(P, R, W, H, C, tiles)
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * args.steps / elapsed
+        per_stage = {}
+        for s, (ms, cnt) in stages.items():
+            if cnt:
+                avg = ms / cnt
+                per_stage[s] = {"avg_ms": round(avg, 4), "launches": int(cnt),
+                                "algorithmic_GBps": round(st_bytes[s] / (avg * 1e-3) / 1e9, 1)}
+        dom = max(per_stage, key=lambda s: per_stage[s]["avg_ms"] * per_stage[s]["launches"] / args.steps)
+        ach = per_stage[dom]["algorithmic_GBps"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "fwd+bwd frames/s @1080p, 500k Gaussians, 32 feat-ch; HBM GB/s vs roofline",
+            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: P={P} Gaussians, {W}x{H}, C={C} channels "
+                                   f"(3 RGB + {C - 3} feature) + depth + alpha, seed {wl['seed']}",
+                       "tile_instances_R": R, "frames_per_step": world,
+                       "parallelism": f"frame-parallel dp{world}, scene replica per GPU"
+                                      + (", RCCL SUM all-reduce of parameter grads" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "note": "composite kernels are VALU/LDS-bound, not HBM-bound (DESIGN.md)"},
+            "frame_hbm": {"algorithmic_bytes_per_frame": frame_bytes, "lineage_radix_passes": n_pass,
+                          "achieved_GBps": round(frame_bytes * value / world / 1e9, 1),
+                          "frac_of_peak": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
+            "stages": per_stage,
+        }
+        if args.fwd_only:
+            out["metric"] = "DEBUG fwd-only frames/s (not the BASELINE metric)"
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

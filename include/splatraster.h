@@ -193,6 +193,26 @@ size_t splatknn_workspace_bytes(int32_t N);
 int splatknn_dist2(int32_t N, const float* points /* [N,3] */, float* out /* [N] */,
                    void* workspace, void* stream);
 
+/* ---- per-stage timing (HIP events on the launch stream) ----------------------------- */
+
+/* Stage ids: every kernel group of the path is bracketed by a hipEvent pair when timing
+ * is enabled (process-wide switch; off by default, ~2 us per stage when on). */
+#define SPLATRASTER_STAGE_PREPROCESS 0     /* preprocess_kernel */
+#define SPLATRASTER_STAGE_DEPTH_SORT 1     /* depth keys + P-sized radix sort */
+#define SPLATRASTER_STAGE_SCAN 2           /* inclusive scan of tiles_touched */
+#define SPLATRASTER_STAGE_EMIT 3           /* emit_kernel */
+#define SPLATRASTER_STAGE_TILE_SORT 4      /* R-sized radix sort on tile id */
+#define SPLATRASTER_STAGE_RANGES 5         /* ranges_kernel */
+#define SPLATRASTER_STAGE_COMPOSITE_FWD 6  /* composite_fwd_kernel */
+#define SPLATRASTER_STAGE_COMPOSITE_BWD 7  /* memset of gradient buffers + composite_bwd_kernel */
+#define SPLATRASTER_STAGE_PREPROCESS_BWD 8 /* preprocess_bwd_kernel */
+#define SPLATRASTER_STAGE_COUNT 9
+
+int splatraster_timing_enable(int on);
+/* Waits for all recorded events, ADDS elapsed milliseconds / launch counts per stage into
+ * ms[SPLATRASTER_STAGE_COUNT] / counts[SPLATRASTER_STAGE_COUNT], then clears the records. */
+int splatraster_timing_collect(double* ms, int64_t* counts);
+
 /* ---- misc ---------------------------------------------------------------------------- */
 
 const char* splatraster_error_string(int status);

@@ -62,6 +62,8 @@ SYMBOLS = {
     "splatraster_get_image_layout": (C.c_int, [_i32, _i32, C.POINTER(ImageLayout)]),
     "splatraster_sort_tmp_bytes": (_sz, [_i64]),
     "splatraster_sort_pairs_u32": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _vp]),
+    "splatraster_timing_enable": (C.c_int, [C.c_int]),
+    "splatraster_timing_collect": (C.c_int, [_vp, _vp]),
     "splatknn_workspace_bytes": (_sz, [_i32]),
     "splatknn_dist2": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "splatraster_error_string": (C.c_char_p, [C.c_int]),
@@ -103,3 +105,20 @@ def check(status: int, what: str) -> None:
         lib = load()
         detail = lib.splatraster_last_hip_error().decode() if status == 2 else ""
         raise RuntimeError(f"{what} failed: {_ERR_NAMES.get(status, status)} {detail}".strip())
+
+
+STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "composite_fwd", "composite_bwd",
+          "preprocess_bwd")
+
+
+def timing_enable(on: bool) -> None:
+    check(load().splatraster_timing_enable(int(on)), "timing_enable")
+
+
+def timing_collect() -> dict:
+    """{stage: (total_ms, launches)} since the last collect (HIP events on the launch stream)."""
+    n = len(STAGES)
+    ms = (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    check(load().splatraster_timing_collect(ms, cnt), "timing_collect")
+    return {s: (ms[i], cnt[i]) for i, s in enumerate(STAGES)}

@@ -2,7 +2,9 @@
 // validation and stage sequencing.  No torch types; everything is raw device pointers.
 #include <string.h>
 
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -14,6 +16,42 @@ void set_hip_error(hipError_t e, const char* what)
 {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
 }
+
+// ---- stage timing ---------------------------------------------------------------------
+struct StageRec { int stage; hipEvent_t a, b; };
+static bool g_timing = false;
+static std::mutex g_timing_mu;
+static std::vector<StageRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t get_event()
+{
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct StageTimer {
+    hipStream_t stream;
+    StageRec rec{};
+    bool on;
+    StageTimer(int stage, hipStream_t s) : stream(s), on(g_timing)
+    {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g_timing_mu);
+        rec.stage = stage; rec.a = get_event(); rec.b = get_event();
+        if (!rec.a || !rec.b) { on = false; return; }
+        (void)hipEventRecord(rec.a, stream);
+    }
+    ~StageTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(rec.b, stream);
+        std::lock_guard<std::mutex> lk(g_timing_mu);
+        g_recs.push_back(rec);
+    }
+};
 
 static inline int tile_bits(int tiles)
 {
@@ -207,18 +245,27 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
     const GeomLayout L = geom_layout(P);
     GeomView g = geom_view(geometry, P);
     char* base = reinterpret_cast<char*>(geometry);
-    st = launch_preprocess(*s, P, means3D, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix,
-                           projmatrix, campos, g, radii, stream);
+    {
+        StageTimer t(SPLATRASTER_STAGE_PREPROCESS, stream);
+        st = launch_preprocess(*s, P, means3D, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                               projmatrix, campos, g, radii, stream);
+    }
     if (st) return st;
-    st = launch_depth_keys(P, g, stream);
-    if (st) return st;
-    bool in_alt = false;
-    uint32_t* keys_alt = reinterpret_cast<uint32_t*>(base + L.keys_alt);
-    uint32_t* vals_alt = reinterpret_cast<uint32_t*>(base + L.vals_alt);
-    st = sort_pairs_u32(P, g.sort_keys, g.depth_order, keys_alt, vals_alt, 32, g.sort_tmp, stream, &in_alt);
-    if (st) return st;
-    if (in_alt) return SPLATRASTER_ERR_UNSUPPORTED;  // 4 passes: never
-    st = inclusive_scan_u32(P, g.tiles_touched, g.depth_order, g.offsets, g.total, base + L.scan_tmp, stream);
+    {
+        StageTimer t(SPLATRASTER_STAGE_DEPTH_SORT, stream);
+        st = launch_depth_keys(P, g, stream);
+        if (st) return st;
+        bool in_alt = false;
+        uint32_t* keys_alt = reinterpret_cast<uint32_t*>(base + L.keys_alt);
+        uint32_t* vals_alt = reinterpret_cast<uint32_t*>(base + L.vals_alt);
+        st = sort_pairs_u32(P, g.sort_keys, g.depth_order, keys_alt, vals_alt, 32, g.sort_tmp, stream, &in_alt);
+        if (st) return st;
+        if (in_alt) return SPLATRASTER_ERR_UNSUPPORTED;  // 4 passes: never
+    }
+    {
+        StageTimer t(SPLATRASTER_STAGE_SCAN, stream);
+        st = inclusive_scan_u32(P, g.tiles_touched, g.depth_order, g.offsets, g.total, base + L.scan_tmp, stream);
+    }
     if (st) return st;
     uint64_t total = 0;
     SR_HIP_CHECK(hipMemcpyAsync(&total, g.total, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
@@ -256,14 +303,24 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
     uint32_t* k1 = (passes & 1) ? b.tile_list : b.keys_tmp;
     uint32_t* v1 = (passes & 1) ? b.point_list : b.vals_tmp;
     if (R > 0) {
-        st = launch_emit(*s, P, R, g, k0, v0, stream);
+        {
+            StageTimer t(SPLATRASTER_STAGE_EMIT, stream);
+            st = launch_emit(*s, P, R, g, k0, v0, stream);
+        }
         if (st) return st;
         bool in_alt = false;
-        st = sort_pairs_u32(R, k0, v0, k1, v1, bits, b.sort_tmp, stream, &in_alt);
+        {
+            StageTimer t(SPLATRASTER_STAGE_TILE_SORT, stream);
+            st = sort_pairs_u32(R, k0, v0, k1, v1, bits, b.sort_tmp, stream, &in_alt);
+        }
         if (st) return st;
     }
-    st = launch_ranges(R, tiles, b.tile_list, b.ranges, stream);
+    {
+        StageTimer t(SPLATRASTER_STAGE_RANGES, stream);
+        st = launch_ranges(R, tiles, b.tile_list, b.ranges, stream);
+    }
     if (st) return st;
+    StageTimer t(SPLATRASTER_STAGE_COMPOSITE_FWD, stream);
     return launch_composite_fwd(*s, R, g, b, im, feat, bg, out_color, out_depth, out_alpha, stream);
 }
 
@@ -298,11 +355,15 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     const int C = s->channels;
     const float* feat = shs ? g.rgb : colors_precomp;
     float* dcol = shs ? g.drgb : dL_dcolors;
-    SR_HIP_CHECK(hipMemsetAsync(g.ggrad, 0, sizeof(float) * 8 * (size_t)P, stream));
-    SR_HIP_CHECK(hipMemsetAsync(dcol, 0, sizeof(float) * (size_t)C * (size_t)P, stream));
-    st = launch_composite_bwd(*s, P, R, g, b, im, feat, C, out_color, out_depth, dL_dout_color, dL_dout_depth,
-                              dL_dout_alpha, g.ggrad, dcol, stream);
+    {
+        StageTimer t(SPLATRASTER_STAGE_COMPOSITE_BWD, stream);
+        SR_HIP_CHECK(hipMemsetAsync(g.ggrad, 0, sizeof(float) * 8 * (size_t)P, stream));
+        SR_HIP_CHECK(hipMemsetAsync(dcol, 0, sizeof(float) * (size_t)C * (size_t)P, stream));
+        st = launch_composite_bwd(*s, P, R, g, b, im, feat, C, out_color, out_depth, dL_dout_color,
+                                  dL_dout_depth, dL_dout_alpha, g.ggrad, dcol, stream);
+    }
     if (st) return st;
+    StageTimer t(SPLATRASTER_STAGE_PREPROCESS_BWD, stream);
     return launch_preprocess_bwd(*s, P, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                  campos, radii, g.clamped, g.ggrad, g.drgb, dL_dmeans3D, dL_dmeans2D,
                                  dL_dopacities, cov3D_precomp ? nullptr : dL_dscales,
@@ -344,6 +405,29 @@ int splatraster_sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, int32_
         SR_HIP_CHECK(hipMemcpyAsync(keys, ka, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream));
         SR_HIP_CHECK(hipMemcpyAsync(vals, va, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream));
     }
+    return SPLATRASTER_OK;
+}
+
+int splatraster_timing_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    g_timing = on != 0;
+    return SPLATRASTER_OK;
+}
+
+int splatraster_timing_collect(double* ms, int64_t* counts)
+{
+    if (!ms || !counts) return SPLATRASTER_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    for (const StageRec& r : g_recs) {
+        SR_HIP_CHECK(hipEventSynchronize(r.b));
+        float t = 0.f;
+        SR_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+        if (r.stage >= 0 && r.stage < SPLATRASTER_STAGE_COUNT) { ms[r.stage] += (double)t; counts[r.stage] += 1; }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
     return SPLATRASTER_OK;
 }
 

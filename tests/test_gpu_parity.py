@@ -1,0 +1,282 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle — needs an MI355X.
+
+Bar (BASELINE.json north_star): bit-exact radii / tile counts / point list / tile ranges,
+<= 1e-4 abs on colour / depth / alpha buffers; gradients within 2e-3 relative + 1e-4 of
+the tensor's scale (float atomics reorder the sums).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from splatloc_amd.synthetic import make_scene
+from tests.helpers import HipRun, assert_grad_close, oracle_backward, oracle_forward
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 1e-4
+
+
+def _check_forward(run: HipRun, f: dict, sc):
+    P = sc.means3D.shape[0]
+    W, H = sc.camera.image_width, sc.camera.image_height
+    st = run.state
+    # ---- bit-exact integer / index outputs ----
+    assert np.array_equal(run.np(run.radii), f["radii"]), "radii"
+    assert np.array_equal(run.np(st["tiles_touched"]).astype(np.uint32), f["tiles_touched"]), "tiles_touched"
+    assert run.num_rendered == f["num_rendered"], "num_rendered"
+    vis = f["radii"] > 0
+    rec0 = run.np(st["rec0"])
+    assert np.array_equal(rec0[vis, 0].view(np.uint32), f["xy"][vis, 0].view(np.uint32)), "pixel x bits"
+    assert np.array_equal(rec0[vis, 1].view(np.uint32), f["xy"][vis, 1].view(np.uint32)), "pixel y bits"
+    assert np.array_equal(rec0[vis, 2].view(np.uint32), f["view_depth"][vis].view(np.uint32)), "depth bits"
+    assert np.array_equal(run.np(st["point_list"]).astype(np.uint32), f["point_list"]), "sorted point list"
+    assert np.array_equal(run.np(st["ranges"]).astype(np.uint32), f["ranges"]), "tile ranges"
+    tile_of = (f["keys"] >> np.uint64(32)).astype(np.uint32)
+    assert np.array_equal(run.np(st["tile_list"]).astype(np.uint32), tile_of), "tile ids"
+    # ---- float buffers ----
+    np.testing.assert_allclose(run.np(st["rec1"])[vis], f["conic_opacity"][vis], rtol=1e-6, atol=0)
+    assert np.abs(run.np(run.color) - f["color"]).max() <= IMG_TOL
+    assert np.abs(run.np(run.alpha) - f["alpha"]).max() <= IMG_TOL
+    dscale = max(1.0, float(np.abs(f["depth"]).max()))
+    assert np.abs(run.np(run.depth) - f["depth"]).max() <= IMG_TOL * dscale
+    nc = run.np(st["n_contrib"]).astype(np.int64)
+    mism = (nc != f["n_contrib"].astype(np.int64)).mean()
+    assert mism < 2e-3, f"n_contrib mismatch fraction {mism}"   # exp ulp at the 1/255, 1e-4 thresholds
+    assert P == rec0.shape[0] and (H, W) == nc.shape
+
+
+def _check_backward(run: HipRun, b: dict):
+    assert_grad_close("dL_dmeans3D", run.np(run.means3D.grad), b["dL_dmeans3D"])
+    assert_grad_close("dL_dmeans2D", run.np(run.means2D.grad), b["dL_dmeans2D"])
+    assert_grad_close("dL_dopacities", run.np(run.opacities.grad), b["dL_dopacities"])
+    if run.colors is not None:
+        assert_grad_close("dL_dcolors", run.np(run.colors.grad), b["dL_dcolors"])
+    if run.shs is not None:
+        assert_grad_close("dL_dshs", run.np(run.shs.grad), b["dL_dshs"])
+    if run.scales is not None:
+        assert_grad_close("dL_dscales", run.np(run.scales.grad), b["dL_dscales"])
+        assert_grad_close("dL_drotations", run.np(run.rotations.grad), b["dL_drotations"])
+    if run.cov3D is not None:
+        assert_grad_close("dL_dcov3D", run.np(run.cov3D.grad), b["dL_dcov3D"])
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(P=10_000, W=640, H=480, C=3, seed=0, scale_median=0.02),    # BASELINE config 1 shape (S0)
+    dict(P=4_000, W=640, H=480, C=4, seed=21, scale_median=0.03),    # reference channel layout
+    dict(P=3_000, W=333, H=201, C=35, seed=22, scale_median=0.03),   # north-star channel count, ragged edges
+    dict(P=2_000, W=200, H=120, C=1, seed=23, scale_median=0.04),
+    dict(P=2_000, W=200, H=120, C=7, seed=24, scale_median=0.04),    # generic C: chunked passes 4+3
+    dict(P=1_500, W=160, H=96, C=40, seed=25, scale_median=0.04),    # 32 + 8
+    dict(P=20_000, W=256, H=256, C=3, seed=26, scale_median=0.05),   # deep lists: several LDS batches
+])
+def test_forward_backward_parity(cfg):
+    sc = make_scene(**cfg)
+    f = oracle_forward(sc)
+    b = oracle_backward(f, sc)
+    run = HipRun(sc)
+    _check_forward(run, f, sc)
+    _check_backward(run, b)
+
+
+def test_scale_modifier_and_no_aux_grads():
+    sc = make_scene(3000, 320, 240, 4, 31, scale_median=0.03)
+    f = oracle_forward(sc, scale_modifier=1.6)
+    b = oracle_backward(f, sc, use_depth=False, use_alpha=False)
+    run = HipRun(sc, scale_modifier=1.6, use_depth=False, use_alpha=False)
+    _check_forward(run, f, sc)
+    _check_backward(run, b)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_path(deg):
+    sc = make_scene(2500, 256, 192, 3, 40 + deg, scale_median=0.03)
+    g = torch.Generator().manual_seed(77 + deg)
+    shs = 0.5 * torch.randn(2500, 16, 3, generator=g)
+    f = oracle_forward(sc, sh_degree=deg, colors_precomp=None, shs=shs.numpy())
+    b = oracle_backward(f, sc)
+    run = HipRun(sc, sh_degree=deg, shs=shs)
+    _check_forward(run, f, sc)
+    assert np.array_equal(run.np(run.state["clamped"])[f["radii"] > 0], f["clamped"][f["radii"] > 0])
+    _check_backward(run, b)
+
+
+def test_cov3d_precomp_path():
+    sc = make_scene(2500, 256, 192, 3, 50, scale_median=0.03)
+    g = torch.Generator().manual_seed(5)
+    L = torch.randn(2500, 3, 3, generator=g) * 0.03
+    S = L @ L.transpose(1, 2)
+    cov = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).contiguous()
+    f = oracle_forward(sc, scales=None, rotations=None, cov3D_precomp=cov.numpy())
+    b = oracle_backward(f, sc)
+    run = HipRun(sc, cov3D=cov)
+    _check_forward(run, f, sc)
+    _check_backward(run, b)
+
+
+def test_all_culled_and_empty():
+    """Edge cases: every Gaussian behind the camera (R = 0) and P = 0."""
+    sc = make_scene(500, 128, 96, 3, 60)
+    sc.means3D[:, 2] = -sc.means3D[:, 2]
+    sc.bg = torch.tensor([0.2, 0.4, 0.6])
+    run = HipRun(sc)
+    assert run.num_rendered == 0 and int(run.radii.abs().sum()) == 0
+    col = run.np(run.color)
+    assert np.allclose(col[0], 0.2) and np.allclose(col[1], 0.4) and np.allclose(col[2], 0.6)
+    assert np.all(run.np(run.alpha) == 0) and np.all(run.np(run.depth) == 0)
+    assert float(run.means3D.grad.abs().sum()) == 0.0 and float(run.colors.grad.abs().sum()) == 0.0
+
+    from splatloc_amd import GaussianRasterizer
+    from tests.helpers import hip_settings
+    dev = torch.device("cuda:0")
+    rast = GaussianRasterizer(raster_settings=hip_settings(sc, dev))
+    e = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    color, depth, alpha, radii = rast(means3D=e(0, 3), means2D=e(0, 3), shs=None, colors_precomp=e(0, 3),
+                                      opacities=e(0, 1), scales=e(0, 3), rotations=e(0, 4), cov3D_precomp=None)
+    assert color.shape == (3, 96, 128) and radii.numel() == 0
+    assert torch.allclose(color[1], torch.full_like(color[1], 0.4))
+
+
+def test_reference_boundary_inputs(golden_dir):
+    """The exact tensors the reference's unmodified render() passes at the boundary
+    (tests/golden/boundary.npz: C = 4, 3-entry bg, strided campos) through HIP vs oracle."""
+    from oracle import oracle
+    from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer
+    g = np.load(os.path.join(golden_dir, "boundary.npz"))
+    meta = json.loads(str(g["meta"]))
+    s = meta["settings"]
+    dev = torch.device("cuda:0")
+    t = lambda k: torch.from_numpy(g[k]).to(dev)  # noqa: E731
+    # reproduce the non-contiguous campos the reference hands over (camera_utils.py:139)
+    campos = torch.zeros(4, 3, device=dev)
+    campos[3] = t("rs_campos")
+    rs = GaussianRasterizationSettings(s["image_height"], s["image_width"], s["tanfovx"], s["tanfovy"], t("rs_bg"),
+                                       s["scale_modifier"], t("rs_viewmatrix"), t("rs_projmatrix"), s["sh_degree"],
+                                       campos.t()[:, 3], s["prefiltered"], s["debug"])
+    assert not rs.campos.is_contiguous()
+    leaf = lambda k: t(k).requires_grad_(True)  # noqa: E731
+    inp = {k: leaf(k) for k in ("means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations")}
+    color, depth, alpha, radii = GaussianRasterizer(raster_settings=rs)(shs=None, cov3D_precomp=None, **inp)
+    st = oracle.Settings(s["image_height"], s["image_width"], s["tanfovx"], s["tanfovy"])
+    f = oracle.forward(st, g["rs_bg"], g["means3D"], g["opacities"], g["rs_viewmatrix"], g["rs_projmatrix"],
+                       g["rs_campos"], colors_precomp=g["colors_precomp"], scales=g["scales"],
+                       rotations=g["rotations"], omp=True)
+    assert np.array_equal(radii.cpu().numpy(), f["radii"]) and radii.dtype == torch.int32
+    assert color.shape == (4, 480, 640) and depth.shape == (1, 480, 640) and alpha.shape == (1, 480, 640)
+    assert np.abs(color.detach().cpu().numpy() - f["color"]).max() <= IMG_TOL
+    assert np.abs(alpha.detach().cpu().numpy() - f["alpha"]).max() <= IMG_TOL
+    # the loss shape of train_gaussians.py: image[:3], kp_prob = image[-1], depth; opacity unused
+    gl = np.load(os.path.join(golden_dir, "loss.npz"))
+    gen = torch.Generator().manual_seed(3)
+    dcol = (torch.rand(4, 480, 640, generator=gen) - 0.5) / (480 * 640)
+    ddep = (torch.rand(1, 480, 640, generator=gen) - 0.5) / (480 * 640)
+    del gl
+    ((color * dcol.to(dev)).sum() + (depth * ddep.to(dev)).sum()).backward()
+    b = oracle.backward(f, dcol.numpy(), ddep.numpy(), None, omp=True)
+    assert_grad_close("means3D", inp["means3D"].grad.cpu().numpy(), b["dL_dmeans3D"])
+    assert_grad_close("means2D", inp["means2D"].grad.cpu().numpy(), b["dL_dmeans2D"])
+    assert_grad_close("colors", inp["colors_precomp"].grad.cpu().numpy(), b["dL_dcolors"])
+    assert_grad_close("opacities", inp["opacities"].grad.cpu().numpy(), b["dL_dopacities"])
+    assert_grad_close("scales", inp["scales"].grad.cpu().numpy(), b["dL_dscales"])
+    assert_grad_close("rotations", inp["rotations"].grad.cpu().numpy(), b["dL_drotations"])
+
+
+def test_mark_visible():
+    from oracle import oracle
+    from splatloc_amd import GaussianRasterizer
+    from tests.helpers import hip_settings
+    sc = make_scene(5000, 128, 96, 3, 61)
+    sc.means3D[::3, 2] *= -1
+    sc.means3D[1::7, 2] = 0.2
+    dev = torch.device("cuda:0")
+    vis = GaussianRasterizer(raster_settings=hip_settings(sc, dev)).markVisible(sc.means3D.to(dev))
+    ref = oracle.mark_visible(sc.means3D.numpy(), sc.camera.world_view_transform.numpy())
+    assert vis.dtype == torch.bool and np.array_equal(vis.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 32), (63, 8), (4096, 13), (4097, 32), (100_003, 32), (1_000_000, 16)])
+def test_radix_sort_is_stable_and_exact(n, bits):
+    """splatraster_sort_pairs_u32 vs numpy stable argsort (bit-exact, ties keep input order)."""
+    import ctypes as C
+    from splatloc_amd import _native
+    lib = _native.load()
+    rng = np.random.default_rng(n)
+    hi = (1 << bits) - 1
+    keys = rng.integers(0, min(hi, 5000 if n > 4096 else hi), size=n, endpoint=True, dtype=np.uint64).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    dev = torch.device("cuda:0")
+    k = torch.from_numpy(keys.view(np.int32)).to(dev)
+    v = torch.from_numpy(vals.view(np.int32)).to(dev)
+    tmp = torch.empty(lib.splatraster_sort_tmp_bytes(n), dtype=torch.uint8, device=dev)
+    _native.check(lib.splatraster_sort_pairs_u32(n, C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), bits,
+                                                 C.c_void_p(tmp.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "sort")
+    torch.cuda.synchronize()
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
+    assert np.array_equal(v.cpu().numpy().view(np.uint32), vals[order])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 257, 5000, 20_000])
+def test_dist2_matches_oracle(n):
+    """simple_knn distCUDA2 (gaussian_model.py:206): exact 3-NN mean squared distance."""
+    from oracle import oracle
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(n)
+    pts = rng.normal(size=(n, 3)).astype(np.float32)
+    if n > 10:
+        pts[5] = pts[4]          # duplicate point: distance 0 neighbour
+    out = distCUDA2(torch.from_numpy(pts).cuda())
+    ref = oracle.dist2(pts)
+    assert out.shape == (n,) and out.dtype == torch.float32
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    if n >= 5000:
+        from scipy.spatial import cKDTree
+        d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+        np.testing.assert_allclose(out.cpu().numpy(), (d[:, 1:] ** 2).mean(1), rtol=1e-4, atol=1e-9)
+
+
+def test_full_size_properties():
+    """North-star shape (S2: 500k Gaussians, 1920x1080, C = 35): size-independent checks —
+    sortedness of the instance list, range table partition, alpha = 1 - final_T,
+    linearity of backward in dL/dout, preprocess bit-exact vs oracle."""
+    from splatloc_amd.synthetic import make_workload
+    sc = make_workload("S2")
+    run = HipRun(sc, backward=True)
+    st = run.state
+    R = run.num_rendered
+    tiles = st["tile_list"].long()
+    assert R > 3_000_000 and bool((tiles[1:] >= tiles[:-1]).all())
+    depth_bits = st["rec0"][:, 2].contiguous().view(torch.int32).long()
+    pl = st["point_list"].long()
+    same = tiles[1:] == tiles[:-1]
+    d0, d1 = depth_bits[pl[:-1]], depth_bits[pl[1:]]
+    assert bool(((d1 > d0) | ((d1 == d0) & (pl[1:] > pl[:-1])))[same].all()), "(depth, index) order inside tiles"
+    rng = st["ranges"].long()
+    assert int((rng[:, 1] - rng[:, 0]).sum()) == R
+    nz = rng[:, 1] > rng[:, 0]
+    assert bool((rng[nz][1:, 0] == rng[nz][:-1, 1]).all())
+    assert float((run.alpha[0] - (1.0 - st["final_T"])).abs().max()) == 0.0
+    assert bool(torch.isfinite(run.color).all()) and bool(torch.isfinite(run.means3D.grad).all())
+    # preprocess + binning integers against the oracle (C oracle handles this size in seconds)
+    from oracle import oracle
+    cam = sc.camera
+    f = oracle.forward(oracle.Settings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy),
+                       sc.bg.numpy(), sc.means3D.numpy(), sc.opacities.numpy(), cam.world_view_transform.numpy(),
+                       cam.full_proj_transform.numpy(), cam.camera_center.numpy(),
+                       colors_precomp=sc.features[:, :1].contiguous().numpy(), scales=sc.scales.numpy(),
+                       rotations=sc.rotations.numpy(), omp=True)
+    assert np.array_equal(run.np(run.radii), f["radii"]) and R == f["num_rendered"]
+    assert np.array_equal(run.np(st["point_list"]).astype(np.uint32), f["point_list"])
+    assert np.array_equal(run.np(st["ranges"]).astype(np.uint32), f["ranges"])
+    assert np.abs(run.np(run.alpha) - f["alpha"]).max() <= IMG_TOL
+    # linearity: backward(2 g) == 2 backward(g)
+    g1 = run.means3D.grad.clone()
+    c1 = run.colors.grad.clone()
+    sc2 = sc
+    sc2.dL_dcolor, sc2.dL_ddepth, sc2.dL_dalpha = 2 * sc.dL_dcolor, 2 * sc.dL_ddepth, 2 * sc.dL_dalpha
+    run2 = HipRun(sc2, backward=True)
+    assert_grad_close("linearity means3D", run2.np(run2.means3D.grad), 2 * run.np(g1), rtol=5e-3, atol_scale=2e-4)
+    assert_grad_close("linearity colors", run2.np(run2.colors.grad), 2 * run.np(c1), rtol=5e-3, atol_scale=2e-4)
