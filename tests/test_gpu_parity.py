@@ -150,11 +150,11 @@ def test_reference_boundary_inputs(golden_dir):
     dev = torch.device("cuda:0")
     t = lambda k: torch.from_numpy(g[k]).to(dev)  # noqa: E731
     # reproduce the non-contiguous campos the reference hands over (camera_utils.py:139)
-    campos = torch.zeros(4, 3, device=dev)
-    campos[3] = t("rs_campos")
+    campos = torch.zeros(3, 4, device=dev)
+    campos[:, 3] = t("rs_campos")
     rs = GaussianRasterizationSettings(s["image_height"], s["image_width"], s["tanfovx"], s["tanfovy"], t("rs_bg"),
                                        s["scale_modifier"], t("rs_viewmatrix"), t("rs_projmatrix"), s["sh_degree"],
-                                       campos.t()[:, 3], s["prefiltered"], s["debug"])
+                                       campos[:, 3], s["prefiltered"], s["debug"])
     assert not rs.campos.is_contiguous()
     leaf = lambda k: t(k).requires_grad_(True)  # noqa: E731
     inp = {k: leaf(k) for k in ("means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations")}
