@@ -81,7 +81,7 @@ def load(build_if_missing: bool = True):
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB_PATH
+    path = os.environ.get("SPLATRASTER_LIB", _build.LIB_PATH)  # override: perf experiments only
     if not os.path.exists(path):
         if not build_if_missing:
             raise RuntimeError(f"{path} is missing: run `python -m splatloc_amd.build`")

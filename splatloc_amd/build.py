@@ -16,6 +16,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "_lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libsplatraster.so")
+# experiments only: SPLATRASTER_LIB points the loader at a variant build (tools/ablate.py)
+
 
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall",

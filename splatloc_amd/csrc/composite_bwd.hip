@@ -19,6 +19,10 @@
 // dL_dcolors row + the 32-byte geometric-gradient record of the Gaussian).
 #include "common.h"
 
+#ifndef SR_BWD_ABLATE
+#define SR_BWD_ABLATE 0  // perf ablation switch (tools/ablate.sh); 0 = product
+#endif
+
 namespace sr {
 
 constexpr int CB_THREADS = 256;
@@ -51,6 +55,98 @@ __device__ __forceinline__ float lane63(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+
+// ---- packed butterfly reduction -----------------------------------------------------------
+// Reduces K per-lane values over the 64 lanes of a wave and leaves total k in lane
+// bitreverse6(k): every stage halves the lane span of each value AND merges two registers
+// into one, so the whole reduction costs ~2.2 VALU per value instead of 6 DPP adds + a
+// readlane/select gather per value.
+//   stage 1 (lane bit 5): v_permlane32_swap + add      (2 instr per pair)
+//   stage 2 (lane bit 4): v_permlane16_swap + add      (2 instr per pair)
+//   stage 3 (lane bit 3): select / select / add row_ror:8
+//   stage 4 (lane bit 2): select / select / two bank-masked row_ror movs / add
+//   stage 5 (lane bit 1): select / select / add quad_perm[2,3,0,1]
+//   stage 6 (lane bit 0): select / select / add quad_perm[1,0,3,2]
+__device__ __forceinline__ float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned as_u(float f) { return __builtin_bit_cast(unsigned, f); }
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov_old(float old, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, v), CTRL, 0xf,
+                                                                 BANK_MASK, false));
+}
+
+template <int K>
+__device__ __forceinline__ float wave_reduce_pack(const float (&v)[K], int lane)
+{
+    static_assert(K >= 1 && K <= 64, "at most 64 values per wave");
+    constexpr int N1 = (K + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2,
+                  N5 = (N4 + 1) / 2, N6 = (N5 + 1) / 2;
+    static_assert(N6 == 1, "");
+    float a[N1];
+#pragma unroll
+    for (int m = 0; m < N1; ++m) {
+        const float x = v[2 * m];
+        const float y = (2 * m + 1 < K) ? v[2 * m + 1] : 0.0f;
+        const auto r = __builtin_amdgcn_permlane32_swap(as_u(x), as_u(y), false, false);
+        a[m] = as_f(r[0]) + as_f(r[1]);
+    }
+    float b[N2];
+#pragma unroll
+    for (int m = 0; m < N2; ++m) {
+        const float x = a[2 * m];
+        const float y = (2 * m + 1 < N1) ? a[2 * m + 1] : 0.0f;
+        const auto r = __builtin_amdgcn_permlane16_swap(as_u(x), as_u(y), false, false);
+        b[m] = as_f(r[0]) + as_f(r[1]);
+    }
+    float c[N3];
+    {
+        const bool lo = (lane & 8) == 0;
+#pragma unroll
+        for (int m = 0; m < N3; ++m) {
+            const float x = b[2 * m];
+            const float y = (2 * m + 1 < N2) ? b[2 * m + 1] : 0.0f;
+            const float keep = lo ? x : y, send = lo ? y : x;
+            c[m] = keep + dpp_get<0x128, 0xf>(send);  // row_ror:8
+        }
+    }
+    float d[N4];
+    {
+        const bool lo = (lane & 4) == 0;
+#pragma unroll
+        for (int m = 0; m < N4; ++m) {
+            const float x = c[2 * m];
+            const float y = (2 * m + 1 < N3) ? c[2 * m + 1] : 0.0f;
+            const float keep = lo ? x : y, send = lo ? y : x;
+            // partner = lane ^ 4: banks 0,2 read lane+4 (row_ror:12), banks 1,3 read lane-4 (row_ror:4)
+            float t = dpp_mov_old<0x12C, 0x5>(0.0f, send);
+            t = dpp_mov_old<0x124, 0xA>(t, send);
+            d[m] = keep + t;
+        }
+    }
+    float e[N5];
+    {
+        const bool lo = (lane & 2) == 0;
+#pragma unroll
+        for (int m = 0; m < N5; ++m) {
+            const float x = d[2 * m];
+            const float y = (2 * m + 1 < N4) ? d[2 * m + 1] : 0.0f;
+            const float keep = lo ? x : y, send = lo ? y : x;
+            e[m] = keep + dpp_get<0x4E, 0xf>(send);  // quad_perm [2,3,0,1]
+        }
+    }
+    const bool lo1 = (lane & 1) == 0;
+    const float x6 = e[0];
+    const float y6 = (N5 > 1) ? e[N5 > 1 ? 1 : 0] : 0.0f;
+    const float keep6 = lo1 ? x6 : y6, send6 = lo1 ? y6 : x6;
+    return keep6 + dpp_get<0xB1, 0xf>(send6);  // quad_perm [1,0,3,2]
+}
+
+#ifndef SR_BWD_REDUCE
+#define SR_BWD_REDUCE 1  // 1 = packed butterfly (product), 0 = per-value DPP reductions (A/B baseline)
+#endif
 
 template <int NC>
 __global__ void __launch_bounds__(CB_THREADS)
@@ -119,6 +215,14 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
     float T = 1.0f;
     uint32_t contributor = 0;
     const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
+#if SR_BWD_REDUCE
+    // wave_reduce_pack leaves total k in lane bitreverse6(k)
+    constexpr int KRED = NC + 7;
+    const int slot = (int)(__brev((unsigned)lane) >> 26);
+    const bool slot_col = slot < NC;
+    const bool slot_ok = slot < KRED;
+    const int slot_off = slot_col ? (c0 + slot) : (slot - NC);
+#endif
 
     for (uint32_t base = beg; todo > 0; base += BATCH, todo -= BATCH) {
         const int nb = todo < BATCH ? todo : BATCH;
@@ -145,6 +249,9 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
             const float alpha = fminf(ALPHA_MAX, r1.w * G);
             const bool hit = (contributor + (uint32_t)j < last) && power <= 0.0f && alpha >= ALPHA_MIN;
             if (!__any(hit)) continue;
+#if SR_BWD_ABLATE >= 3
+            { T *= hit ? (1.0f - alpha) : 1.0f; continue; }
+#endif
             const float* f = &s_feat[j * NCP];
             const float w = hit ? alpha * T : 0.0f;
             float q = r0.z * gD;
@@ -169,6 +276,34 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
             v[4] = -0.5f * gdy * dy * dL_dG;
             v[5] = G * dL_dalpha_i;
             v[6] = w * gD;
+#if SR_BWD_ABLATE >= 2
+            {
+                float keep = 0.f;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) keep += v[k];
+#pragma unroll
+                for (int ch = 0; ch < NC; ++ch) keep += w * g[ch];
+                asm volatile("" ::"v"(keep));
+                continue;
+            }
+#endif
+#if SR_BWD_REDUCE
+            static_assert(NC + 7 <= WAVE, "packed reduction handles at most 57 channels per pass");
+            float red[KRED];
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) red[ch] = w * g[ch];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) red[NC + k] = v[k];
+            const float outv = wave_reduce_pack<KRED>(red, lane);
+            const uint32_t gi = s_id[j];
+            float* dst = slot_col ? (dcolors + (size_t)gi * C_total + slot_off)
+                                  : (ggrad + (size_t)gi * 8 + slot_off);
+#if SR_BWD_ABLATE >= 1
+            asm volatile("" ::"v"(outv), "v"(dst));
+#else
+            if (slot_ok) atomicAdd(dst, outv);
+#endif
+#else
             // reduce over the wave and gather value k into lane k
             float outv = 0.0f;
 #pragma unroll
@@ -177,25 +312,19 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
                 outv = (lane == ch) ? t : outv;
             }
             const uint32_t gi = s_id[j];
-            if (NC + 7 <= WAVE) {
 #pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    const float t = lane63(wave_sum_row3(v[k]));
-                    outv = (lane == NC + k) ? t : outv;
-                }
-                float* dst = (lane < NC) ? (dcolors + (size_t)gi * C_total + c0 + lane)
-                                         : (ggrad + (size_t)gi * 8 + (lane - NC));
-                if (lane < NC + 7) atomicAdd(dst, outv);
-            } else {
-                if (lane < NC) atomicAdd(dcolors + (size_t)gi * C_total + c0 + lane, outv);
-                float outg = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    const float t = lane63(wave_sum_row3(v[k]));
-                    outg = (lane == k) ? t : outg;
-                }
-                if (lane < 7) atomicAdd(ggrad + (size_t)gi * 8 + lane, outg);
+            for (int k = 0; k < 7; ++k) {
+                const float t = lane63(wave_sum_row3(v[k]));
+                outv = (lane == NC + k) ? t : outv;
             }
+            float* dst = (lane < NC) ? (dcolors + (size_t)gi * C_total + c0 + lane)
+                                     : (ggrad + (size_t)gi * 8 + (lane - NC));
+#if SR_BWD_ABLATE >= 1
+            asm volatile("" ::"v"(outv), "v"(dst));
+#else
+            if (lane < NC + 7) atomicAdd(dst, outv);
+#endif
+#endif
         }
         contributor += (uint32_t)nb;
     }
