@@ -17,7 +17,7 @@
 // pixels of the wave's 8x8 quadrant with DPP row reductions (no LDS traffic), gathered
 // into distinct lanes, and flushed with ONE wave-wide float atomic (contiguous addresses:
 // dL_dcolors row + the 32-byte geometric-gradient record of the Gaussian).
-#include "common.h"
+#include "composite_common.h"
 
 #ifndef SR_BWD_ABLATE
 #define SR_BWD_ABLATE 0  // perf ablation switch (tools/ablate.sh); 0 = product
@@ -165,10 +165,12 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
     __shared__ __attribute__((aligned(16))) float4 s_rec1[BATCH];
     __shared__ __attribute__((aligned(16))) float s_feat[BATCH * NCP];
     __shared__ uint32_t s_id[BATCH];
+    __shared__ uint64_t s_cand[4][BATCH / WAVE];
+    __shared__ uint8_t s_any[BATCH];
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
-    const int wave = tid / WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const int gx = (W + TILE - 1) / TILE;
     const int tile = blockIdx.y * gx + blockIdx.x;
     const int px = blockIdx.x * TILE + (wave & 1) * 8 + (lane & 7);
@@ -227,20 +229,38 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
     for (uint32_t base = beg; todo > 0; base += BATCH, todo -= BATCH) {
         const int nb = todo < BATCH ? todo : BATCH;
         __syncthreads();
+        unsigned m4 = 0u;
         if (tid < nb) {
             const uint32_t gi = point_list[base + tid];
+            const float4 a0 = rec0[gi], a1 = rec1[gi];
             s_id[tid] = gi;
-            s_rec0[tid] = rec0[gi];
-            s_rec1[tid] = rec1[gi];
+            s_rec0[tid] = a0;
+            s_rec1[tid] = a1;
+            m4 = quadrant_reach_mask(a0, a1, (float)(blockIdx.x * TILE), (float)(blockIdx.y * TILE));
+            s_any[tid] = (uint8_t)m4;
+        }
+        if (wave < BATCH / WAVE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t bal = __ballot((m4 >> q) & 1u);
+                if (lane == 0) s_cand[q][wave] = bal;
+            }
         }
         __syncthreads();
         for (int e = tid; e < nb * NC; e += CB_THREADS) {
             const int row = e / NC, ch = e - row * NC;
-            s_feat[row * NCP + ch] = feat[(size_t)s_id[row] * C_total + c0 + ch];
+            if (s_any[row]) s_feat[row * NCP + ch] = feat[(size_t)s_id[row] * C_total + c0 + ch];
         }
         __syncthreads();
         const int nw = (int)min((uint32_t)nb, wave_last > contributor ? wave_last - contributor : 0u);
-        for (int j = 0; j < nw; ++j) {
+#pragma unroll 1
+        for (int k = 0; k * WAVE < nw; ++k) {
+          uint64_t cand = uniform_u64(s_cand[wave][k]);
+          const int lim = nw - k * WAVE;  // only list positions below the wave's deepest contributor
+          if (lim < WAVE) cand &= (1ull << lim) - 1ull;
+          while (cand) {
+            const int j = k * WAVE + __builtin_ctzll(cand);
+            cand &= cand - 1;
             const float4 r0 = s_rec0[j];
             const float4 r1 = s_rec1[j];
             const float dx = r0.x - fx, dy = r0.y - fy;
@@ -325,6 +345,7 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
             if (lane < NC + 7) atomicAdd(dst, outv);
 #endif
 #endif
+          }
         }
         contributor += (uint32_t)nb;
     }

@@ -8,7 +8,11 @@
 // batches staged in LDS: 32-byte projected records + the feature rows (4*C bytes each),
 // fetched with coalesced global loads and read back as wave-uniform (broadcast) LDS reads.
 // VALU/LDS-bound; no MFMA (no dense contraction in this form).
-#include "common.h"
+#include "composite_common.h"
+
+#ifndef SR_FWD_ABLATE
+#define SR_FWD_ABLATE 0  // perf ablation switch (tools/ablate.py); 0 = product
+#endif
 
 namespace sr {
 
@@ -36,10 +40,12 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
     __shared__ __attribute__((aligned(16))) float4 s_rec1[BATCH];
     __shared__ __attribute__((aligned(16))) float s_feat[BATCH * NCP];
     __shared__ uint32_t s_id[BATCH];
+    __shared__ uint64_t s_cand[4][BATCH / WAVE];  // per quadrant: candidate bitmask of the batch
+    __shared__ uint8_t s_any[BATCH];              // row reaches at least one quadrant
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
-    const int wave = tid / WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const int gx = (W + TILE - 1) / TILE;
     const int tile = blockIdx.y * gx + blockIdx.x;
     const int px = blockIdx.x * TILE + (wave & 1) * 8 + (lane & 7);
@@ -61,21 +67,39 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
         if (__syncthreads_count(done) == CF_THREADS) break;
         const int nb = todo < BATCH ? todo : BATCH;
         // ---- stage ids + records ----
+        unsigned m4 = 0u;
         if (tid < nb) {
             const uint32_t g = point_list[base + tid];
+            const float4 a0 = rec0[g], a1 = rec1[g];
             s_id[tid] = g;
-            s_rec0[tid] = rec0[g];
-            s_rec1[tid] = rec1[g];
+            s_rec0[tid] = a0;
+            s_rec1[tid] = a1;
+            m4 = quadrant_reach_mask(a0, a1, (float)(blockIdx.x * TILE), (float)(blockIdx.y * TILE));
+            s_any[tid] = (uint8_t)m4;
+        }
+        if (wave < BATCH / WAVE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t bal = __ballot((m4 >> q) & 1u);
+                if (lane == 0) s_cand[q][wave] = bal;
+            }
         }
         __syncthreads();
         // ---- stage feature rows: consecutive threads walk consecutive floats of a row ----
+#if SR_FWD_ABLATE != 3
         for (int e = tid; e < nb * NC; e += CF_THREADS) {
             const int row = e / NC, ch = e - row * NC;
-            s_feat[row * NCP + ch] = feat[(size_t)s_id[row] * C_total + c0 + ch];
+            if (s_any[row]) s_feat[row * NCP + ch] = feat[(size_t)s_id[row] * C_total + c0 + ch];
         }
+#endif
         __syncthreads();
-        if (!__all(done)) {
-            for (int j = 0; j < nb; ++j) {
+        bool wave_done = __all(done);
+#pragma unroll 1
+        for (int k = 0; k < BATCH / WAVE && !wave_done; ++k) {
+            uint64_t cand = uniform_u64(s_cand[wave][k]);
+            while (cand) {
+                const int j = k * WAVE + __builtin_ctzll(cand);
+                cand &= cand - 1;
                 const float4 r0 = s_rec0[j];
                 const float4 r1 = s_rec1[j];
                 const float dx = r0.x - fx, dy = r0.y - fy;
@@ -85,11 +109,16 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
                 const bool live = !done && power <= 0.0f && alpha >= ALPHA_MIN;
                 const bool hit = live && test_T >= T_EPS;
                 if (live && !hit) done = true;  // transmittance exhausted: pixel finished
+                if (__any(live && !hit) && __all(done)) { wave_done = true; break; }
                 if (__any(hit)) {
                     const float w = hit ? alpha * T : 0.0f;
                     const float* f = &s_feat[j * NCP];
+#if SR_FWD_ABLATE != 2
 #pragma unroll
                     for (int ch = 0; ch < NC; ++ch) acc[ch] += f[ch] * w;
+#else
+                    acc[0] += f[0] * w;
+#endif
                     D += r0.z * w;
                     if (hit) {
                         T = test_T;
@@ -101,14 +130,24 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
         contributor += (uint32_t)nb;
     }
 
+#if SR_FWD_ABLATE == 1
+    {
+        float keep = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) keep += acc[ch];
+        if (keep == 123.456f) out_color[0] = keep;
+    }
+#endif
     if (inside) {
         const size_t pix = (size_t)py * W + px;
         const size_t plane = (size_t)H * W;
+#if SR_FWD_ABLATE != 1
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
             const int c = c0 + ch;
             out_color[(size_t)c * plane + pix] = acc[ch] + T * (c < bg_channels ? bg[c] : 0.0f);
         }
+#endif
         if (write_aux) {
             out_depth[pix] = D;
             out_alpha[pix] = 1.0f - T;
