@@ -13,24 +13,32 @@
 // (pixel, Gaussian) instead of three per-channel recurrences.  Everything is linear in
 // (g, g_D, g_A), so channels can be split over several launches (generic C).
 //
-// Per (wave, Gaussian): 7 geometric partials + NC colour partials are reduced over the 64
-// pixels of the wave's 8x8 quadrant with DPP row reductions (no LDS traffic), gathered
-// into distinct lanes, and flushed with ONE wave-wide float atomic (contiguous addresses:
-// dL_dcolors row + the 32-byte geometric-gradient record of the Gaussian).
+// One 256-thread workgroup per 16x16 tile, wave w = 8x8 quadrant w.  Per (wave, Gaussian)
+// the per-pixel partials must be summed over the wave's 64 pixels:
+//   * 7 geometric partials (+ channels beyond the first 32): packed butterfly reduction
+//     (permlane32/16 swap + DPP, ~2.2 VALU per value), one wave-wide float atomic;
+//   * NC >= 32: dL/dfeature[g][ch] = sum_pix w[pix][g] * dL/dcolor[pix][ch] for the first 32
+//     channels is a dense [32 g x 64 pix] x [64 pix x 32 ch] contraction per group of 32
+//     contributing Gaussians: the weights are parked in LDS (one ds_write per step) and the
+//     contraction runs on the matrix pipe with v_mfma_f32_32x32x2_f32 — exact fp32 (a k-ordered
+//     fmaf chain), concurrent with the VALU work of the other resident waves.
 #include "composite_common.h"
-
-#ifndef SR_BWD_ABLATE
-#define SR_BWD_ABLATE 0  // perf ablation switch (tools/ablate.sh); 0 = product
-#endif
 
 namespace sr {
 
 constexpr int CB_THREADS = 256;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NC>
 struct BwdCfg {
+    static constexpr bool MFMA = NC >= 32;
+    static constexpr int NM = MFMA ? 32 : 0;   // channels reduced on the matrix pipe
+    static constexpr int NV = NC - NM;         // channels reduced with the packed butterfly
+    static constexpr int KRED = NV + 7;
     static constexpr int NCP = (NC + 3) & ~3;
-    static constexpr int BATCH = (NC > 16) ? 128 : 256;
+    static constexpr int BATCH = MFMA ? 64 : ((NC > 16) ? 128 : 256);
+    static constexpr int GROUP = 16;           // Gaussians per MFMA flush (M of v_mfma_f32_16x16x4_f32)
+    static constexpr int WS = 17;              // LDS row stride of the per-wave weight panel [64 pix][GROUP]
 };
 
 // ---- DPP helpers (wave64 = 4 rows of 16 lanes) -----------------------------------------
@@ -39,21 +47,6 @@ __device__ __forceinline__ float dpp_get(float v)
 {
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
-// full 64-lane sum; the total is valid in lanes 48..63 (row 3)
-__device__ __forceinline__ float wave_sum_row3(float v)
-{
-    v += dpp_get<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-    v += dpp_get<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-    v += dpp_get<0x141, 0xf>(v);  // row_half_mirror
-    v += dpp_get<0x140, 0xf>(v);  // row_mirror       -> every lane holds its row's sum
-    v += dpp_get<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
-    v += dpp_get<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ float lane63(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---- packed butterfly reduction -----------------------------------------------------------
@@ -144,10 +137,6 @@ __device__ __forceinline__ float wave_reduce_pack(const float (&v)[K], int lane)
     return keep6 + dpp_get<0xB1, 0xf>(send6);  // quad_perm [1,0,3,2]
 }
 
-#ifndef SR_BWD_REDUCE
-#define SR_BWD_REDUCE 1  // 1 = packed butterfly (product), 0 = per-value DPP reductions (A/B baseline)
-#endif
-
 template <int NC>
 __global__ void __launch_bounds__(CB_THREADS)
 composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
@@ -159,14 +148,21 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
                      const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
                      float* __restrict__ ggrad /*[P,8]*/, float* __restrict__ dcolors /*[P,C_total]*/)
 {
-    constexpr int NCP = BwdCfg<NC>::NCP;
-    constexpr int BATCH = BwdCfg<NC>::BATCH;
+    using Cfg = BwdCfg<NC>;
+    constexpr int NCP = Cfg::NCP, BATCH = Cfg::BATCH, NM = Cfg::NM, NV = Cfg::NV, KRED = Cfg::KRED;
+    constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
+    constexpr bool MFMA = Cfg::MFMA;
+    static_assert(KRED <= WAVE, "at most 57 butterfly-reduced channels per pass");
     __shared__ __attribute__((aligned(16))) float4 s_rec0[BATCH];
     __shared__ __attribute__((aligned(16))) float4 s_rec1[BATCH];
     __shared__ __attribute__((aligned(16))) float s_feat[BATCH * NCP];
     __shared__ uint32_t s_id[BATCH];
     __shared__ uint64_t s_cand[4][BATCH / WAVE];
     __shared__ uint8_t s_any[BATCH];
+    __shared__ uint32_t s_max[CB_THREADS / WAVE];
+    // matrix-pipe weight panel, one per wave: w[64 pix][GROUP]
+    __shared__ float s_w[MFMA ? 4 * WAVE * WS : 1];
+    __shared__ uint32_t s_gid[MFMA ? 4 * GROUP : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -203,11 +199,28 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) g[ch] = 0.0f;
     }
+    float* my_w = &s_w[MFMA ? wave * WAVE * WS : 0];
+    uint32_t* my_gid = &s_gid[MFMA ? wave * GROUP : 0];
+    // B operand of the contraction, kept in registers for the whole tile: for k-step kk and
+    // channel half t, lane l holds dL/dcolor[pix = 4 kk + (l >> 4)][ch = 16 t + (l & 15)].
+    // Built once by transposing through the (still unused) weight panel.
+    float gt[MFMA ? 16 : 1][2];
+    if (MFMA) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch) my_w[lane * WS + ch] = g[16 * t + ch];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) gt[kk][t] = my_w[(4 * kk + (lane >> 4)) * WS + (lane & 15)];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     // the tile only needs the list up to its deepest contributor
     uint32_t max_last = last;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) max_last = max(max_last, (uint32_t)__shfl_xor((int)max_last, d, WAVE));
-    __shared__ uint32_t s_max[CB_THREADS / WAVE];
     if (lane == 0) s_max[wave] = max_last;
     __syncthreads();
     const uint32_t tile_last = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
@@ -217,14 +230,37 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
     float T = 1.0f;
     uint32_t contributor = 0;
     const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
-#if SR_BWD_REDUCE
     // wave_reduce_pack leaves total k in lane bitreverse6(k)
-    constexpr int KRED = NC + 7;
     const int slot = (int)(__brev((unsigned)lane) >> 26);
-    const bool slot_col = slot < NC;
+    const bool slot_col = slot < NV;
     const bool slot_ok = slot < KRED;
-    const int slot_off = slot_col ? (c0 + slot) : (slot - NC);
-#endif
+    const int slot_off = slot_col ? (c0 + NM + slot) : (slot - NV);
+    int nslot = 0;  // Gaussians parked in the weight panel (wave-uniform)
+
+    // dL/dfeature of the parked Gaussians: D[g][ch] = sum_pix W[pix][g] * G[pix][ch]
+    // (v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
+    //  D[row = 4 (l >> 4) + reg][col = l & 15])
+    auto flush_panel = [&](int count) {
+        __builtin_amdgcn_wave_barrier();
+        f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
+        const int row = (lane >> 4) * WS + (lane & 15);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float a = my_w[4 * kk * WS + row];
+            D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][0], D0, 0, 0, 0);
+            D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][1], D1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gs = 4 * (lane >> 4) + r;
+            if (gs < count) {
+                float* dst = dcolors + (size_t)my_gid[gs] * C_total + c0 + (lane & 15);
+                atomicAdd(dst, D0[r]);
+                atomicAdd(dst + 16, D1[r]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
 
     for (uint32_t base = beg; todo > 0; base += BATCH, todo -= BATCH) {
         const int nb = todo < BATCH ? todo : BATCH;
@@ -255,100 +291,64 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
         const int nw = (int)min((uint32_t)nb, wave_last > contributor ? wave_last - contributor : 0u);
 #pragma unroll 1
         for (int k = 0; k * WAVE < nw; ++k) {
-          uint64_t cand = uniform_u64(s_cand[wave][k]);
-          const int lim = nw - k * WAVE;  // only list positions below the wave's deepest contributor
-          if (lim < WAVE) cand &= (1ull << lim) - 1ull;
-          while (cand) {
-            const int j = k * WAVE + __builtin_ctzll(cand);
-            cand &= cand - 1;
-            const float4 r0 = s_rec0[j];
-            const float4 r1 = s_rec1[j];
-            const float dx = r0.x - fx, dy = r0.y - fy;
-            const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(ALPHA_MAX, r1.w * G);
-            const bool hit = (contributor + (uint32_t)j < last) && power <= 0.0f && alpha >= ALPHA_MIN;
-            if (!__any(hit)) continue;
-#if SR_BWD_ABLATE >= 3
-            { T *= hit ? (1.0f - alpha) : 1.0f; continue; }
-#endif
-            const float* f = &s_feat[j * NCP];
-            const float w = hit ? alpha * T : 0.0f;
-            float q = r0.z * gD;
+            uint64_t cand = uniform_u64(s_cand[wave][k]);
+            const int lim = nw - k * WAVE;  // only list positions below the wave's deepest contributor
+            if (lim < WAVE) cand &= (1ull << lim) - 1ull;
+            while (cand) {
+                const int j = k * WAVE + __builtin_ctzll(cand);
+                cand &= cand - 1;
+                const float4 r0 = s_rec0[j];
+                const float4 r1 = s_rec1[j];
+                const float dx = r0.x - fx, dy = r0.y - fy;
+                const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(ALPHA_MAX, r1.w * G);
+                const bool hit = (contributor + (uint32_t)j < last) && power <= 0.0f && alpha >= ALPHA_MIN;
+                if (!__any(hit)) continue;
+                const float* f = &s_feat[j * NCP];
+                const float w = hit ? alpha * T : 0.0f;
+                float q = r0.z * gD;
 #pragma unroll
-            for (int ch = 0; ch < NC; ++ch) q += f[ch] * g[ch];
-            const float one_m = 1.0f - alpha;
-            float dL_dalpha_i = 0.0f;
-            if (hit) {
-                S -= w * q;
-                dL_dalpha_i = T * q - S * __frcp_rn(one_m);
-                T *= one_m;
+                for (int ch = 0; ch < NC; ++ch) q += f[ch] * g[ch];
+                const float one_m = 1.0f - alpha;
+                float dL_dalpha_i = 0.0f;
+                if (hit) {
+                    S -= w * q;
+                    dL_dalpha_i = T * q - S * __frcp_rn(one_m);
+                    T *= one_m;
+                }
+                const float dL_dG = r1.w * dL_dalpha_i;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
+                const float dG_ddely = -gdy * r1.z - gdx * r1.y;
+                float red[KRED];
+#pragma unroll
+                for (int ch = 0; ch < NV; ++ch) red[ch] = w * g[NM + ch];
+                red[NV + 0] = dL_dG * dG_ddelx * halfW;
+                red[NV + 1] = dL_dG * dG_ddely * halfH;
+                red[NV + 2] = -0.5f * gdx * dx * dL_dG;
+                red[NV + 3] = -gdx * dy * dL_dG;
+                red[NV + 4] = -0.5f * gdy * dy * dL_dG;
+                red[NV + 5] = G * dL_dalpha_i;
+                red[NV + 6] = w * gD;
+                const float outv = wave_reduce_pack<KRED>(red, lane);
+                const uint32_t gi = s_id[j];
+                float* dst = slot_col ? (dcolors + (size_t)gi * C_total + slot_off)
+                                      : (ggrad + (size_t)gi * 8 + slot_off);
+                if (slot_ok) atomicAdd(dst, outv);
+                if (MFMA) {
+                    my_w[lane * WS + nslot] = w;  // park the weights (0 for pixels that miss)
+                    if (lane == 0) my_gid[nslot] = gi;
+                    if (++nslot == GROUP) {
+                        flush_panel(GROUP);
+                        nslot = 0;
+                    }
+                }
             }
-            const float dL_dG = r1.w * dL_dalpha_i;
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
-            const float dG_ddely = -gdy * r1.z - gdx * r1.y;
-            float v[8];
-            v[0] = dL_dG * dG_ddelx * halfW;
-            v[1] = dL_dG * dG_ddely * halfH;
-            v[2] = -0.5f * gdx * dx * dL_dG;
-            v[3] = -gdx * dy * dL_dG;
-            v[4] = -0.5f * gdy * dy * dL_dG;
-            v[5] = G * dL_dalpha_i;
-            v[6] = w * gD;
-#if SR_BWD_ABLATE >= 2
-            {
-                float keep = 0.f;
-#pragma unroll
-                for (int k = 0; k < 7; ++k) keep += v[k];
-#pragma unroll
-                for (int ch = 0; ch < NC; ++ch) keep += w * g[ch];
-                asm volatile("" ::"v"(keep));
-                continue;
-            }
-#endif
-#if SR_BWD_REDUCE
-            static_assert(NC + 7 <= WAVE, "packed reduction handles at most 57 channels per pass");
-            float red[KRED];
-#pragma unroll
-            for (int ch = 0; ch < NC; ++ch) red[ch] = w * g[ch];
-#pragma unroll
-            for (int k = 0; k < 7; ++k) red[NC + k] = v[k];
-            const float outv = wave_reduce_pack<KRED>(red, lane);
-            const uint32_t gi = s_id[j];
-            float* dst = slot_col ? (dcolors + (size_t)gi * C_total + slot_off)
-                                  : (ggrad + (size_t)gi * 8 + slot_off);
-#if SR_BWD_ABLATE >= 1
-            asm volatile("" ::"v"(outv), "v"(dst));
-#else
-            if (slot_ok) atomicAdd(dst, outv);
-#endif
-#else
-            // reduce over the wave and gather value k into lane k
-            float outv = 0.0f;
-#pragma unroll
-            for (int ch = 0; ch < NC; ++ch) {
-                const float t = lane63(wave_sum_row3(w * g[ch]));
-                outv = (lane == ch) ? t : outv;
-            }
-            const uint32_t gi = s_id[j];
-#pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const float t = lane63(wave_sum_row3(v[k]));
-                outv = (lane == NC + k) ? t : outv;
-            }
-            float* dst = (lane < NC) ? (dcolors + (size_t)gi * C_total + c0 + lane)
-                                     : (ggrad + (size_t)gi * 8 + (lane - NC));
-#if SR_BWD_ABLATE >= 1
-            asm volatile("" ::"v"(outv), "v"(dst));
-#else
-            if (lane < NC + 7) atomicAdd(dst, outv);
-#endif
-#endif
-          }
         }
         contributor += (uint32_t)nb;
     }
+    if (MFMA && nslot > 0) flush_panel(nslot);
 }
 
 template <int NC>
