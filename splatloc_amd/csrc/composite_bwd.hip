@@ -24,6 +24,13 @@
 //     fmaf chain), concurrent with the VALU work of the other resident waves.
 #include "composite_common.h"
 
+#ifndef SR_BWD_MFMA_BATCH
+#define SR_BWD_MFMA_BATCH 128  // A/B on S2: 128 + 4 waves/SIMD = 1.54 ms vs 64/3 = 1.68 ms
+#endif
+#ifndef SR_BWD_MINW
+#define SR_BWD_MINW 4  // waves per SIMD the register allocator must allow (5 spills: 5.9 ms)
+#endif
+
 namespace sr {
 
 constexpr int CB_THREADS = 256;
@@ -36,7 +43,7 @@ struct BwdCfg {
     static constexpr int NV = NC - NM;         // channels reduced with the packed butterfly
     static constexpr int KRED = NV + 7;
     static constexpr int NCP = (NC + 3) & ~3;
-    static constexpr int BATCH = MFMA ? 64 : ((NC > 16) ? 128 : 256);
+    static constexpr int BATCH = MFMA ? SR_BWD_MFMA_BATCH : ((NC > 16) ? 128 : 256);
     static constexpr int GROUP = 16;           // Gaussians per MFMA flush (M of v_mfma_f32_16x16x4_f32)
     static constexpr int WS = 17;              // LDS row stride of the per-wave weight panel [64 pix][GROUP]
 };
@@ -138,7 +145,7 @@ __device__ __forceinline__ float wave_reduce_pack(const float (&v)[K], int lane)
 }
 
 template <int NC>
-__global__ void __launch_bounds__(CB_THREADS)
+__global__ void __launch_bounds__(CB_THREADS, SR_BWD_MINW)
 composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                      const float4* __restrict__ rec0, const float4* __restrict__ rec1,
