@@ -7,19 +7,38 @@
 // quadrant is skipped by the whole wave with one ballot.  The tile's list is consumed in
 // batches staged in LDS: 32-byte projected records + the feature rows (4*C bytes each),
 // fetched with coalesced global loads and read back as wave-uniform (broadcast) LDS reads.
-// VALU/LDS-bound; no MFMA (no dense contraction in this form).
+// VALU-bound.
+//
+// NC >= 32: the accumulation of the first 32 channels, out[pix][ch] += w[pix][g] * F[g][ch],
+// is a [32 ch x 2 g] x [2 g x 32 pix] product per pair of contributing Gaussians and runs on
+// the matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fmaf chain = the sequential
+// front-to-back sum).  A operand: one conflict-free ds_read_b32 of the two staged feature
+// rows; B operand: the two weight registers of the pair after ONE v_permlane32_swap
+// (lanes 0-31 <- pixels 0-31 / 32-63 of Gaussian 0, lanes 32-63 <- of Gaussian 1).
 #include "composite_common.h"
-
-#ifndef SR_FWD_ABLATE
-#define SR_FWD_ABLATE 0  // perf ablation switch (tools/ablate.py); 0 = product
-#endif
 
 namespace sr {
 
 constexpr int CF_THREADS = 256;
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// In-place half swap: afterwards x = [x.lanes0-31 | y.lanes0-31], y = [x.lanes32-63 | y.lanes32-63].
+// Inline asm on purpose: with ROCm 7.2 hipcc, feeding BOTH results of
+// __builtin_amdgcn_permlane32_swap to MFMA B operands made the second MFMA read the first
+// result's register (seen in the .s; image rows 4-7 of every quadrant repeated rows 0-3).
+// The s_nop pads cover VALU-write -> permlane read and permlane write -> MFMA read hazards,
+// which the compiler does not insert inside asm statements.
+__device__ __forceinline__ void swap_halves(float& x, float& y)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+}
+
 template <int NC>
 struct FwdCfg {
+    static constexpr bool MFMA = NC >= 32;
+    static constexpr int NM = MFMA ? 32 : 0;            // channels accumulated on the matrix pipe
+    static constexpr int NV = NC - NM;                  // channels accumulated with VALU FMAs
     static constexpr int NCP = (NC + 3) & ~3;           // LDS row stride (floats), 16-B aligned rows
     static constexpr int BATCH = (NC > 16) ? 128 : 256; // Gaussians staged per round
 };
@@ -36,6 +55,8 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
 {
     constexpr int NCP = FwdCfg<NC>::NCP;
     constexpr int BATCH = FwdCfg<NC>::BATCH;
+    constexpr bool MFMA = FwdCfg<NC>::MFMA;
+    constexpr int NM = FwdCfg<NC>::NM, NV = FwdCfg<NC>::NV;
     __shared__ __attribute__((aligned(16))) float4 s_rec0[BATCH];
     __shared__ __attribute__((aligned(16))) float4 s_rec1[BATCH];
     __shared__ __attribute__((aligned(16))) float s_feat[BATCH * NCP];
@@ -58,9 +79,21 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
 
     bool done = !inside;
     float T = 1.0f, D = 0.0f;
-    float acc[NC];
+    float acc[NV > 0 ? NV : 1];  // VALU-accumulated channels (all of them when NC < 32)
 #pragma unroll
-    for (int ch = 0; ch < NC; ++ch) acc[ch] = 0.0f;
+    for (int ch = 0; ch < NV; ++ch) acc[ch] = 0.0f;
+    // matrix-pipe accumulators D[ch][pix]: accA = pixels (lanes) 0-31 of the wave, accB = 32-63
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accA[r] = 0.0f; accB[r] = 0.0f; }
+    float w_pend = 0.0f;  // weights of a contributing Gaussian waiting for its pair partner
+    int j_pend = -1;      // its row in the staged batch (wave-uniform), -1 = none
+    auto mfma_pair = [&](int j0, float w0, int j1, float w1) {
+        const float a = s_feat[((lane >> 5) ? j1 : j0) * NCP + (lane & 31)];  // A[i = ch][k = g]
+        swap_halves(w0, w1);  // w0 -> B for pixels 0-31, w1 -> B for pixels 32-63
+        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, accB, 0, 0, 0);
+    };
     uint32_t contributor = 0, last = 0;
 
     for (uint32_t base = beg; todo > 0; base += BATCH, todo -= BATCH) {
@@ -86,12 +119,10 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
         }
         __syncthreads();
         // ---- stage feature rows: consecutive threads walk consecutive floats of a row ----
-#if SR_FWD_ABLATE != 3
         for (int e = tid; e < nb * NC; e += CF_THREADS) {
             const int row = e / NC, ch = e - row * NC;
             if (s_any[row]) s_feat[row * NCP + ch] = feat[(size_t)s_id[row] * C_total + c0 + ch];
         }
-#endif
         __syncthreads();
         bool wave_done = __all(done);
 #pragma unroll 1
@@ -112,14 +143,19 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
                 if (__any(live && !hit) && __all(done)) { wave_done = true; break; }
                 if (__any(hit)) {
                     const float w = hit ? alpha * T : 0.0f;
-                    const float* f = &s_feat[j * NCP];
-#if SR_FWD_ABLATE != 2
+                    const float* f = &s_feat[j * NCP + NM];
 #pragma unroll
-                    for (int ch = 0; ch < NC; ++ch) acc[ch] += f[ch] * w;
-#else
-                    acc[0] += f[0] * w;
-#endif
+                    for (int ch = 0; ch < NV; ++ch) acc[ch] += f[ch] * w;
                     D += r0.z * w;
+                    if (MFMA) {
+                        if (j_pend < 0) {
+                            w_pend = w;
+                            j_pend = j;
+                        } else {
+                            mfma_pair(j_pend, w_pend, j, w);
+                            j_pend = -1;
+                        }
+                    }
                     if (hit) {
                         T = test_T;
                         last = contributor + (uint32_t)j + 1u;
@@ -127,27 +163,40 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
                 }
             }
         }
+        // the staged rows are about to be overwritten: retire an unpaired Gaussian (partner weight 0)
+        if (MFMA && j_pend >= 0) {
+            mfma_pair(j_pend, w_pend, j_pend, 0.0f);
+            j_pend = -1;
+        }
         contributor += (uint32_t)nb;
     }
 
-#if SR_FWD_ABLATE == 1
-    {
-        float keep = 0.f;
+    if (MFMA) {
+        // D[ch][pix]: lane l, register r holds channel (r&3) + 8 (r>>2) + 4 (l>>5) of wave pixel
+        // (l & 31) [accA] / 32 + (l & 31) [accB]; T of those pixels comes from lanes (l&31), 32+(l&31).
+        float TA = T, TB = T;
+        swap_halves(TA, TB);
+        const int qx = blockIdx.x * TILE + (wave & 1) * 8, qy = blockIdx.y * TILE + (wave >> 1) * 8;
+        const int pa = lane & 31, pb = 32 + (lane & 31);
+        const int xa = qx + (pa & 7), ya = qy + (pa >> 3), xb = qx + (pb & 7), yb = qy + (pb >> 3);
+        const bool ina = xa < W && ya < H, inb = xb < W && yb < H;
+        const size_t plane = (size_t)H * W;
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch) keep += acc[ch];
-        if (keep == 123.456f) out_color[0] = keep;
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float bgc = c < bg_channels ? bg[c] : 0.0f;
+            if (ina) out_color[(size_t)c * plane + (size_t)ya * W + xa] = accA[r] + TA * bgc;
+            if (inb) out_color[(size_t)c * plane + (size_t)yb * W + xb] = accB[r] + TB * bgc;
+        }
     }
-#endif
     if (inside) {
         const size_t pix = (size_t)py * W + px;
         const size_t plane = (size_t)H * W;
-#if SR_FWD_ABLATE != 1
 #pragma unroll
-        for (int ch = 0; ch < NC; ++ch) {
-            const int c = c0 + ch;
+        for (int ch = 0; ch < NV; ++ch) {
+            const int c = c0 + NM + ch;
             out_color[(size_t)c * plane + pix] = acc[ch] + T * (c < bg_channels ? bg[c] : 0.0f);
         }
-#endif
         if (write_aux) {
             out_depth[pix] = D;
             out_alpha[pix] = 1.0f - T;
