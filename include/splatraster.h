@@ -206,7 +206,8 @@ int splatknn_dist2(int32_t N, const float* points /* [N,3] */, float* out /* [N]
 #define SPLATRASTER_STAGE_COMPOSITE_FWD 6  /* composite_fwd_kernel */
 #define SPLATRASTER_STAGE_COMPOSITE_BWD 7  /* memset of gradient buffers + composite_bwd_kernel */
 #define SPLATRASTER_STAGE_PREPROCESS_BWD 8 /* preprocess_bwd_kernel */
-#define SPLATRASTER_STAGE_COUNT 9
+#define SPLATRASTER_STAGE_PAYLOAD 9        /* payload_kernel: per-instance records + quadrant reach masks */
+#define SPLATRASTER_STAGE_COUNT 10
 
 int splatraster_timing_enable(int on);
 /* Waits for all recorded events, ADDS elapsed milliseconds / launch counts per stage into

@@ -108,7 +108,7 @@ def check(status: int, what: str) -> None:
 
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "composite_fwd", "composite_bwd",
-          "preprocess_bwd")
+          "preprocess_bwd", "payload")
 
 
 def timing_enable(on: bool) -> None:

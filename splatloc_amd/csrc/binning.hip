@@ -7,7 +7,7 @@
 //   2. instances are emitted IN DEPTH ORDER, one thread per instance (coalesced writes);
 //   3. a stable sort of the R instances on the tile id only (<= 16 bits, 2 passes).
 // Because both sorts are stable, ties resolve exactly as in the 64-bit formulation.
-#include "common.h"
+#include "composite_common.h"
 
 namespace sr {
 
@@ -97,6 +97,36 @@ int launch_ranges(int64_t R, int32_t tiles, const uint32_t* tile_list, uint32_t*
     if (R == 0) return SPLATRASTER_OK;
     hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, tile_list,
                        ranges);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
+// Per-instance payload, written once per frame in sorted order so that every later reader
+// (forward and backward compositing, four quadrant-waves per tile) streams it with coalesced
+// loads instead of chasing id -> record through 16-byte gathers scattered over HBM:
+//   irec0/irec1[j] = the projected record of point_list[j];  imask[j] = quadrant reach bits.
+__global__ void __launch_bounds__(256)
+payload_kernel(int64_t R, int gx, const uint32_t* __restrict__ point_list,
+               const uint32_t* __restrict__ tile_list, const float4* __restrict__ rec0,
+               const float4* __restrict__ rec1, float4* __restrict__ irec0, float4* __restrict__ irec1,
+               uint8_t* __restrict__ imask)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    const uint32_t g = point_list[j], t = tile_list[j];
+    const float4 a0 = rec0[g], a1 = rec1[g];
+    const uint32_t ty = t / (uint32_t)gx, tx = t - ty * (uint32_t)gx;
+    irec0[j] = a0;
+    irec1[j] = a1;
+    imask[j] = (uint8_t)quadrant_reach_mask(a0, a1, (float)(tx * TILE), (float)(ty * TILE));
+}
+
+int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b, hipStream_t stream)
+{
+    if (R == 0) return SPLATRASTER_OK;
+    const int gx = (s.image_width + TILE - 1) / TILE;
+    hipLaunchKernelGGL(payload_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, b.point_list,
+                       b.tile_list, g.rec0, g.rec1, b.irec0, b.irec1, b.imask);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

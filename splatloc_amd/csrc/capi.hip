@@ -110,7 +110,7 @@ GeomView geom_view(void* base, int32_t P)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec0, irec1, imask, bytes;
 };
 static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
 {
@@ -125,6 +125,9 @@ static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
     L.valsB = take(4 * n);
     L.ranges = take(8 * (tiles > 0 ? tiles : 1));
     L.sort_tmp = take(sort_tmp_bytes((int64_t)n));
+    L.irec0 = take(16 * n);
+    L.irec1 = take(16 * n);
+    L.imask = take(n);
     L.bytes = o;
     return L;
 }
@@ -141,6 +144,9 @@ BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H)
     v.vals_tmp = reinterpret_cast<uint32_t*>(b + L.valsB);
     v.ranges = reinterpret_cast<uint32_t*>(b + L.ranges);
     v.sort_tmp = b + L.sort_tmp;
+    v.irec0 = reinterpret_cast<float4*>(b + L.irec0);
+    v.irec1 = reinterpret_cast<float4*>(b + L.irec1);
+    v.imask = reinterpret_cast<uint8_t*>(b + L.imask);
     return v;
 }
 
@@ -318,6 +324,11 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
     {
         StageTimer t(SPLATRASTER_STAGE_RANGES, stream);
         st = launch_ranges(R, tiles, b.tile_list, b.ranges, stream);
+    }
+    if (st) return st;
+    if (R > 0) {
+        StageTimer t(SPLATRASTER_STAGE_PAYLOAD, stream);
+        st = launch_payload(*s, R, g, b, stream);
     }
     if (st) return st;
     StageTimer t(SPLATRASTER_STAGE_COMPOSITE_FWD, stream);

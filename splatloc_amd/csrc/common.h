@@ -62,6 +62,9 @@ struct BinView {
     uint32_t* keys_tmp;   // [R] unsorted tile ids
     uint32_t* vals_tmp;   // [R] unsorted gaussian ids
     void* sort_tmp;       // radix sort scratch
+    float4* irec0;        // [R] per-instance copy of rec0 (sorted order): px, py, depth, radius
+    float4* irec1;        // [R] per-instance copy of rec1: conic a, b, c, opacity
+    uint8_t* imask;       // [R] bit q: the Gaussian may reach quadrant q of its tile
 };
 struct ImgView {
     float* final_T;
@@ -98,6 +101,7 @@ int launch_depth_keys(int32_t P, const GeomView& g, hipStream_t stream);
 int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
                 uint32_t* vals, hipStream_t stream);
 int launch_ranges(int64_t R, int32_t tiles, const uint32_t* tile_list, uint32_t* ranges, hipStream_t stream);
+int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b, hipStream_t stream);
 
 int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b,
                          const ImgView& im, const float* feat, const float* bg, float* out_color,

@@ -13,27 +13,26 @@
 // (pixel, Gaussian) instead of three per-channel recurrences.  Everything is linear in
 // (g, g_D, g_A), so channels can be split over several launches (generic C).
 //
-// One 256-thread workgroup per 16x16 tile, wave w = 8x8 quadrant w.  Per (wave, Gaussian)
-// the per-pixel partials must be summed over the wave's 64 pixels:
-//   * 7 geometric partials (+ channels beyond the first 32): packed butterfly reduction
-//     (permlane32/16 swap + DPP, ~2.2 VALU per value), one wave-wide float atomic;
+// Machine mapping = the forward's (composite_fwd.hip): ONE wave64 = one workgroup = one 8x8
+// quadrant, the tile's list streamed from the per-instance payload (mask byte + record),
+// candidates' feature rows gathered into LDS, candidates processed two at a time; no
+// __syncthreads.  Per (wave, Gaussian) the per-pixel partials are summed over the 64 pixels:
+//   * 7 geometric partials (+ channels beyond the first 32) of BOTH Gaussians of a pair:
+//     one packed butterfly reduction (permlane32/16 swap + DPP, ~2.2 VALU per value) and one
+//     wave-wide float atomic;
 //   * NC >= 32: dL/dfeature[g][ch] = sum_pix w[pix][g] * dL/dcolor[pix][ch] for the first 32
-//     channels is a dense [32 g x 64 pix] x [64 pix x 32 ch] contraction per group of 32
-//     contributing Gaussians: the weights are parked in LDS (one ds_write per step) and the
-//     contraction runs on the matrix pipe with v_mfma_f32_32x32x2_f32 — exact fp32 (a k-ordered
-//     fmaf chain), concurrent with the VALU work of the other resident waves.
+//     channels is a dense [16 g x 64 pix] x [64 pix x 32 ch] contraction per group of 16
+//     contributing Gaussians: the weights are parked in a 4-KB LDS panel (one ds_write per
+//     step), the dL/dcolor panel lives in registers for the whole tile, and the contraction
+//     runs on the matrix pipe with v_mfma_f32_16x16x4_f32 — exact fp32 (k-ordered fmaf chain).
 #include "composite_common.h"
 
-#ifndef SR_BWD_MFMA_BATCH
-#define SR_BWD_MFMA_BATCH 128  // A/B on S2: 128 + 4 waves/SIMD = 1.54 ms vs 64/3 = 1.68 ms
-#endif
 #ifndef SR_BWD_MINW
-#define SR_BWD_MINW 4  // waves per SIMD the register allocator must allow (5 spills: 5.9 ms)
+#define SR_BWD_MINW 3  // waves per SIMD the register allocator must allow (4 spills at C = 35: 1.98 vs 1.52 ms)
 #endif
 
 namespace sr {
 
-constexpr int CB_THREADS = 256;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NC>
@@ -41,11 +40,11 @@ struct BwdCfg {
     static constexpr bool MFMA = NC >= 32;
     static constexpr int NM = MFMA ? 32 : 0;   // channels reduced on the matrix pipe
     static constexpr int NV = NC - NM;         // channels reduced with the packed butterfly
-    static constexpr int KRED = NV + 7;
+    static constexpr int KV = NV + 7;          // butterfly values per Gaussian
     static constexpr int NCP = (NC + 3) & ~3;
-    static constexpr int BATCH = MFMA ? SR_BWD_MFMA_BATCH : ((NC > 16) ? 128 : 256);
+    static constexpr int FS = 32;              // feature rows staged per round
     static constexpr int GROUP = 16;           // Gaussians per MFMA flush (M of v_mfma_f32_16x16x4_f32)
-    static constexpr int WS = 17;              // LDS row stride of the per-wave weight panel [64 pix][GROUP]
+    static constexpr int WS = 17;              // LDS row stride of the weight panel [64 pix][GROUP]
 };
 
 // ---- DPP helpers (wave64 = 4 rows of 16 lanes) -----------------------------------------
@@ -145,45 +144,41 @@ __device__ __forceinline__ float wave_reduce_pack(const float (&v)[K], int lane)
 }
 
 template <int NC>
-__global__ void __launch_bounds__(CB_THREADS, SR_BWD_MINW)
-composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
+__global__ void __launch_bounds__(WAVE, SR_BWD_MINW)
+composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass, int tiles,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                     const float4* __restrict__ rec0, const float4* __restrict__ rec1,
-                     const float* __restrict__ feat, const float* __restrict__ out_color,
-                     const float* __restrict__ out_depth, const float* __restrict__ final_T,
-                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-                     const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
-                     float* __restrict__ ggrad /*[P,8]*/, float* __restrict__ dcolors /*[P,C_total]*/)
+                     const float4* __restrict__ irec0, const float4* __restrict__ irec1,
+                     const uint8_t* __restrict__ imask, const float* __restrict__ feat,
+                     const float* __restrict__ out_color, const float* __restrict__ out_depth,
+                     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+                     const float* __restrict__ dL_dalpha, float* __restrict__ ggrad /*[P,8]*/,
+                     float* __restrict__ dcolors /*[P,C_total]*/)
 {
     using Cfg = BwdCfg<NC>;
-    constexpr int NCP = Cfg::NCP, BATCH = Cfg::BATCH, NM = Cfg::NM, NV = Cfg::NV, KRED = Cfg::KRED;
+    constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
     constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
     constexpr bool MFMA = Cfg::MFMA;
-    static_assert(KRED <= WAVE, "at most 57 butterfly-reduced channels per pass");
-    __shared__ __attribute__((aligned(16))) float4 s_rec0[BATCH];
-    __shared__ __attribute__((aligned(16))) float4 s_rec1[BATCH];
-    __shared__ __attribute__((aligned(16))) float s_feat[BATCH * NCP];
-    __shared__ uint32_t s_id[BATCH];
-    __shared__ uint64_t s_cand[4][BATCH / WAVE];
-    __shared__ uint8_t s_any[BATCH];
-    __shared__ uint32_t s_max[CB_THREADS / WAVE];
-    // matrix-pipe weight panel, one per wave: w[64 pix][GROUP]
-    __shared__ float s_w[MFMA ? 4 * WAVE * WS : 1];
-    __shared__ uint32_t s_gid[MFMA ? 4 * GROUP : 1];
+    static_assert(2 * KV <= WAVE, "at most 25 butterfly-reduced channels per pass");
+    __shared__ __attribute__((aligned(16))) float4 s_rec0[WAVE];
+    __shared__ __attribute__((aligned(16))) float4 s_rec1[WAVE];
+    __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
+    __shared__ uint32_t s_cgid[FS];
+    __shared__ float s_w[MFMA ? WAVE * WS : 1];   // matrix-pipe weight panel w[64 pix][GROUP]
+    __shared__ uint32_t s_gid[MFMA ? GROUP : 1];  // Gaussian id of every parked panel column
 
-    const int tid = threadIdx.x;
-    const int lane = tid & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    int tile, quad;
+    quadrant_of_block(blockIdx.x, tile, quad);
+    if (tile >= tiles) return;
+    const int lane = threadIdx.x;
     const int gx = (W + TILE - 1) / TILE;
-    const int tile = blockIdx.y * gx + blockIdx.x;
-    const int px = blockIdx.x * TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int qx = (tile % gx) * TILE + (quad & 1) * 8, qy = (tile / gx) * TILE + (quad >> 1) * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
     const size_t plane = (size_t)H * W;
     const size_t pix = inside ? (size_t)py * W + px : 0;
-
-    const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+    const uint32_t beg = ranges[2 * tile], end0 = ranges[2 * tile + 1];
 
     // per-pixel constants
     float g[NC];
@@ -206,8 +201,6 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) g[ch] = 0.0f;
     }
-    float* my_w = &s_w[MFMA ? wave * WAVE * WS : 0];
-    uint32_t* my_gid = &s_gid[MFMA ? wave * GROUP : 0];
     // B operand of the contraction, kept in registers for the whole tile: for k-step kk and
     // channel half t, lane l holds dL/dcolor[pix = 4 kk + (l >> 4)][ch = 16 t + (l & 15)].
     // Built once by transposing through the (still unused) weight panel.
@@ -217,31 +210,30 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
         for (int t = 0; t < 2; ++t) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int ch = 0; ch < 16; ++ch) my_w[lane * WS + ch] = g[16 * t + ch];
+            for (int ch = 0; ch < 16; ++ch) s_w[lane * WS + ch] = g[16 * t + ch];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) gt[kk][t] = my_w[(4 * kk + (lane >> 4)) * WS + (lane & 15)];
+            for (int kk = 0; kk < 16; ++kk) gt[kk][t] = s_w[(4 * kk + (lane >> 4)) * WS + (lane & 15)];
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // the tile only needs the list up to its deepest contributor
-    uint32_t max_last = last;
+    // this quadrant only needs the list up to its deepest contributor
+    uint32_t wave_last = last;
 #pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) max_last = max(max_last, (uint32_t)__shfl_xor((int)max_last, d, WAVE));
-    if (lane == 0) s_max[wave] = max_last;
-    __syncthreads();
-    const uint32_t tile_last = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    const uint32_t wave_last = max_last;
-    int todo = (int)min(end - beg, tile_last);
+    for (int d = 1; d < WAVE; d <<= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, d, WAVE));
+    const uint32_t end = min(end0, beg + wave_last);
 
     float T = 1.0f;
-    uint32_t contributor = 0;
     const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
-    // wave_reduce_pack leaves total k in lane bitreverse6(k)
-    const int slot = (int)(__brev((unsigned)lane) >> 26);
-    const bool slot_col = slot < NV;
-    const bool slot_ok = slot < KRED;
-    const int slot_off = slot_col ? (c0 + NM + slot) : (slot - NV);
+    // wave_reduce_pack leaves total k in lane bitreverse6(k); values [0, KV) belong to the first
+    // Gaussian of a pair, [KV, 2 KV) to the second; inside a Gaussian: NV colours then 7 geometric
+    const int slotv = (int)(__brev((unsigned)lane) >> 26);
+    const bool slot_second = slotv >= KV;
+    const int sv = slot_second ? slotv - KV : slotv;
+    const bool slot_col = sv < NV;
+    const bool slot_ok = slotv < 2 * KV;
+    const int slot_off = slot_col ? (c0 + NM + sv) : (sv - NV);
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
     int nslot = 0;  // Gaussians parked in the weight panel (wave-uniform)
 
     // dL/dfeature of the parked Gaussians: D[g][ch] = sum_pix W[pix][g] * G[pix][ch]
@@ -253,7 +245,7 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
         const int row = (lane >> 4) * WS + (lane & 15);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            const float a = my_w[4 * kk * WS + row];
+            const float a = s_w[4 * kk * WS + row];
             D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][0], D0, 0, 0, 0);
             D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][1], D1, 0, 0, 0);
         }
@@ -261,7 +253,7 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
         for (int r = 0; r < 4; ++r) {
             const int gs = 4 * (lane >> 4) + r;
             if (gs < count) {
-                float* dst = dcolors + (size_t)my_gid[gs] * C_total + c0 + (lane & 15);
+                float* dst = dcolors + (size_t)s_gid[gs] * C_total + c0 + (lane & 15);
                 atomicAdd(dst, D0[r]);
                 atomicAdd(dst + 16, D1[r]);
             }
@@ -269,91 +261,137 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass,
         __builtin_amdgcn_wave_barrier();
     };
 
-    for (uint32_t base = beg; todo > 0; base += BATCH, todo -= BATCH) {
-        const int nb = todo < BATCH ? todo : BATCH;
-        __syncthreads();
-        unsigned m4 = 0u;
-        if (tid < nb) {
-            const uint32_t gi = point_list[base + tid];
-            const float4 a0 = rec0[gi], a1 = rec1[gi];
-            s_id[tid] = gi;
-            s_rec0[tid] = a0;
-            s_rec1[tid] = a1;
-            m4 = quadrant_reach_mask(a0, a1, (float)(blockIdx.x * TILE), (float)(blockIdx.y * TILE));
-            s_any[tid] = (uint8_t)m4;
+    // chunk in flight: mask bit, id and record of list entry base + lane
+    bool reach = false;
+    uint32_t gid = 0;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    auto fetch = [&](uint32_t base, bool& r_, uint32_t& g_, float4& x0, float4& x1) {
+        r_ = false;
+        if (base + (uint32_t)lane < end) {
+            const uint32_t j = base + (uint32_t)lane;
+            r_ = (imask[j] >> quad) & 1u;
+            g_ = point_list[j];
+            x0 = irec0[j];
+            x1 = irec1[j];
         }
-        if (wave < BATCH / WAVE) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint64_t bal = __ballot((m4 >> q) & 1u);
-                if (lane == 0) s_cand[q][wave] = bal;
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < nb * NC; e += CB_THREADS) {
-            const int row = e / NC, ch = e - row * NC;
-            if (s_any[row]) s_feat[row * NCP + ch] = feat[(size_t)s_id[row] * C_total + c0 + ch];
-        }
-        __syncthreads();
-        const int nw = (int)min((uint32_t)nb, wave_last > contributor ? wave_last - contributor : 0u);
+    };
+    fetch(beg, reach, gid, a0, a1);
+
 #pragma unroll 1
-        for (int k = 0; k * WAVE < nw; ++k) {
-            uint64_t cand = uniform_u64(s_cand[wave][k]);
-            const int lim = nw - k * WAVE;  // only list positions below the wave's deepest contributor
-            if (lim < WAVE) cand &= (1ull << lim) - 1ull;
-            while (cand) {
-                const int j = k * WAVE + __builtin_ctzll(cand);
+    for (uint32_t base = beg; base < end; base += WAVE) {
+        uint64_t cand = __builtin_amdgcn_ballot_w64(reach);
+        const uint32_t cur_gid = gid;
+        const bool cur_reach = reach;
+        if (cand != 0) {
+            __builtin_amdgcn_wave_barrier();
+            s_rec0[lane] = a0;
+            s_rec1[lane] = a1;
+        }
+        fetch(base + WAVE, reach, gid, a0, a1);  // next chunk, consumed after this one
+        const uint32_t idx0 = base - beg;
+#pragma unroll 1
+        while (cand != 0) {
+            // ---- stage the feature rows of the next <= FS candidates ----
+            const int rank = __popcll(cand & lt_mask);
+            const int ncand = min(FS, (int)__popcll(cand));
+            __builtin_amdgcn_wave_barrier();
+            if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int e = lane; e < ncand * NC; e += WAVE) {
+                const int row = e / NC, ch = e - row * NC;
+                s_feat[row * NCP + ch] = feat[(size_t)s_cgid[row] * C_total + c0 + ch];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (int slot = 0; slot < ncand; slot += 2) {
+                const bool has1 = slot + 1 < ncand;  // wave-uniform
+                const int j0 = __builtin_ctzll(cand);
                 cand &= cand - 1;
-                const float4 r0 = s_rec0[j];
-                const float4 r1 = s_rec1[j];
-                const float dx = r0.x - fx, dy = r0.y - fy;
-                const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-                const float G = __expf(power);
-                const float alpha = fminf(ALPHA_MAX, r1.w * G);
-                const bool hit = (contributor + (uint32_t)j < last) && power <= 0.0f && alpha >= ALPHA_MIN;
-                if (!__any(hit)) continue;
-                const float* f = &s_feat[j * NCP];
-                const float w = hit ? alpha * T : 0.0f;
-                float q = r0.z * gD;
+                const int j1 = has1 ? __builtin_ctzll(cand) : j0;
+                if (has1) cand &= cand - 1;
+                const int s1 = has1 ? slot + 1 : slot;
+                const float4 p0 = s_rec0[j0], q0 = s_rec1[j0];
+                const float4 p1 = s_rec0[j1], q1 = s_rec1[j1];
+                const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
+                const float pw0 = -0.5f * (q0.x * dx0 * dx0 + q0.z * dy0 * dy0) - q0.y * dx0 * dy0;
+                const float pw1 = -0.5f * (q1.x * dx1 * dx1 + q1.z * dy1 * dy1) - q1.y * dx1 * dy1;
+                const float G0 = __expf(pw0), G1 = __expf(pw1);
+                const float al0 = fminf(ALPHA_MAX, q0.w * G0), al1 = fminf(ALPHA_MAX, q1.w * G1);
+                const bool hit0 = (idx0 + (uint32_t)j0 < last) && pw0 <= 0.0f && al0 >= ALPHA_MIN;
+                const bool hit1 = has1 && (idx0 + (uint32_t)j1 < last) && pw1 <= 0.0f && al1 >= ALPHA_MIN;
+                if (__builtin_amdgcn_ballot_w64(hit0 || hit1) == 0) continue;
+                // ---- dot products q = f . g (+ depth) of both Gaussians ----
+                const float* f0 = &s_feat[slot * NCP];
+                const float* f1 = &s_feat[s1 * NCP];
+                float qd0 = p0.z * gD, qd1 = p1.z * gD;
 #pragma unroll
-                for (int ch = 0; ch < NC; ++ch) q += f[ch] * g[ch];
-                const float one_m = 1.0f - alpha;
-                float dL_dalpha_i = 0.0f;
-                if (hit) {
-                    S -= w * q;
-                    dL_dalpha_i = T * q - S * __frcp_rn(one_m);
-                    T *= one_m;
+                for (int ch = 0; ch < NC; ++ch) {
+                    qd0 += f0[ch] * g[ch];
+                    qd1 += f1[ch] * g[ch];
                 }
-                const float dL_dG = r1.w * dL_dalpha_i;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
-                const float dG_ddely = -gdy * r1.z - gdx * r1.y;
-                float red[KRED];
+                // ---- Gaussian 0, then Gaussian 1 (sequential in T and S) ----
+                const float w0 = hit0 ? al0 * T : 0.0f;
+                float dA0 = 0.0f, dA1 = 0.0f;
+                if (hit0) {
+                    S -= w0 * qd0;
+                    dA0 = T * qd0 - S * __frcp_rn(1.0f - al0);
+                    T *= 1.0f - al0;
+                }
+                const float w1 = hit1 ? al1 * T : 0.0f;
+                if (hit1) {
+                    S -= w1 * qd1;
+                    dA1 = T * qd1 - S * __frcp_rn(1.0f - al1);
+                    T *= 1.0f - al1;
+                }
+                float red[2 * KV];
 #pragma unroll
-                for (int ch = 0; ch < NV; ++ch) red[ch] = w * g[NM + ch];
-                red[NV + 0] = dL_dG * dG_ddelx * halfW;
-                red[NV + 1] = dL_dG * dG_ddely * halfH;
-                red[NV + 2] = -0.5f * gdx * dx * dL_dG;
-                red[NV + 3] = -gdx * dy * dL_dG;
-                red[NV + 4] = -0.5f * gdy * dy * dL_dG;
-                red[NV + 5] = G * dL_dalpha_i;
-                red[NV + 6] = w * gD;
-                const float outv = wave_reduce_pack<KRED>(red, lane);
-                const uint32_t gi = s_id[j];
+                for (int ch = 0; ch < NV; ++ch) {
+                    red[ch] = w0 * g[NM + ch];
+                    red[KV + ch] = w1 * g[NM + ch];
+                }
+                {
+                    const float dG = q0.w * dA0, gdx = G0 * dx0, gdy = G0 * dy0;
+                    red[NV + 0] = dG * (-gdx * q0.x - gdy * q0.y) * halfW;
+                    red[NV + 1] = dG * (-gdy * q0.z - gdx * q0.y) * halfH;
+                    red[NV + 2] = -0.5f * gdx * dx0 * dG;
+                    red[NV + 3] = -gdx * dy0 * dG;
+                    red[NV + 4] = -0.5f * gdy * dy0 * dG;
+                    red[NV + 5] = G0 * dA0;
+                    red[NV + 6] = w0 * gD;
+                }
+                {
+                    const float dG = q1.w * dA1, gdx = G1 * dx1, gdy = G1 * dy1;
+                    red[KV + NV + 0] = dG * (-gdx * q1.x - gdy * q1.y) * halfW;
+                    red[KV + NV + 1] = dG * (-gdy * q1.z - gdx * q1.y) * halfH;
+                    red[KV + NV + 2] = -0.5f * gdx * dx1 * dG;
+                    red[KV + NV + 3] = -gdx * dy1 * dG;
+                    red[KV + NV + 4] = -0.5f * gdy * dy1 * dG;
+                    red[KV + NV + 5] = G1 * dA1;
+                    red[KV + NV + 6] = w1 * gD;
+                }
+                const float outv = wave_reduce_pack<2 * KV>(red, lane);
+                const uint32_t gi0 = s_cgid[slot], gi1 = s_cgid[s1];
+                const uint32_t gi = slot_second ? gi1 : gi0;
                 float* dst = slot_col ? (dcolors + (size_t)gi * C_total + slot_off)
                                       : (ggrad + (size_t)gi * 8 + slot_off);
-                if (slot_ok) atomicAdd(dst, outv);
+                if (slot_ok && (has1 || !slot_second)) atomicAdd(dst, outv);
                 if (MFMA) {
-                    my_w[lane * WS + nslot] = w;  // park the weights (0 for pixels that miss)
-                    if (lane == 0) my_gid[nslot] = gi;
-                    if (++nslot == GROUP) {
-                        flush_panel(GROUP);
+                    // park the weights (0 for pixels that miss); a pair never straddles a flush
+                    s_w[lane * WS + nslot] = w0;
+                    s_w[lane * WS + nslot + 1] = w1;
+                    if (lane == 0) {
+                        s_gid[nslot] = gi0;
+                        s_gid[nslot + 1] = gi1;
+                    }
+                    nslot += has1 ? 2 : 1;
+                    if (nslot >= GROUP - 1) {
+                        flush_panel(nslot);
                         nslot = 0;
                     }
                 }
             }
         }
-        contributor += (uint32_t)nb;
     }
     if (MFMA && nslot > 0) flush_panel(nslot);
 }
@@ -365,11 +403,14 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
                           const float* dL_ddepth, const float* dL_dalpha, float* ggrad, float* dcolors,
                           hipStream_t stream)
 {
+    (void)g;
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
-    hipLaunchKernelGGL(composite_bwd_kernel<NC>, dim3(gx, gy), dim3(CB_THREADS), 0, stream, s.image_width,
-                       s.image_height, feat_stride, c0, first, b.ranges, b.point_list, g.rec0, g.rec1, feat,
-                       out_color, out_depth, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, ggrad,
-                       dcolors);
+    const int tiles = gx * gy;
+    const unsigned blocks = (unsigned)((tiles + 7) / 8) * 32u;  // 4 quadrants per tile, tiles padded to 8
+    hipLaunchKernelGGL(composite_bwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
+                       s.image_height, feat_stride, c0, first, tiles, b.ranges, b.point_list, b.irec0, b.irec1,
+                       b.imask, feat, out_color, out_depth, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth,
+                       dL_dalpha, ggrad, dcolors);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

@@ -2,24 +2,33 @@
 //
 // Replaces the render stage of the rasterizer extension behind
 // diff_gauss.GaussianRasterizer.forward (gaussian_renderer/__init__.py:117-126; algorithm
-// per SURVEY.md §8a "COMPOSITE fwd").  One 256-thread workgroup (4 wave64) per 16x16
-// tile; wave w owns the 8x8 pixel quadrant (w&1, w>>1) so that a Gaussian that misses a
-// quadrant is skipped by the whole wave with one ballot.  The tile's list is consumed in
-// batches staged in LDS: 32-byte projected records + the feature rows (4*C bytes each),
-// fetched with coalesced global loads and read back as wave-uniform (broadcast) LDS reads.
-// VALU-bound.
+// per SURVEY.md §8a "COMPOSITE fwd").
+//
+// Machine mapping: ONE wave64 = one workgroup = one 8x8 pixel quadrant of a
+// 16x16 tile.  The four quadrants of a tile have very different amounts of work; as waves of
+// one 256-thread workgroup they met at three barriers per batch and spent > 50 % of their
+// cycles waiting.  Here every quadrant walks the tile's list on its own, wave-synchronously,
+// with no __syncthreads anywhere:
+//   * the list is streamed 64 entries at a time from the per-instance payload written by
+//     payload_kernel (binning.hip): reach-mask byte + 32-byte record, contiguous in sorted
+//     order -> independent coalesced loads per lane, issued one chunk ahead;
+//   * only entries whose mask says they may reach THIS quadrant become candidates; their
+//     feature rows (4*C bytes) are gathered into LDS, at most FS rows per round;
+//   * candidates are composited two at a time (twice the ILP of the alpha evaluation, and
+//     exactly the K = 2 of the matrix instruction below).
 //
 // NC >= 32: the accumulation of the first 32 channels, out[pix][ch] += w[pix][g] * F[g][ch],
-// is a [32 ch x 2 g] x [2 g x 32 pix] product per pair of contributing Gaussians and runs on
-// the matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fmaf chain = the sequential
-// front-to-back sum).  A operand: one conflict-free ds_read_b32 of the two staged feature
-// rows; B operand: the two weight registers of the pair after ONE v_permlane32_swap
-// (lanes 0-31 <- pixels 0-31 / 32-63 of Gaussian 0, lanes 32-63 <- of Gaussian 1).
+// is a [32 ch x 2 g] x [2 g x 32 pix] product per candidate pair and runs on the matrix pipe
+// (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fmaf chain = the sequential front-to-back
+// sum).  A operand: one conflict-free ds_read_b32 of the two staged feature rows; B operand:
+// the two weight registers of the pair after ONE v_permlane32_swap.
 #include "composite_common.h"
 
-namespace sr {
+#ifndef SR_FWD_MINW
+#define SR_FWD_MINW 4  // waves per SIMD the register allocator must allow
+#endif
 
-constexpr int CF_THREADS = 256;
+namespace sr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -37,150 +46,157 @@ __device__ __forceinline__ void swap_halves(float& x, float& y)
 template <int NC>
 struct FwdCfg {
     static constexpr bool MFMA = NC >= 32;
-    static constexpr int NM = MFMA ? 32 : 0;            // channels accumulated on the matrix pipe
-    static constexpr int NV = NC - NM;                  // channels accumulated with VALU FMAs
-    static constexpr int NCP = (NC + 3) & ~3;           // LDS row stride (floats), 16-B aligned rows
-    static constexpr int BATCH = (NC > 16) ? 128 : 256; // Gaussians staged per round
+    static constexpr int NM = MFMA ? 32 : 0;   // channels accumulated on the matrix pipe
+    static constexpr int NV = NC - NM;         // channels accumulated with VALU FMAs
+    static constexpr int NCP = (NC + 3) & ~3;  // LDS row stride (floats), 16-B aligned rows
+    static constexpr int FS = 32;              // feature rows staged per round
 };
 
 template <int NC>
-__global__ void __launch_bounds__(CF_THREADS)
-composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int write_aux,
+__global__ void __launch_bounds__(WAVE, SR_FWD_MINW)
+composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int write_aux, int tiles,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                     const float4* __restrict__ rec0, const float4* __restrict__ rec1,
-                     const float* __restrict__ feat, const float* __restrict__ bg,
-                     float* __restrict__ out_color, float* __restrict__ out_depth,
-                     float* __restrict__ out_alpha, float* __restrict__ final_T,
-                     uint32_t* __restrict__ n_contrib)
+                     const float4* __restrict__ irec0, const float4* __restrict__ irec1,
+                     const uint8_t* __restrict__ imask, const float* __restrict__ feat,
+                     const float* __restrict__ bg, float* __restrict__ out_color,
+                     float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
 {
-    constexpr int NCP = FwdCfg<NC>::NCP;
-    constexpr int BATCH = FwdCfg<NC>::BATCH;
-    constexpr bool MFMA = FwdCfg<NC>::MFMA;
-    constexpr int NM = FwdCfg<NC>::NM, NV = FwdCfg<NC>::NV;
-    __shared__ __attribute__((aligned(16))) float4 s_rec0[BATCH];
-    __shared__ __attribute__((aligned(16))) float4 s_rec1[BATCH];
-    __shared__ __attribute__((aligned(16))) float s_feat[BATCH * NCP];
-    __shared__ uint32_t s_id[BATCH];
-    __shared__ uint64_t s_cand[4][BATCH / WAVE];  // per quadrant: candidate bitmask of the batch
-    __shared__ uint8_t s_any[BATCH];              // row reaches at least one quadrant
+    using Cfg = FwdCfg<NC>;
+    constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, FS = Cfg::FS;
+    constexpr bool MFMA = Cfg::MFMA;
+    __shared__ __attribute__((aligned(16))) float4 s_rec0[WAVE];
+    __shared__ __attribute__((aligned(16))) float4 s_rec1[WAVE];
+    __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
+    __shared__ uint32_t s_cgid[FS];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    int tile, quad;
+    quadrant_of_block(blockIdx.x, tile, quad);
+    if (tile >= tiles) return;
+    const int lane = threadIdx.x;
     const int gx = (W + TILE - 1) / TILE;
-    const int tile = blockIdx.y * gx + blockIdx.x;
-    const int px = blockIdx.x * TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int qx = (tile % gx) * TILE + (quad & 1) * 8, qy = (tile / gx) * TILE + (quad >> 1) * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
-
     const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
-    int todo = (int)(end - beg);
 
-    bool done = !inside;
+    bool active = inside;  // pixel still accumulating
     float T = 1.0f, D = 0.0f;
-    float acc[NV > 0 ? NV : 1];  // VALU-accumulated channels (all of them when NC < 32)
+    float acc[NV > 0 ? NV : 1];
 #pragma unroll
     for (int ch = 0; ch < NV; ++ch) acc[ch] = 0.0f;
     // matrix-pipe accumulators D[ch][pix]: accA = pixels (lanes) 0-31 of the wave, accB = 32-63
     f32x16 accA, accB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accA[r] = 0.0f; accB[r] = 0.0f; }
-    float w_pend = 0.0f;  // weights of a contributing Gaussian waiting for its pair partner
-    int j_pend = -1;      // its row in the staged batch (wave-uniform), -1 = none
-    auto mfma_pair = [&](int j0, float w0, int j1, float w1) {
-        const float a = s_feat[((lane >> 5) ? j1 : j0) * NCP + (lane & 31)];  // A[i = ch][k = g]
-        swap_halves(w0, w1);  // w0 -> B for pixels 0-31, w1 -> B for pixels 32-63
-        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, accB, 0, 0, 0);
-    };
-    uint32_t contributor = 0, last = 0;
+    uint32_t last = 0;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
 
-    for (uint32_t base = beg; todo > 0; base += BATCH, todo -= BATCH) {
-        if (__syncthreads_count(done) == CF_THREADS) break;
-        const int nb = todo < BATCH ? todo : BATCH;
-        // ---- stage ids + records ----
-        unsigned m4 = 0u;
-        if (tid < nb) {
-            const uint32_t g = point_list[base + tid];
-            const float4 a0 = rec0[g], a1 = rec1[g];
-            s_id[tid] = g;
-            s_rec0[tid] = a0;
-            s_rec1[tid] = a1;
-            m4 = quadrant_reach_mask(a0, a1, (float)(blockIdx.x * TILE), (float)(blockIdx.y * TILE));
-            s_any[tid] = (uint8_t)m4;
+    // chunk in flight: mask bit, id and record of list entry base + lane
+    bool reach = false;
+    uint32_t gid = 0;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    auto fetch = [&](uint32_t base, bool& r_, uint32_t& g_, float4& x0, float4& x1) {
+        r_ = false;
+        if (base + (uint32_t)lane < end) {
+            const uint32_t j = base + (uint32_t)lane;
+            r_ = (imask[j] >> quad) & 1u;
+            g_ = point_list[j];
+            x0 = irec0[j];
+            x1 = irec1[j];
         }
-        if (wave < BATCH / WAVE) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint64_t bal = __ballot((m4 >> q) & 1u);
-                if (lane == 0) s_cand[q][wave] = bal;
-            }
-        }
-        __syncthreads();
-        // ---- stage feature rows: consecutive threads walk consecutive floats of a row ----
-        for (int e = tid; e < nb * NC; e += CF_THREADS) {
-            const int row = e / NC, ch = e - row * NC;
-            if (s_any[row]) s_feat[row * NCP + ch] = feat[(size_t)s_id[row] * C_total + c0 + ch];
-        }
-        __syncthreads();
-        bool wave_done = __all(done);
+    };
+    fetch(beg, reach, gid, a0, a1);
+
+    bool wave_done = __builtin_amdgcn_ballot_w64(active) == 0;
 #pragma unroll 1
-        for (int k = 0; k < BATCH / WAVE && !wave_done; ++k) {
-            uint64_t cand = uniform_u64(s_cand[wave][k]);
-            while (cand) {
-                const int j = k * WAVE + __builtin_ctzll(cand);
+    for (uint32_t base = beg; base < end && !wave_done; base += WAVE) {
+        uint64_t cand = __builtin_amdgcn_ballot_w64(reach);
+        const uint32_t cur_gid = gid;
+        const bool cur_reach = reach;
+        if (cand != 0) {
+            __builtin_amdgcn_wave_barrier();
+            s_rec0[lane] = a0;
+            s_rec1[lane] = a1;
+        }
+        // next chunk: issued now, consumed after this chunk has been composited
+        fetch(base + WAVE, reach, gid, a0, a1);
+#pragma unroll 1
+        while (cand != 0 && !wave_done) {
+            // ---- stage the feature rows of the next <= FS candidates ----
+            const int rank = __popcll(cand & lt_mask);
+            const int ncand = min(FS, (int)__popcll(cand));
+            __builtin_amdgcn_wave_barrier();
+            if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int e = lane; e < ncand * NC; e += WAVE) {
+                const int row = e / NC, ch = e - row * NC;
+                s_feat[row * NCP + ch] = feat[(size_t)s_cgid[row] * C_total + c0 + ch];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- composite them front to back, two at a time ----
+#pragma unroll 1
+            for (int slot = 0; slot < ncand; slot += 2) {
+                const bool has1 = slot + 1 < ncand;  // wave-uniform
+                const int j0 = __builtin_ctzll(cand);
                 cand &= cand - 1;
-                const float4 r0 = s_rec0[j];
-                const float4 r1 = s_rec1[j];
-                const float dx = r0.x - fx, dy = r0.y - fy;
-                const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-                const float alpha = fminf(ALPHA_MAX, r1.w * __expf(power));
-                const float test_T = T * (1.0f - alpha);
-                const bool live = !done && power <= 0.0f && alpha >= ALPHA_MIN;
-                const bool hit = live && test_T >= T_EPS;
-                if (live && !hit) done = true;  // transmittance exhausted: pixel finished
-                if (__any(live && !hit) && __all(done)) { wave_done = true; break; }
-                if (__any(hit)) {
-                    const float w = hit ? alpha * T : 0.0f;
-                    const float* f = &s_feat[j * NCP + NM];
+                const int j1 = has1 ? __builtin_ctzll(cand) : j0;
+                if (has1) cand &= cand - 1;
+                const float4 p0 = s_rec0[j0], q0 = s_rec1[j0];
+                const float4 p1 = s_rec0[j1], q1 = s_rec1[j1];
+                const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
+                const float pw0 = -0.5f * (q0.x * dx0 * dx0 + q0.z * dy0 * dy0) - q0.y * dx0 * dy0;
+                const float pw1 = -0.5f * (q1.x * dx1 * dx1 + q1.z * dy1 * dy1) - q1.y * dx1 * dy1;
+                const float al0 = fminf(ALPHA_MAX, q0.w * __expf(pw0));
+                const float al1 = fminf(ALPHA_MAX, q1.w * __expf(pw1));
+                // Gaussian 0
+                const bool live0 = active && pw0 <= 0.0f && al0 >= ALPHA_MIN;
+                const float tT0 = T * (1.0f - al0);
+                const bool hit0 = live0 && tT0 >= T_EPS;
+                const bool act1 = active && !(live0 && !hit0);  // transmittance exhausted: pixel finished
+                const float w0 = hit0 ? al0 * T : 0.0f;
+                const float T1 = hit0 ? tT0 : T;
+                // Gaussian 1 (absent when !has1)
+                const bool live1 = has1 && act1 && pw1 <= 0.0f && al1 >= ALPHA_MIN;
+                const float tT1 = T1 * (1.0f - al1);
+                const bool hit1 = live1 && tT1 >= T_EPS;
+                active = act1 && !(live1 && !hit1);
+                const float w1 = hit1 ? al1 * T1 : 0.0f;
+                T = hit1 ? tT1 : T1;
+                const uint32_t idx = base - beg;
+                last = hit1 ? idx + (uint32_t)j1 + 1u : (hit0 ? idx + (uint32_t)j0 + 1u : last);
+                if (__builtin_amdgcn_ballot_w64(hit0 || hit1) == 0) {
+                    if (__builtin_amdgcn_ballot_w64(active) == 0) { wave_done = true; break; }
+                    continue;
+                }
+                const int s1 = has1 ? slot + 1 : slot;
+                const float* f0 = &s_feat[slot * NCP + NM];
+                const float* f1 = &s_feat[s1 * NCP + NM];
 #pragma unroll
-                    for (int ch = 0; ch < NV; ++ch) acc[ch] += f[ch] * w;
-                    D += r0.z * w;
-                    if (MFMA) {
-                        if (j_pend < 0) {
-                            w_pend = w;
-                            j_pend = j;
-                        } else {
-                            mfma_pair(j_pend, w_pend, j, w);
-                            j_pend = -1;
-                        }
-                    }
-                    if (hit) {
-                        T = test_T;
-                        last = contributor + (uint32_t)j + 1u;
-                    }
+                for (int ch = 0; ch < NV; ++ch) acc[ch] += f0[ch] * w0 + f1[ch] * w1;
+                D += p0.z * w0 + p1.z * w1;
+                if (MFMA) {
+                    const float a = s_feat[((lane >> 5) ? s1 : slot) * NCP + (lane & 31)];  // A[i = ch][k = g]
+                    float b0 = w0, b1 = w1;
+                    swap_halves(b0, b1);  // b0 -> B for pixels 0-31, b1 -> B for pixels 32-63
+                    accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, accB, 0, 0, 0);
                 }
             }
         }
-        // the staged rows are about to be overwritten: retire an unpaired Gaussian (partner weight 0)
-        if (MFMA && j_pend >= 0) {
-            mfma_pair(j_pend, w_pend, j_pend, 0.0f);
-            j_pend = -1;
-        }
-        contributor += (uint32_t)nb;
     }
 
+    const size_t plane = (size_t)H * W;
     if (MFMA) {
         // D[ch][pix]: lane l, register r holds channel (r&3) + 8 (r>>2) + 4 (l>>5) of wave pixel
         // (l & 31) [accA] / 32 + (l & 31) [accB]; T of those pixels comes from lanes (l&31), 32+(l&31).
         float TA = T, TB = T;
         swap_halves(TA, TB);
-        const int qx = blockIdx.x * TILE + (wave & 1) * 8, qy = blockIdx.y * TILE + (wave >> 1) * 8;
         const int pa = lane & 31, pb = 32 + (lane & 31);
         const int xa = qx + (pa & 7), ya = qy + (pa >> 3), xb = qx + (pb & 7), yb = qy + (pb >> 3);
         const bool ina = xa < W && ya < H, inb = xb < W && yb < H;
-        const size_t plane = (size_t)H * W;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -191,7 +207,6 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px;
-        const size_t plane = (size_t)H * W;
 #pragma unroll
         for (int ch = 0; ch < NV; ++ch) {
             const int c = c0 + NM + ch;
@@ -212,10 +227,14 @@ static int launch_one(const splatraster_settings& s, int c0, int write_aux, cons
                       const float* bg, float* out_color, float* out_depth, float* out_alpha,
                       hipStream_t stream)
 {
+    (void)g;
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
-    hipLaunchKernelGGL(composite_fwd_kernel<NC>, dim3(gx, gy), dim3(CF_THREADS), 0, stream, s.image_width,
-                       s.image_height, feat_stride, c0, s.bg_channels, write_aux, b.ranges, b.point_list,
-                       g.rec0, g.rec1, feat, bg, out_color, out_depth, out_alpha, im.final_T, im.n_contrib);
+    const int tiles = gx * gy;
+    const unsigned blocks = (unsigned)((tiles + 7) / 8) * 32u;  // 4 quadrants per tile, tiles padded to 8
+    hipLaunchKernelGGL(composite_fwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
+                       s.image_height, feat_stride, c0, s.bg_channels, write_aux, tiles, b.ranges, b.point_list,
+                       b.irec0, b.irec1, b.imask, feat, bg, out_color, out_depth, out_alpha, im.final_T,
+                       im.n_contrib);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

@@ -51,3 +51,46 @@ for q in (8, 4):
     print(f" {q}x{q} sub-tile steps: processed {a / len(tiles):.0f}/tile, with >=1 hit {h / len(tiles):.0f}/tile ({100 * h / max(a, 1):.1f}%)")
 print(f" pixel hits per tile {hits / len(tiles):.0f}; hits per processed instance {hits / max(tot_proc, 1):.1f} of 256"
       f"; lanes active in hit 8x8 steps {hits / max(steps[8][1], 1):.1f} of 64")
+
+# ---- reach-mask candidates (same test as composite_common.h::quadrant_reach_mask) ----
+def reach_mask(xy, con, tx0, ty0):
+    A, B, C, o = con[:, 0], con[:, 1], con[:, 2], con[:, 3]
+    with np.errstate(all="ignore"):
+        lim0 = 2 * np.log(255 * o)
+        lim = lim0 + 0.02 + 1e-4 * np.abs(lim0)
+        nBrA, nBrC = -B / A, -B / C
+        out = np.zeros((len(A), 4), bool)
+        for q in range(4):
+            bx0, by0 = tx0 + (q & 1) * 8, ty0 + (q >> 1) * 8
+            u0, u1 = xy[:, 0] - (bx0 + 7), xy[:, 0] - bx0
+            v0, v1 = xy[:, 1] - (by0 + 7), xy[:, 1] - by0
+            inside = (u0 <= 0) & (u1 >= 0) & (v0 <= 0) & (v1 >= 0)
+            qmin = np.full(len(A), 3e38)
+            for ue in (u0, u1):
+                vs = np.minimum(v1, np.maximum(v0, nBrC * ue))
+                qmin = np.minimum(qmin, A * ue * ue + 2 * B * ue * vs + C * vs * vs)
+            for ve in (v0, v1):
+                us = np.minimum(u1, np.maximum(u0, nBrA * ve))
+                qmin = np.minimum(qmin, A * us * us + 2 * B * us * ve + C * ve * ve)
+            qmin = np.where(inside, 0, qmin)
+            out[:, q] = (qmin <= lim) & (lim > 0)
+    return out
+
+cand_all = cand_proc = anyq = fwd_steps = 0
+for t in tiles:
+    s, e = f["ranges"][t]
+    ty, tx = divmod(t, gx)
+    g = f["point_list"][s:e]
+    m = reach_mask(f["xy"][g], f["conic_opacity"][g], tx * 16, ty * 16)
+    cand_all += m.sum()
+    anyq += m.any(1).sum()
+    ys, xs = np.mgrid[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16]
+    inside = (ys < H) & (xs < W)
+    nc = np.where(inside, f["n_contrib"][np.minimum(ys, H - 1), np.minimum(xs, W - 1)], 0)
+    fT = np.where(inside, f["final_T"][np.minimum(ys, H - 1), np.minimum(xs, W - 1)], 0)
+    for q in range(4):
+        qs = (slice((q >> 1) * 8, (q >> 1) * 8 + 8), slice((q & 1) * 8, (q & 1) * 8 + 8))
+        wl = nc[qs].max()
+        cand_proc += m[:wl, q].sum()
+print(f" reach-mask candidates per tile: all list {cand_all / len(tiles):.0f} quadrant-steps ({anyq / len(tiles):.0f} Gaussians reach >=1 quadrant of {tot_len / len(tiles):.0f});"
+      f" within the backward prefix {cand_proc / len(tiles):.0f}  (hit steps {steps[8][1] / len(tiles):.0f})")
