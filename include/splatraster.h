@@ -155,8 +155,8 @@ int splatraster_mark_visible(int32_t P, const float* means3D, const float* viewm
 
 /* Debug / test introspection: byte offsets of the arrays inside the opaque buffers. */
 typedef struct splatraster_geometry_layout {
-    size_t rec0;          /* float4[P]: pixel x, pixel y, view depth, radius (float, 0 = culled) */
-    size_t rec1;          /* float4[P]: conic a, b, c, opacity */
+    size_t rec0;          /* 32-byte records, stride 32: float4 at rec0 + 32 i = pixel x, pixel y, view depth, radius (float, 0 = culled) */
+    size_t rec1;          /* = rec0 + 16: float4 at rec1 + 32 i = conic a, b, c, opacity */
     size_t tiles_touched; /* uint32[P] (original index order) */
     size_t depth_order;   /* uint32[P]: Gaussian indices, stable-sorted by depth bits (culled last) */
     size_t offsets;       /* uint32[P]: inclusive scan of tiles_touched in depth_order */

@@ -19,13 +19,13 @@ __device__ __forceinline__ int f2i_sat_b(float v)
 }
 
 __global__ void __launch_bounds__(256)
-depth_keys_kernel(int P, const float4* __restrict__ rec0, uint32_t* __restrict__ keys,
+depth_keys_kernel(int P, const float4* __restrict__ rec, uint32_t* __restrict__ keys,
                   uint32_t* __restrict__ vals)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     // view depth > 0.2 for every visible Gaussian, so its IEEE bits order like the value
-    const float4 r = rec0[i];
+    const float4 r = rec[2 * i];
     keys[i] = r.w > 0.f ? __float_as_uint(r.z) : 0xFFFFFFFFu;
     vals[i] = (uint32_t)i;
 }
@@ -33,7 +33,7 @@ depth_keys_kernel(int P, const float4* __restrict__ rec0, uint32_t* __restrict__
 int launch_depth_keys(int32_t P, const GeomView& g, hipStream_t stream)
 {
     if (P == 0) return SPLATRASTER_OK;
-    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.rec0, g.sort_keys,
+    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.rec, g.sort_keys,
                        g.depth_order);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
@@ -43,7 +43,7 @@ int launch_depth_keys(int32_t P, const GeomView& g, hipStream_t stream)
 // of tiles_touched in depth order), k = j - offsets[r-1] is the tile slot inside the rect.
 __global__ void __launch_bounds__(256)
 emit_kernel(int64_t R, int P, int W, int H, const uint32_t* __restrict__ offsets,
-            const uint32_t* __restrict__ depth_order, const float4* __restrict__ rec0,
+            const uint32_t* __restrict__ depth_order, const float4* __restrict__ rec,
             uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,7 +58,7 @@ emit_kernel(int64_t R, int P, int W, int H, const uint32_t* __restrict__ offsets
     const uint32_t prev = r > 0 ? offsets[r - 1] : 0u;
     const uint32_t k = ju - prev;
     const uint32_t g = depth_order[r];
-    const float4 p = rec0[g];
+    const float4 p = rec[2 * g];
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const float rf = p.w;  // integer-valued radius stored by preprocess
     const int rminx = min(gx, max(0, f2i_sat_b((p.x - rf) / (float)TILE)));
@@ -76,7 +76,7 @@ int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomV
     if (R == 0) return SPLATRASTER_OK;
     const int64_t blocks = (R + 255) / 256;
     hipLaunchKernelGGL(emit_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, R, P, s.image_width,
-                       s.image_height, g.offsets, g.depth_order, g.rec0, keys, vals);
+                       s.image_height, g.offsets, g.depth_order, g.rec, keys, vals);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
@@ -104,20 +104,19 @@ int launch_ranges(int64_t R, int32_t tiles, const uint32_t* tile_list, uint32_t*
 // Per-instance payload, written once per frame in sorted order so that every later reader
 // (forward and backward compositing, four quadrant-waves per tile) streams it with coalesced
 // loads instead of chasing id -> record through 16-byte gathers scattered over HBM:
-//   irec0/irec1[j] = the projected record of point_list[j];  imask[j] = quadrant reach bits.
+//   irec[2j], irec[2j+1] = the 32-byte projected record of point_list[j];  imask[j] = reach bits.
 __global__ void __launch_bounds__(256)
 payload_kernel(int64_t R, int gx, const uint32_t* __restrict__ point_list,
-               const uint32_t* __restrict__ tile_list, const float4* __restrict__ rec0,
-               const float4* __restrict__ rec1, float4* __restrict__ irec0, float4* __restrict__ irec1,
-               uint8_t* __restrict__ imask)
+               const uint32_t* __restrict__ tile_list, const float4* __restrict__ rec,
+               float4* __restrict__ irec, uint8_t* __restrict__ imask)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= R) return;
     const uint32_t g = point_list[j], t = tile_list[j];
-    const float4 a0 = rec0[g], a1 = rec1[g];
+    const float4 a0 = rec[2 * (size_t)g], a1 = rec[2 * (size_t)g + 1];  // one 32-byte gather
     const uint32_t ty = t / (uint32_t)gx, tx = t - ty * (uint32_t)gx;
-    irec0[j] = a0;
-    irec1[j] = a1;
+    irec[2 * j] = a0;
+    irec[2 * j + 1] = a1;
     imask[j] = (uint8_t)quadrant_reach_mask(a0, a1, (float)(tx * TILE), (float)(ty * TILE));
 }
 
@@ -126,7 +125,7 @@ int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, 
     if (R == 0) return SPLATRASTER_OK;
     const int gx = (s.image_width + TILE - 1) / TILE;
     hipLaunchKernelGGL(payload_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, b.point_list,
-                       b.tile_list, g.rec0, g.rec1, b.irec0, b.irec1, b.imask);
+                       b.tile_list, g.rec, b.irec, b.imask);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

@@ -70,8 +70,8 @@ static GeomLayout geom_layout(int32_t P)
     GeomLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
-    L.rec0 = take(16 * n);
-    L.rec1 = take(16 * n);
+    L.rec0 = take(32 * n);
+    L.rec1 = L.rec0 + 16;
     L.tiles_touched = take(4 * n);
     L.depth_order = take(4 * n);
     L.offsets = take(4 * n);
@@ -94,8 +94,7 @@ GeomView geom_view(void* base, int32_t P)
     const GeomLayout L = geom_layout(P);
     char* b = reinterpret_cast<char*>(base);
     GeomView g;
-    g.rec0 = reinterpret_cast<float4*>(b + L.rec0);
-    g.rec1 = reinterpret_cast<float4*>(b + L.rec1);
+    g.rec = reinterpret_cast<float4*>(b + L.rec0);
     g.tiles_touched = reinterpret_cast<uint32_t*>(b + L.tiles_touched);
     g.depth_order = reinterpret_cast<uint32_t*>(b + L.depth_order);
     g.offsets = reinterpret_cast<uint32_t*>(b + L.offsets);
@@ -110,7 +109,7 @@ GeomView geom_view(void* base, int32_t P)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec0, irec1, imask, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, bytes;
 };
 static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
 {
@@ -125,8 +124,7 @@ static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
     L.valsB = take(4 * n);
     L.ranges = take(8 * (tiles > 0 ? tiles : 1));
     L.sort_tmp = take(sort_tmp_bytes((int64_t)n));
-    L.irec0 = take(16 * n);
-    L.irec1 = take(16 * n);
+    L.irec = take(32 * n);
     L.imask = take(n);
     L.bytes = o;
     return L;
@@ -144,8 +142,7 @@ BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H)
     v.vals_tmp = reinterpret_cast<uint32_t*>(b + L.valsB);
     v.ranges = reinterpret_cast<uint32_t*>(b + L.ranges);
     v.sort_tmp = b + L.sort_tmp;
-    v.irec0 = reinterpret_cast<float4*>(b + L.irec0);
-    v.irec1 = reinterpret_cast<float4*>(b + L.irec1);
+    v.irec = reinterpret_cast<float4*>(b + L.irec);
     v.imask = reinterpret_cast<uint8_t*>(b + L.imask);
     return v;
 }

@@ -42,8 +42,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // ---- opaque buffer views -------------------------------------------------------------
 struct GeomView {
-    float4* rec0;            // px, py, depth, radius (as float; 0 = culled)
-    float4* rec1;            // conic a, b, c, opacity
+    float4* rec;             // [2P] 32-byte records: rec[2i] = px, py, depth, radius (float; 0 = culled),
+                             //                       rec[2i+1] = conic a, b, c, opacity
     uint32_t* tiles_touched; // [P] original order
     uint32_t* depth_order;   // [P] gaussian ids sorted by depth
     uint32_t* offsets;       // [P] inclusive scan of tiles_touched in depth order
@@ -62,8 +62,7 @@ struct BinView {
     uint32_t* keys_tmp;   // [R] unsorted tile ids
     uint32_t* vals_tmp;   // [R] unsorted gaussian ids
     void* sort_tmp;       // radix sort scratch
-    float4* irec0;        // [R] per-instance copy of rec0 (sorted order): px, py, depth, radius
-    float4* irec1;        // [R] per-instance copy of rec1: conic a, b, c, opacity
+    float4* irec;         // [2R] per-instance copy of the 32-byte record, in sorted order
     uint8_t* imask;       // [R] bit q: the Gaussian may reach quadrant q of its tile
 };
 struct ImgView {

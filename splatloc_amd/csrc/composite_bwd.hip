@@ -147,7 +147,7 @@ template <int NC>
 __global__ void __launch_bounds__(WAVE, SR_BWD_MINW)
 composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass, int tiles,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                     const float4* __restrict__ irec0, const float4* __restrict__ irec1,
+                     const float4* __restrict__ irec,
                      const uint8_t* __restrict__ imask, const float* __restrict__ feat,
                      const float* __restrict__ out_color, const float* __restrict__ out_depth,
                      const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -271,8 +271,8 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass, int tile
             const uint32_t j = base + (uint32_t)lane;
             r_ = (imask[j] >> quad) & 1u;
             g_ = point_list[j];
-            x0 = irec0[j];
-            x1 = irec1[j];
+            x0 = irec[2 * (size_t)j];
+            x1 = irec[2 * (size_t)j + 1];
         }
     };
     fetch(beg, reach, gid, a0, a1);
@@ -408,7 +408,7 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
     const int tiles = gx * gy;
     const unsigned blocks = (unsigned)((tiles + 7) / 8) * 32u;  // 4 quadrants per tile, tiles padded to 8
     hipLaunchKernelGGL(composite_bwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
-                       s.image_height, feat_stride, c0, first, tiles, b.ranges, b.point_list, b.irec0, b.irec1,
+                       s.image_height, feat_stride, c0, first, tiles, b.ranges, b.point_list, b.irec,
                        b.imask, feat, out_color, out_depth, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth,
                        dL_dalpha, ggrad, dcolors);
     SR_LAUNCH_CHECK();

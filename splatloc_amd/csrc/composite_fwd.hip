@@ -56,7 +56,7 @@ template <int NC>
 __global__ void __launch_bounds__(WAVE, SR_FWD_MINW)
 composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int write_aux, int tiles,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                     const float4* __restrict__ irec0, const float4* __restrict__ irec1,
+                     const float4* __restrict__ irec,
                      const uint8_t* __restrict__ imask, const float* __restrict__ feat,
                      const float* __restrict__ bg, float* __restrict__ out_color,
                      float* __restrict__ out_depth, float* __restrict__ out_alpha,
@@ -103,8 +103,8 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
             const uint32_t j = base + (uint32_t)lane;
             r_ = (imask[j] >> quad) & 1u;
             g_ = point_list[j];
-            x0 = irec0[j];
-            x1 = irec1[j];
+            x0 = irec[2 * (size_t)j];
+            x1 = irec[2 * (size_t)j + 1];
         }
     };
     fetch(beg, reach, gid, a0, a1);
@@ -233,7 +233,7 @@ static int launch_one(const splatraster_settings& s, int c0, int write_aux, cons
     const unsigned blocks = (unsigned)((tiles + 7) / 8) * 32u;  // 4 quadrants per tile, tiles padded to 8
     hipLaunchKernelGGL(composite_fwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
                        s.image_height, feat_stride, c0, s.bg_channels, write_aux, tiles, b.ranges, b.point_list,
-                       b.irec0, b.irec1, b.imask, feat, bg, out_color, out_depth, out_alpha, im.final_T,
+                       b.irec, b.imask, feat, bg, out_color, out_depth, out_alpha, im.final_T,
                        im.n_contrib);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;

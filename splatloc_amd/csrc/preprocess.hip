@@ -93,7 +93,7 @@ preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale
                   const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
                   const float* __restrict__ view, const float* __restrict__ proj,
                   const float* __restrict__ campos_p,
-                  float4* __restrict__ rec0, float4* __restrict__ rec1, uint32_t* __restrict__ tiles_touched,
+                  float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
                   float* __restrict__ rgb, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,8 +183,8 @@ preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale
     }
     radii[i] = out_radius;
     tiles_touched[i] = out_tiles;
-    rec0[i] = r0;
-    rec1[i] = r1;
+    rec[2 * i] = r0;
+    rec[2 * i + 1] = r1;
 }
 
 int launch_preprocess(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
@@ -196,8 +196,7 @@ int launch_preprocess(const splatraster_settings& s, int32_t P, const float* mea
     const int blocks = (P + 255) / 256;
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, stream, P, s.image_width,
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs,
-                       means3D, shs, opacities, scales, rotations, cov3D_precomp, view, proj, campos, g.rec0,
-                       g.rec1,
+                       means3D, shs, opacities, scales, rotations, cov3D_precomp, view, proj, campos, g.rec,
                        g.tiles_touched, g.rgb, g.clamped, radii);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;

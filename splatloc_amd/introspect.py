@@ -23,8 +23,8 @@ def geometry_views(geom: torch.Tensor, P: int) -> dict:
     L = _native.GeometryLayout()
     _native.check(lib.splatraster_get_geometry_layout(P, C.byref(L)), "geometry_layout")
     return dict(
-        rec0=_view(geom, L.rec0, 4 * P, torch.float32).view(P, 4),
-        rec1=_view(geom, L.rec1, 4 * P, torch.float32).view(P, 4),
+        rec0=_view(geom, L.rec0, 8 * P, torch.float32).view(P, 8)[:, :4],
+        rec1=_view(geom, L.rec0, 8 * P, torch.float32).view(P, 8)[:, 4:],
         tiles_touched=_view(geom, L.tiles_touched, P, torch.int32),
         depth_order=_view(geom, L.depth_order, P, torch.int32),
         offsets=_view(geom, L.offsets, P, torch.int32),

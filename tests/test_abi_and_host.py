@@ -40,8 +40,9 @@ def test_host_only_entry_points():
     assert lib.splatraster_image_bytes(1920, 1080) >= 8 * 1920 * 1080
     L = _native.GeometryLayout()
     assert lib.splatraster_get_geometry_layout(1000, C.byref(L)) == 0
-    offs = [L.rec0, L.rec1, L.tiles_touched, L.depth_order, L.offsets, L.rgb, L.clamped]
+    offs = [L.rec0, L.tiles_touched, L.depth_order, L.offsets, L.rgb, L.clamped]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and L.total == g1
+    assert L.rec1 == L.rec0 + 16          # interleaved 32-byte records
     B = _native.BinningLayout()
     assert lib.splatraster_get_binning_layout(1000, 5000, 640, 480, C.byref(B)) == 0
     assert B.total == lib.splatraster_binning_bytes(1000, 5000, 640, 480)
