@@ -373,7 +373,7 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     if (st) return st;
     StageTimer t(SPLATRASTER_STAGE_PREPROCESS_BWD, stream);
     return launch_preprocess_bwd(*s, P, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
-                                 campos, radii, g.clamped, g.ggrad, g.drgb, dL_dmeans3D, dL_dmeans2D,
+                                 campos, radii, g.clamped, g.rec, g.ggrad, g.drgb, dL_dmeans3D, dL_dmeans2D,
                                  dL_dopacities, cov3D_precomp ? nullptr : dL_dscales,
                                  cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr,
                                  dL_dshs, stream);

@@ -52,7 +52,7 @@ struct GeomView {
     uint32_t* sort_keys;     // [P] scratch (depth bits)
     uint32_t* sort_tmp;      // scratch for the P-sized sort + scan partials
     uint32_t* total;         // [2] device-side R (uint64 as two words)
-    float* ggrad;            // [8P] backward scratch: per-Gaussian geometric gradient records
+    float* ggrad;            // [8P] backward scratch: per-Gaussian gradient-moment records
     float* drgb;             // [3P] backward scratch: dL/d(SH colour)
 };
 struct BinView {
@@ -82,7 +82,8 @@ int launch_preprocess(const splatraster_settings& s, int32_t P, const float* mea
 int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           const float* view, const float* proj, const float* campos, const int32_t* radii,
-                          const uint8_t* clamped, const float* ggrad, const float* dcolors_rgb,
+                          const uint8_t* clamped, const float4* rec, const float* ggrad,
+                          const float* dcolors_rgb,
                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
                           float* dL_drotations, float* dL_dcov3D, float* dL_dshs, hipStream_t stream);
 int launch_mark_visible(int32_t P, const float* means3D, const float* view, uint8_t* present,
@@ -109,7 +110,7 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, co
                          const BinView& b, const ImgView& im, const float* feat, int feat_stride,
                          const float* out_color, const float* out_depth, const float* dL_dcolor,
                          const float* dL_ddepth, const float* dL_dalpha,
-                         float* ggrad /*[P,8]: dmean2D.xy, dconic.abc, dopacity, ddepth, pad*/,
+                         float* ggrad /*[P,8]: moments sum E dx, E dy, E dx^2, E dx dy, E dy^2, E, w g_D, pad*/,
                          float* dcolors /*[P,C]*/, hipStream_t stream);
 
 int knn_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream);

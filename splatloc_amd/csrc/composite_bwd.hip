@@ -152,7 +152,7 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass, int tile
                      const float* __restrict__ out_color, const float* __restrict__ out_depth,
                      const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                     const float* __restrict__ dL_dalpha, float* __restrict__ ggrad /*[P,8]*/,
+                     const float* __restrict__ dL_dalpha, float* __restrict__ ggrad /*[P,8] moments*/,
                      float* __restrict__ dcolors /*[P,C_total]*/)
 {
     using Cfg = BwdCfg<NC>;
@@ -224,7 +224,6 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass, int tile
     const uint32_t end = min(end0, beg + wave_last);
 
     float T = 1.0f;
-    const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
     // wave_reduce_pack leaves total k in lane bitreverse6(k); values [0, KV) belong to the first
     // Gaussian of a pair, [KV, 2 KV) to the second; inside a Gaussian: NV colours then 7 geometric
     const int slotv = (int)(__brev((unsigned)lane) >> 26);
@@ -350,24 +349,27 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass, int tile
                     red[ch] = w0 * g[NM + ch];
                     red[KV + ch] = w1 * g[NM + ch];
                 }
+                // geometric partials as raw moments of E = G dL/dalpha over the pixel offset d;
+                // the per-Gaussian factors (conic, opacity, 0.5 W / 0.5 H) are applied once per
+                // Gaussian in preprocess_bwd instead of once per (pixel, Gaussian) here
                 {
-                    const float dG = q0.w * dA0, gdx = G0 * dx0, gdy = G0 * dy0;
-                    red[NV + 0] = dG * (-gdx * q0.x - gdy * q0.y) * halfW;
-                    red[NV + 1] = dG * (-gdy * q0.z - gdx * q0.y) * halfH;
-                    red[NV + 2] = -0.5f * gdx * dx0 * dG;
-                    red[NV + 3] = -gdx * dy0 * dG;
-                    red[NV + 4] = -0.5f * gdy * dy0 * dG;
-                    red[NV + 5] = G0 * dA0;
+                    const float E = G0 * dA0, Ex = E * dx0, Ey = E * dy0;
+                    red[NV + 0] = Ex;
+                    red[NV + 1] = Ey;
+                    red[NV + 2] = Ex * dx0;
+                    red[NV + 3] = Ex * dy0;
+                    red[NV + 4] = Ey * dy0;
+                    red[NV + 5] = E;
                     red[NV + 6] = w0 * gD;
                 }
                 {
-                    const float dG = q1.w * dA1, gdx = G1 * dx1, gdy = G1 * dy1;
-                    red[KV + NV + 0] = dG * (-gdx * q1.x - gdy * q1.y) * halfW;
-                    red[KV + NV + 1] = dG * (-gdy * q1.z - gdx * q1.y) * halfH;
-                    red[KV + NV + 2] = -0.5f * gdx * dx1 * dG;
-                    red[KV + NV + 3] = -gdx * dy1 * dG;
-                    red[KV + NV + 4] = -0.5f * gdy * dy1 * dG;
-                    red[KV + NV + 5] = G1 * dA1;
+                    const float E = G1 * dA1, Ex = E * dx1, Ey = E * dy1;
+                    red[KV + NV + 0] = Ex;
+                    red[KV + NV + 1] = Ey;
+                    red[KV + NV + 2] = Ex * dx1;
+                    red[KV + NV + 3] = Ex * dy1;
+                    red[KV + NV + 4] = Ey * dy1;
+                    red[KV + NV + 5] = E;
                     red[KV + NV + 6] = w1 * gD;
                 }
                 const float outv = wave_reduce_pack<2 * KV>(red, lane);

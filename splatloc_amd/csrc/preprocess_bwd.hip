@@ -2,8 +2,12 @@
 // "PREPROCESS bwd"): conic -> cov2D -> (Sigma3, view-space mean) -> scale / quaternion /
 // mean3D, NDC mean2D -> mean3D through the projection, depth -> mean3D, SH -> (sh, mean3D).
 //
-// One thread per Gaussian; reads the 32-byte geometric-gradient record accumulated by the
-// compositing backward plus the forward inputs, writes every gradient tensor once.
+// One thread per Gaussian; reads the 32-byte record of gradient MOMENTS accumulated by the
+// compositing backward, with E = G dL/dalpha and d = mu2D - pixel summed over (pixel, tile):
+//   (sum E dx, sum E dy, sum E dx^2, sum E dx dy, sum E dy^2, sum E, sum w g_D, pad)
+// turns them into dL/dmean2D (NDC), dL/dconic, dL/dopacity, dL/ddepth with the per-Gaussian
+// factors (conic, opacity, 0.5 W, 0.5 H), and chains through the projection.  Plus the forward
+// inputs; writes every gradient tensor once.
 // HBM-bound: ~100 B read, ~70 B written per Gaussian.
 #include "common.h"
 
@@ -85,7 +89,8 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
                       const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
                       const float* __restrict__ proj, const float* __restrict__ campos_p,
                       const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
-                      const float* __restrict__ ggrad, const float* __restrict__ drgb,
+                      const float4* __restrict__ rec, const float* __restrict__ ggrad,
+                      const float* __restrict__ drgb,
                       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                       float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D,
@@ -106,8 +111,11 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
     if (visible) {
         const float4 g0 = reinterpret_cast<const float4*>(ggrad)[2 * i];
         const float4 g1 = reinterpret_cast<const float4*>(ggrad)[2 * i + 1];
-        dm2x = g0.x; dm2y = g0.y;
-        const float gA = g0.z, gB = g0.w, gC = g1.x;
+        const float4 con = rec[2 * (size_t)i + 1];  // conic a, b, c, opacity of the forward
+        // power = -1/2 (A dx^2 + C dy^2) - B dx dy, alpha = o G:
+        dm2x = -0.5f * (float)W * con.w * (con.x * g0.x + con.y * g0.y);
+        dm2y = -0.5f * (float)H * con.w * (con.z * g0.y + con.y * g0.x);
+        const float gA = -0.5f * con.w * g0.z, gB = -con.w * g0.w, gC = -0.5f * con.w * g1.x;
         dop = g1.y;
         const float gdepth = g1.z;
         const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
@@ -265,15 +273,16 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
 int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           const float* view, const float* proj, const float* campos, const int32_t* radii,
-                          const uint8_t* clamped, const float* ggrad, const float* dcolors_rgb,
+                          const uint8_t* clamped, const float4* rec, const float* ggrad,
+                          const float* dcolors_rgb,
                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
                           float* dL_drotations, float* dL_dcov3D, float* dL_dshs, hipStream_t stream)
 {
     if (P == 0) return SPLATRASTER_OK;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, s.image_width,
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs, means3D,
-                       shs, scales, rotations, cov3D_precomp, view, proj, campos, radii, clamped, ggrad,
-                       dcolors_rgb, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscales, dL_drotations,
+                       shs, scales, rotations, cov3D_precomp, view, proj, campos, radii, clamped, rec,
+                       ggrad, dcolors_rgb, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscales, dL_drotations,
                        dL_dcov3D, dL_dshs);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
