@@ -31,9 +31,14 @@
 #define SR_BWD_MINW 3  // waves per SIMD the register allocator must allow (4 spills at C = 35: 1.98 vs 1.52 ms)
 #endif
 
+#ifndef SR_BWD_PKDOT
+#define SR_BWD_PKDOT 0  // v_pk_fma_f32 dot products: measured SLOWER (1.76 vs 1.47 ms on S2; A/B tools/ablate.py)
+#endif
+
 namespace sr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NC>
 struct BwdCfg {
@@ -323,12 +328,29 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass, int tile
                 // ---- dot products q = f . g (+ depth) of both Gaussians ----
                 const float* f0 = &s_feat[slot * NCP];
                 const float* f1 = &s_feat[s1 * NCP];
+#if SR_BWD_PKDOT
+                // even/odd channel partial sums as 2-vectors: v_pk_fma_f32 does both per instruction
+                f32x2 qa0 = {p0.z * gD, 0.0f}, qa1 = {p1.z * gD, 0.0f};
+#pragma unroll
+                for (int k = 0; k < NC / 2; ++k) {
+                    const f32x2 gg = {g[2 * k], g[2 * k + 1]};
+                    const f32x2 x0 = {f0[2 * k], f0[2 * k + 1]}, x1 = {f1[2 * k], f1[2 * k + 1]};
+                    qa0 = __builtin_elementwise_fma(x0, gg, qa0);
+                    qa1 = __builtin_elementwise_fma(x1, gg, qa1);
+                }
+                float qd0 = qa0[0] + qa0[1], qd1 = qa1[0] + qa1[1];
+                if (NC & 1) {
+                    qd0 += f0[NC - 1] * g[NC - 1];
+                    qd1 += f1[NC - 1] * g[NC - 1];
+                }
+#else
                 float qd0 = p0.z * gD, qd1 = p1.z * gD;
 #pragma unroll
                 for (int ch = 0; ch < NC; ++ch) {
                     qd0 += f0[ch] * g[ch];
                     qd1 += f1[ch] * g[ch];
                 }
+#endif
                 // ---- Gaussian 0, then Gaussian 1 (sequential in T and S) ----
                 const float w0 = hit0 ? al0 * T : 0.0f;
                 float dA0 = 0.0f, dA1 = 0.0f;
