@@ -66,8 +66,9 @@ typedef struct splatraster_settings {
  * depth-sorted order, instance offsets, SH colours + clamp flags. */
 size_t splatraster_geometry_bytes(int32_t P);
 /* per-tile-instance state for R = num_rendered instances: sorted point list and the
- * sort's ping-pong buffers, plus the [tiles] range table. */
-size_t splatraster_binning_bytes(int32_t P, int64_t R, int32_t width, int32_t height);
+ * sort's ping-pong buffers, the [tiles] range table, the per-instance payload (32-byte record
+ * + quadrant reach mask) and, when channels % 4 != 0, the 16-byte-aligned feature table. */
+size_t splatraster_binning_bytes(int32_t P, int64_t R, int32_t width, int32_t height, int32_t channels);
 /* per-pixel forward state needed by backward: final transmittance, last contributor. */
 size_t splatraster_image_bytes(int32_t width, int32_t height);
 
@@ -100,7 +101,7 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P,
 /*
  * Stage 2 of forward: instance emission, stable tile-bucket radix sort, tile ranges and
  * front-to-back alpha compositing.  R must be the value stage 1 returned and `binning`
- * must hold splatraster_binning_bytes(P, R, W, H) bytes.
+ * must hold splatraster_binning_bytes(P, R, W, H, C) bytes.
  *
  * Outputs: out_color [C,H,W], out_depth [1,H,W], out_alpha [1,H,W]
  * (the first three members of the tuple GaussianRasterizer.forward returns,
@@ -176,7 +177,7 @@ typedef struct splatraster_image_layout {
     size_t total;
 } splatraster_image_layout;
 int splatraster_get_geometry_layout(int32_t P, splatraster_geometry_layout* out);
-int splatraster_get_binning_layout(int32_t P, int64_t R, int32_t width, int32_t height,
+int splatraster_get_binning_layout(int32_t P, int64_t R, int32_t width, int32_t height, int32_t channels,
                                    splatraster_binning_layout* out);
 int splatraster_get_image_layout(int32_t width, int32_t height, splatraster_image_layout* out);
 

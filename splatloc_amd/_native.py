@@ -51,14 +51,14 @@ class ImageLayout(C.Structure):
 _vp, _i32, _i64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
 SYMBOLS = {
     "splatraster_geometry_bytes": (_sz, [_i32]),
-    "splatraster_binning_bytes": (_sz, [_i32, _i64, _i32, _i32]),
+    "splatraster_binning_bytes": (_sz, [_i32, _i64, _i32, _i32, _i32]),
     "splatraster_image_bytes": (_sz, [_i32, _i32]),
     "splatraster_forward_geometry": (C.c_int, [C.POINTER(Settings), _i32] + [_vp] * 9 + [_vp, _vp, C.POINTER(_i64), _vp]),
     "splatraster_forward_render": (C.c_int, [C.POINTER(Settings), _i32, _i64] + [_vp] * 9),
     "splatraster_backward": (C.c_int, [C.POINTER(Settings), _i32, _i64] + [_vp] * 30),
     "splatraster_mark_visible": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_get_geometry_layout": (C.c_int, [_i32, C.POINTER(GeometryLayout)]),
-    "splatraster_get_binning_layout": (C.c_int, [_i32, _i64, _i32, _i32, C.POINTER(BinningLayout)]),
+    "splatraster_get_binning_layout": (C.c_int, [_i32, _i64, _i32, _i32, _i32, C.POINTER(BinningLayout)]),
     "splatraster_get_image_layout": (C.c_int, [_i32, _i32, C.POINTER(ImageLayout)]),
     "splatraster_sort_tmp_bytes": (_sz, [_i64]),
     "splatraster_sort_pairs_u32": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _vp]),

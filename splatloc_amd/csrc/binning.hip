@@ -130,4 +130,35 @@ int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, 
     return SPLATRASTER_OK;
 }
 
+// Feature rows are user input [P, C]; with C % 4 != 0 (C = 35: 140-byte rows) they are only
+// 4-byte aligned, which forces 4-byte gathers in the compositing kernels.  One streaming pass
+// per frame pads them to 16-byte aligned rows of CP = roundup4(C) floats (pad = 0).
+__global__ void __launch_bounds__(256)
+pad_features_kernel(int64_t n4 /* P * CP / 4 */, int C, int PPR, const float* __restrict__ feat,
+                    float4* __restrict__ featp4)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte piece per thread
+    if (e >= n4) return;
+    const int64_t row = e / PPR;
+    const int c = (int)(e - row * PPR) * 4;
+    const float* src = feat + row * C + c;
+    float4 v;
+    v.x = src[0];
+    v.y = c + 1 < C ? src[1] : 0.0f;
+    v.z = c + 2 < C ? src[2] : 0.0f;
+    v.w = c + 3 < C ? src[3] : 0.0f;
+    featp4[e] = v;
+}
+
+int launch_pad_features(int32_t P, int C, const float* feat, float* featp, hipStream_t stream)
+{
+    const int CP = padded_channels(C);
+    const int64_t n4 = (int64_t)P * CP / 4;
+    if (n4 == 0 || CP == C) return SPLATRASTER_OK;
+    hipLaunchKernelGGL(pad_features_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, n4, C, CP / 4,
+                       feat, reinterpret_cast<float4*>(featp));
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
 }  // namespace sr

@@ -109,9 +109,9 @@ GeomView geom_view(void* base, int32_t P)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, bytes;
 };
-static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
+static BinLayout bin_layout(int32_t P, int64_t R, int32_t W, int32_t H, int32_t C)
 {
     const size_t n = (size_t)(R > 0 ? R : 1);
     const size_t tiles = (size_t)((W + TILE - 1) / TILE) * (size_t)((H + TILE - 1) / TILE);
@@ -126,14 +126,15 @@ static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
     L.sort_tmp = take(sort_tmp_bytes((int64_t)n));
     L.irec = take(32 * n);
     L.imask = take(n);
+    // padded feature table only when the rows are not already 16-byte aligned
+    L.featp = take((C % 4) ? (size_t)(P > 0 ? P : 1) * padded_channels(C) * sizeof(float) : 16);
     L.bytes = o;
     return L;
 }
 
-BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H)
+BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H, int32_t C)
 {
-    (void)P;
-    const BinLayout L = bin_layout(R, W, H);
+    const BinLayout L = bin_layout(P, R, W, H, C);
     char* b = reinterpret_cast<char*>(base);
     BinView v;
     v.point_list = reinterpret_cast<uint32_t*>(b + L.valsA);
@@ -144,6 +145,7 @@ BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H)
     v.sort_tmp = b + L.sort_tmp;
     v.irec = reinterpret_cast<float4*>(b + L.irec);
     v.imask = reinterpret_cast<uint8_t*>(b + L.imask);
+    v.featp = reinterpret_cast<float*>(b + L.featp);
     return v;
 }
 
@@ -187,10 +189,9 @@ const char* splatraster_error_string(int status)
 const char* splatraster_last_hip_error(void) { return g_last_error.c_str(); }
 
 size_t splatraster_geometry_bytes(int32_t P) { return geom_layout(P).bytes; }
-size_t splatraster_binning_bytes(int32_t P, int64_t R, int32_t width, int32_t height)
+size_t splatraster_binning_bytes(int32_t P, int64_t R, int32_t width, int32_t height, int32_t channels)
 {
-    (void)P;
-    return bin_layout(R, width, height).bytes;
+    return bin_layout(P, R, width, height, channels).bytes;
 }
 size_t splatraster_image_bytes(int32_t width, int32_t height)
 {
@@ -206,12 +207,11 @@ int splatraster_get_geometry_layout(int32_t P, splatraster_geometry_layout* out)
     out->clamped = L.clamped; out->total = L.bytes;
     return SPLATRASTER_OK;
 }
-int splatraster_get_binning_layout(int32_t P, int64_t R, int32_t width, int32_t height,
+int splatraster_get_binning_layout(int32_t P, int64_t R, int32_t width, int32_t height, int32_t channels,
                                    splatraster_binning_layout* out)
 {
-    (void)P;
     if (!out) return SPLATRASTER_ERR_BAD_ARG;
-    const BinLayout L = bin_layout(R, width, height);
+    const BinLayout L = bin_layout(P, R, width, height, channels);
     out->point_list = L.valsA; out->tile_list = L.keysA; out->ranges = L.ranges; out->total = L.bytes;
     return SPLATRASTER_OK;
 }
@@ -295,7 +295,7 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
     GeomView g{};
     if (geometry) g = geom_view(geometry, P);
     if (!binning) return SPLATRASTER_ERR_BAD_ARG;
-    BinView b = bin_view(binning, P, R, W, H);
+    BinView b = bin_view(binning, P, R, W, H, s->channels);
     const float* feat = colors_precomp ? colors_precomp : g.rgb;
     if (R > 0 && !feat) return SPLATRASTER_ERR_BAD_ARG;
     const int bits = tile_bits(tiles);
@@ -323,13 +323,19 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
         st = launch_ranges(R, tiles, b.tile_list, b.ranges, stream);
     }
     if (st) return st;
+    const float* featp = feat;  // 16-byte aligned rows for the compositing kernels
     if (R > 0) {
         StageTimer t(SPLATRASTER_STAGE_PAYLOAD, stream);
         st = launch_payload(*s, R, g, b, stream);
+        if (st) return st;
+        if (s->channels % 4) {
+            st = launch_pad_features(P, s->channels, feat, b.featp, stream);
+            featp = b.featp;
+        }
     }
     if (st) return st;
     StageTimer t(SPLATRASTER_STAGE_COMPOSITE_FWD, stream);
-    return launch_composite_fwd(*s, R, g, b, im, feat, bg, out_color, out_depth, out_alpha, stream);
+    return launch_composite_fwd(*s, R, g, b, im, featp, bg, out_color, out_depth, out_alpha, stream);
 }
 
 int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, const float* bg,
@@ -358,7 +364,7 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int W = s->image_width, H = s->image_height;
     GeomView g = geom_view(geometry, P);
-    BinView b = bin_view(const_cast<void*>(binning), P, R, W, H);
+    BinView b = bin_view(const_cast<void*>(binning), P, R, W, H, s->channels);
     ImgView im = img_view(const_cast<void*>(image), W, H);
     const int C = s->channels;
     const float* feat = shs ? g.rgb : colors_precomp;
@@ -367,7 +373,7 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
         StageTimer t(SPLATRASTER_STAGE_COMPOSITE_BWD, stream);
         SR_HIP_CHECK(hipMemsetAsync(g.ggrad, 0, sizeof(float) * 8 * (size_t)P, stream));
         SR_HIP_CHECK(hipMemsetAsync(dcol, 0, sizeof(float) * (size_t)C * (size_t)P, stream));
-        st = launch_composite_bwd(*s, P, R, g, b, im, feat, C, out_color, out_depth, dL_dout_color,
+        st = launch_composite_bwd(*s, P, R, g, b, im, (C % 4) ? b.featp : feat, C, out_color, out_depth, dL_dout_color,
                                   dL_dout_depth, dL_dout_alpha, g.ggrad, dcol, stream);
     }
     if (st) return st;

@@ -64,6 +64,7 @@ struct BinView {
     void* sort_tmp;       // radix sort scratch
     float4* irec;         // [2R] per-instance copy of the 32-byte record, in sorted order
     uint8_t* imask;       // [R] bit q: the Gaussian may reach quadrant q of its tile
+    float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows)
 };
 struct ImgView {
     float* final_T;
@@ -71,7 +72,7 @@ struct ImgView {
 };
 
 GeomView geom_view(void* base, int32_t P);
-BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H);
+BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H, int32_t C);
 ImgView img_view(void* base, int32_t W, int32_t H);
 
 // ---- stage launchers (each returns a SPLATRASTER_* status) -----------------------------
@@ -102,9 +103,12 @@ int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomV
                 uint32_t* vals, hipStream_t stream);
 int launch_ranges(int64_t R, int32_t tiles, const uint32_t* tile_list, uint32_t* ranges, hipStream_t stream);
 int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b, hipStream_t stream);
+// 16-byte aligned copy of the [P, C] feature rows (returns feat itself when C % 4 == 0)
+int launch_pad_features(int32_t P, int C, const float* feat, float* featp, hipStream_t stream);
+static inline int padded_channels(int C) { return (C + 3) & ~3; }
 
 int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b,
-                         const ImgView& im, const float* feat, const float* bg, float* out_color,
+                         const ImgView& im, const float* featp /*padded rows*/, const float* bg, float* out_color,
                          float* out_depth, float* out_alpha, hipStream_t stream);
 int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g,
                          const BinView& b, const ImgView& im, const float* feat, int feat_stride,

@@ -150,10 +150,10 @@ __device__ __forceinline__ float wave_reduce_pack(const float (&v)[K], int lane)
 
 template <int NC>
 __global__ void __launch_bounds__(WAVE, SR_BWD_MINW)
-composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass, int tiles,
+composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass, int tiles,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                      const float4* __restrict__ irec,
-                     const uint8_t* __restrict__ imask, const float* __restrict__ feat,
+                     const uint8_t* __restrict__ imask, const float4* __restrict__ featp4,
                      const float* __restrict__ out_color, const float* __restrict__ out_depth,
                      const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
@@ -164,6 +164,7 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass, int tile
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
     constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
     constexpr bool MFMA = Cfg::MFMA;
+    constexpr int PPR = NCP / 4;  // 16-byte pieces per staged row
     static_assert(2 * KV <= WAVE, "at most 25 butterfly-reduced channels per pass");
     __shared__ __attribute__((aligned(16))) float4 s_rec0[WAVE];
     __shared__ __attribute__((aligned(16))) float4 s_rec1[WAVE];
@@ -301,10 +302,11 @@ composite_bwd_kernel(int W, int H, int C_total, int c0, int first_pass, int tile
             __builtin_amdgcn_wave_barrier();
             if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid;
             __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-            for (int e = lane; e < ncand * NC; e += WAVE) {
-                const int row = e / NC, ch = e - row * NC;
-                s_feat[row * NCP + ch] = feat[(size_t)s_cgid[row] * C_total + c0 + ch];
+            // 16-byte pieces of the 16-byte-aligned padded rows
+#pragma unroll 2
+            for (int e = lane; e < ncand * PPR; e += WAVE) {
+                const int row = e / PPR, pc = e - row * PPR;
+                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)s_cgid[row] * CP4 + (c0 >> 2) + pc];
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
@@ -432,8 +434,8 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
     const int tiles = gx * gy;
     const unsigned blocks = (unsigned)((tiles + 7) / 8) * 32u;  // 4 quadrants per tile, tiles padded to 8
     hipLaunchKernelGGL(composite_bwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
-                       s.image_height, feat_stride, c0, first, tiles, b.ranges, b.point_list, b.irec,
-                       b.imask, feat, out_color, out_depth, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth,
+                       s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, b.ranges,
+                       b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), out_color, out_depth, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth,
                        dL_dalpha, ggrad, dcolors);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;

@@ -54,10 +54,10 @@ struct FwdCfg {
 
 template <int NC>
 __global__ void __launch_bounds__(WAVE, SR_FWD_MINW)
-composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int write_aux, int tiles,
+composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_aux, int tiles,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                      const float4* __restrict__ irec,
-                     const uint8_t* __restrict__ imask, const float* __restrict__ feat,
+                     const uint8_t* __restrict__ imask, const float4* __restrict__ featp4,
                      const float* __restrict__ bg, float* __restrict__ out_color,
                      float* __restrict__ out_depth, float* __restrict__ out_alpha,
                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
@@ -65,6 +65,7 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
     using Cfg = FwdCfg<NC>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, FS = Cfg::FS;
     constexpr bool MFMA = Cfg::MFMA;
+    constexpr int PPR = NCP / 4;  // 16-byte pieces per staged row
     __shared__ __attribute__((aligned(16))) float4 s_rec0[WAVE];
     __shared__ __attribute__((aligned(16))) float4 s_rec1[WAVE];
     __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
@@ -130,10 +131,11 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
             __builtin_amdgcn_wave_barrier();
             if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid;
             __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-            for (int e = lane; e < ncand * NC; e += WAVE) {
-                const int row = e / NC, ch = e - row * NC;
-                s_feat[row * NCP + ch] = feat[(size_t)s_cgid[row] * C_total + c0 + ch];
+            // 16-byte pieces of the 16-byte-aligned padded rows
+#pragma unroll 2
+            for (int e = lane; e < ncand * PPR; e += WAVE) {
+                const int row = e / PPR, pc = e - row * PPR;
+                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)s_cgid[row] * CP4 + (c0 >> 2) + pc];
             }
             __builtin_amdgcn_wave_barrier();
             // ---- composite them front to back, two at a time ----
@@ -223,7 +225,7 @@ composite_fwd_kernel(int W, int H, int C_total, int c0, int bg_channels, int wri
 
 template <int NC>
 static int launch_one(const splatraster_settings& s, int c0, int write_aux, const GeomView& g,
-                      const BinView& b, const ImgView& im, const float* feat, int feat_stride,
+                      const BinView& b, const ImgView& im, const float* featp, int feat_stride,
                       const float* bg, float* out_color, float* out_depth, float* out_alpha,
                       hipStream_t stream)
 {
@@ -232,15 +234,15 @@ static int launch_one(const splatraster_settings& s, int c0, int write_aux, cons
     const int tiles = gx * gy;
     const unsigned blocks = (unsigned)((tiles + 7) / 8) * 32u;  // 4 quadrants per tile, tiles padded to 8
     hipLaunchKernelGGL(composite_fwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
-                       s.image_height, feat_stride, c0, s.bg_channels, write_aux, tiles, b.ranges, b.point_list,
-                       b.irec, b.imask, feat, bg, out_color, out_depth, out_alpha, im.final_T,
+                       s.image_height, padded_channels(feat_stride) / 4, c0, s.bg_channels, write_aux, tiles, b.ranges,
+                       b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(featp), bg, out_color, out_depth, out_alpha, im.final_T,
                        im.n_contrib);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
 
 int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b,
-                         const ImgView& im, const float* feat, const float* bg, float* out_color,
+                         const ImgView& im, const float* featp, const float* bg, float* out_color,
                          float* out_depth, float* out_alpha, hipStream_t stream)
 {
     (void)R;
@@ -248,7 +250,7 @@ int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomVie
     int c0 = 0, aux = 1, st = SPLATRASTER_OK;
 #define SR_FWD_CASE(N)                                                                              \
     case N:                                                                                         \
-        return launch_one<N>(s, 0, 1, g, b, im, feat, C, bg, out_color, out_depth, out_alpha, stream);
+        return launch_one<N>(s, 0, 1, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream);
     switch (C) {
         SR_FWD_CASE(1) SR_FWD_CASE(2) SR_FWD_CASE(3) SR_FWD_CASE(4) SR_FWD_CASE(8) SR_FWD_CASE(16)
         SR_FWD_CASE(32) SR_FWD_CASE(35)
@@ -258,13 +260,13 @@ int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomVie
     // generic channel count: chunked passes (alpha is re-evaluated per chunk)
     while (c0 < C && st == SPLATRASTER_OK) {
         const int left = C - c0;
-        if (left >= 32) { st = launch_one<32>(s, c0, aux, g, b, im, feat, C, bg, out_color, out_depth, out_alpha, stream); c0 += 32; }
-        else if (left >= 16) { st = launch_one<16>(s, c0, aux, g, b, im, feat, C, bg, out_color, out_depth, out_alpha, stream); c0 += 16; }
-        else if (left >= 8) { st = launch_one<8>(s, c0, aux, g, b, im, feat, C, bg, out_color, out_depth, out_alpha, stream); c0 += 8; }
-        else if (left >= 4) { st = launch_one<4>(s, c0, aux, g, b, im, feat, C, bg, out_color, out_depth, out_alpha, stream); c0 += 4; }
-        else if (left == 3) { st = launch_one<3>(s, c0, aux, g, b, im, feat, C, bg, out_color, out_depth, out_alpha, stream); c0 += 3; }
-        else if (left == 2) { st = launch_one<2>(s, c0, aux, g, b, im, feat, C, bg, out_color, out_depth, out_alpha, stream); c0 += 2; }
-        else { st = launch_one<1>(s, c0, aux, g, b, im, feat, C, bg, out_color, out_depth, out_alpha, stream); c0 += 1; }
+        if (left >= 32) { st = launch_one<32>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 32; }
+        else if (left >= 16) { st = launch_one<16>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 16; }
+        else if (left >= 8) { st = launch_one<8>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 8; }
+        else if (left >= 4) { st = launch_one<4>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 4; }
+        else if (left == 3) { st = launch_one<3>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 3; }
+        else if (left == 2) { st = launch_one<2>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 2; }
+        else { st = launch_one<1>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 1; }
         aux = 0;
     }
     return st;

@@ -33,10 +33,10 @@ def geometry_views(geom: torch.Tensor, P: int) -> dict:
     )
 
 
-def binning_views(binning: torch.Tensor, P: int, R: int, W: int, H: int) -> dict:
+def binning_views(binning: torch.Tensor, P: int, R: int, W: int, H: int, channels: int = 4) -> dict:
     lib = _native.load()
     L = _native.BinningLayout()
-    _native.check(lib.splatraster_get_binning_layout(P, R, W, H, C.byref(L)), "binning_layout")
+    _native.check(lib.splatraster_get_binning_layout(P, R, W, H, channels, C.byref(L)), "binning_layout")
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     return dict(
         point_list=_view(binning, L.point_list, R, torch.int32),

@@ -114,7 +114,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _native.check(lib.splatraster_forward_geometry(
                 C.byref(st), P, _ptr(m3), _ptr(shs), _ptr(opa), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(view),
                 _ptr(proj), _ptr(campos), _ptr(geom), _ptr(radii), C.byref(R), stream), "forward_geometry")
-            binning = torch.empty((lib.splatraster_binning_bytes(P, R.value, W, H),), dtype=torch.uint8,
+            binning = torch.empty((lib.splatraster_binning_bytes(P, R.value, W, H, Cn),), dtype=torch.uint8,
                                   device=dev)
             _native.check(lib.splatraster_forward_render(
                 C.byref(st), P, R.value, _ptr(bg), _ptr(col), _ptr(geom), _ptr(binning), _ptr(img),

@@ -35,7 +35,7 @@ def test_host_only_entry_points():
     assert lib.splatraster_error_string(0) == b"ok" and lib.splatraster_error_string(1) == b"bad argument"
     g1, g2 = lib.splatraster_geometry_bytes(1000), lib.splatraster_geometry_bytes(500_000)
     assert 0 < g1 < g2 and g2 % 256 == 0
-    b = lib.splatraster_binning_bytes(500_000, 4_000_000, 1920, 1080)
+    b = lib.splatraster_binning_bytes(500_000, 4_000_000, 1920, 1080, 35)
     assert b >= 16 * 4_000_000
     assert lib.splatraster_image_bytes(1920, 1080) >= 8 * 1920 * 1080
     L = _native.GeometryLayout()
@@ -44,8 +44,10 @@ def test_host_only_entry_points():
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and L.total == g1
     assert L.rec1 == L.rec0 + 16          # interleaved 32-byte records
     B = _native.BinningLayout()
-    assert lib.splatraster_get_binning_layout(1000, 5000, 640, 480, C.byref(B)) == 0
-    assert B.total == lib.splatraster_binning_bytes(1000, 5000, 640, 480)
+    assert lib.splatraster_get_binning_layout(1000, 5000, 640, 480, 4, C.byref(B)) == 0
+    assert B.total == lib.splatraster_binning_bytes(1000, 5000, 640, 480, 4)
+    # C % 4 != 0 adds the 16-byte-aligned feature table
+    assert lib.splatraster_binning_bytes(1000, 5000, 640, 480, 35) >= B.total + 1000 * 36 * 4 - 256
     assert lib.splatraster_get_geometry_layout(10, None) == 1           # BAD_ARG, no crash
     assert lib.splatknn_workspace_bytes(20_000) >= 20_000 * 12
     assert lib.splatraster_sort_tmp_bytes(1 << 20) > 8 * (1 << 20)
