@@ -82,11 +82,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)   # > 1 rank per GPU only in the single-GPU plumbing test
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm (xGMI); SPLATLOC_DIST_BACKEND=gloo lets tests drive this exact
+        # code path with several ranks on one GPU.
+        backend = os.environ.get("SPLATLOC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer, _native
     from splatloc_amd.frame_parallel import allreduce_grads

@@ -1,0 +1,122 @@
+"""End-to-end checks on the GPU: the gradients drive an optimiser the way train_gaussians.py
+uses them, and bench.py's multi-rank path runs (2 ranks on one GPU, gloo)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from splatloc_amd.synthetic import make_scene
+from tests.helpers import hip_settings
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _render(rast, p, sc_scales, C):
+    # activations as GaussianModel's getters apply them (gaussian_model.py:78-113)
+    return rast(means3D=p["xyz"], means2D=torch.zeros_like(p["xyz"], requires_grad=True), shs=None,
+                colors_precomp=torch.sigmoid(p["feat"]), opacities=torch.sigmoid(p["opacity"]),
+                scales=torch.exp(p["log_scale"]), rotations=torch.nn.functional.normalize(p["rot"]),
+                cov3D_precomp=None)
+
+
+@pytest.mark.parametrize("C", [4, 35])
+def test_adam_fits_a_target_render(C):
+    """map()-shaped optimisation (train_gaussians.py:187-267): L1 on colour + depth, Adam on
+    the same parameter groups; the loss must drop substantially within 60 steps."""
+    from splatloc_amd import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    sc = make_scene(3000, 160, 128, C, 5, scale_median=0.04)
+    rast = GaussianRasterizer(raster_settings=hip_settings(sc, dev))
+    g = torch.Generator().manual_seed(1)
+    inv_sig = lambda x: torch.log(x / (1 - x))  # noqa: E731
+    target = {"xyz": sc.means3D, "feat": inv_sig(sc.features.clamp(0.02, 0.98)),
+              "opacity": inv_sig(sc.opacities.clamp(0.02, 0.98)), "log_scale": torch.log(sc.scales),
+              "rot": sc.rotations}
+    with torch.no_grad():
+        tgt = {k: v.to(dev) for k, v in target.items()}
+        t_color, t_depth, _, _ = _render(rast, tgt, None, C)
+    p = {"xyz": (sc.means3D + 0.01 * torch.randn(sc.means3D.shape, generator=g)),
+         "feat": target["feat"] + 0.8 * torch.randn(target["feat"].shape, generator=g),
+         "opacity": target["opacity"] + 0.5 * torch.randn(target["opacity"].shape, generator=g),
+         "log_scale": target["log_scale"] + 0.15 * torch.randn(target["log_scale"].shape, generator=g),
+         "rot": target["rot"] + 0.1 * torch.randn(target["rot"].shape, generator=g)}
+    p = {k: v.to(dev).requires_grad_(True) for k, v in p.items()}
+    opt = torch.optim.Adam([{"params": [p["xyz"]], "lr": 2e-4}, {"params": [p["feat"]], "lr": 5e-2},
+                            {"params": [p["opacity"]], "lr": 3e-2}, {"params": [p["log_scale"]], "lr": 5e-3},
+                            {"params": [p["rot"]], "lr": 2e-3}], eps=1e-15)
+    losses = []
+    for _ in range(60):
+        color, depth, alpha, radii = _render(rast, p, None, C)
+        loss = (color - t_color).abs().mean() + (depth - t_depth).abs().mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        assert all(torch.isfinite(v.grad).all() for v in p.values())
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.45 * losses[0], (losses[0], losses[-1])
+    assert radii.dtype == torch.int32 and int((radii > 0).sum()) > 1000
+
+
+def test_five_views_alive_before_one_backward():
+    """train_gaussians.py:195-229 keeps window_size = 5 forwards alive, sums the losses, and runs
+    ONE backward: saved state of different frames must not alias."""
+    from splatloc_amd import GaussianRasterizer
+    from splatloc_amd.camera import PinholeCamera
+    dev = torch.device("cuda:0")
+    sc = make_scene(4000, 192, 128, 4, 9, scale_median=0.04).to(dev)
+    leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.features, sc.opacities, sc.scales, sc.rotations)]
+
+    def view(k):
+        ang = 0.05 * (k - 2)
+        R = torch.tensor([[torch.cos(torch.tensor(ang)), 0, torch.sin(torch.tensor(ang))], [0, 1, 0],
+                          [-torch.sin(torch.tensor(ang)), 0, torch.cos(torch.tensor(ang))]])
+        cam = PinholeCamera(192, 128, 96.0, 96.0, 95.5, 63.5, R, torch.tensor([0.02 * k, 0.0, 0.0])).to(dev)
+        sc.camera = cam
+        return GaussianRasterizer(raster_settings=hip_settings(sc, dev))
+
+    def render(k, ls):
+        m3, col, op, sca, rot = ls
+        return view(k)(means3D=m3, means2D=torch.zeros_like(m3, requires_grad=True), shs=None, colors_precomp=col,
+                       opacities=op, scales=sca, rotations=rot, cov3D_precomp=None)
+
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.rand(4, 128, 192, generator=g).to(dev) for _ in range(5)]
+    total = 0
+    for k in range(5):                      # five forwards alive
+        color, depth, alpha, _ = render(k, leaves)
+        total = total + (color * ws[k]).sum() + depth.sum() * 1e-3
+    total.backward()                        # one backward
+    joint = [l.grad.clone() for l in leaves]
+    for l in leaves:
+        l.grad = None
+    for k in range(5):                      # reference: one view at a time
+        color, depth, alpha, _ = render(k, leaves)
+        ((color * ws[k]).sum() + depth.sum() * 1e-3).backward()
+    for a, b in zip(joint, [l.grad for l in leaves]):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-12
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """bench.py --gpus 2 through torch.distributed.run (the driver's launch line), gloo backend,
+    both ranks on cuda:0: exercises rank/world plumbing, the gradient all-reduce and the
+    max-over-ranks timing.  (RCCL itself needs 2 GPUs; this box has one.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SPLATLOC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--workload", "S0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]     # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["frames_per_step"] == 2 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["steps"] == 3 and "roofline" in out and "cpu_baseline" not in out
