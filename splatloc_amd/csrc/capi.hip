@@ -62,7 +62,7 @@ static inline int tile_bits(int tiles)
 
 struct GeomLayout {
     size_t rec0, rec1, tiles_touched, depth_order, offsets, rgb, clamped, sort_keys, keys_alt, vals_alt,
-        sort_tmp, scan_tmp, total, ggrad, drgb, bytes;
+        sort_tmp, scan_tmp, total, bytes;
 };
 static GeomLayout geom_layout(int32_t P)
 {
@@ -83,8 +83,6 @@ static GeomLayout geom_layout(int32_t P)
     L.sort_tmp = take(sort_tmp_bytes((int64_t)n));
     L.scan_tmp = take(scan_tmp_bytes((int64_t)n));
     L.total = take(16);
-    L.ggrad = take(32 * n);
-    L.drgb = take(12 * n);
     L.bytes = o;
     return L;
 }
@@ -103,13 +101,11 @@ GeomView geom_view(void* base, int32_t P)
     g.sort_keys = reinterpret_cast<uint32_t*>(b + L.sort_keys);
     g.sort_tmp = reinterpret_cast<uint32_t*>(b + L.sort_tmp);
     g.total = reinterpret_cast<uint32_t*>(b + L.total);
-    g.ggrad = reinterpret_cast<float*>(b + L.ggrad);
-    g.drgb = reinterpret_cast<float*>(b + L.drgb);
     return g;
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, bytes;
 };
 static BinLayout bin_layout(int32_t P, int64_t R, int32_t W, int32_t H, int32_t C)
 {
@@ -128,6 +124,7 @@ static BinLayout bin_layout(int32_t P, int64_t R, int32_t W, int32_t H, int32_t 
     L.imask = take(n);
     // padded feature table only when the rows are not already 16-byte aligned
     L.featp = take((C % 4) ? (size_t)(P > 0 ? P : 1) * padded_channels(C) * sizeof(float) : 16);
+    L.gacc = take((size_t)(P > 0 ? P : 1) * gacc_row_floats(C) * sizeof(float));
     L.bytes = o;
     return L;
 }
@@ -146,6 +143,7 @@ BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H, int32_t
     v.irec = reinterpret_cast<float4*>(b + L.irec);
     v.imask = reinterpret_cast<uint8_t*>(b + L.imask);
     v.featp = reinterpret_cast<float*>(b + L.featp);
+    v.gacc = reinterpret_cast<float*>(b + L.gacc);
     return v;
 }
 
@@ -368,18 +366,17 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     ImgView im = img_view(const_cast<void*>(image), W, H);
     const int C = s->channels;
     const float* feat = shs ? g.rgb : colors_precomp;
-    float* dcol = shs ? g.drgb : dL_dcolors;
     {
         StageTimer t(SPLATRASTER_STAGE_COMPOSITE_BWD, stream);
-        SR_HIP_CHECK(hipMemsetAsync(g.ggrad, 0, sizeof(float) * 8 * (size_t)P, stream));
-        SR_HIP_CHECK(hipMemsetAsync(dcol, 0, sizeof(float) * (size_t)C * (size_t)P, stream));
+        SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * (size_t)gacc_row_floats(C) * (size_t)P, stream));
         st = launch_composite_bwd(*s, P, R, g, b, im, (C % 4) ? b.featp : feat, C, out_color, out_depth, dL_dout_color,
-                                  dL_dout_depth, dL_dout_alpha, g.ggrad, dcol, stream);
+                                  dL_dout_depth, dL_dout_alpha, b.gacc, stream);
     }
     if (st) return st;
     StageTimer t(SPLATRASTER_STAGE_PREPROCESS_BWD, stream);
     return launch_preprocess_bwd(*s, P, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
-                                 campos, radii, g.clamped, g.rec, g.ggrad, g.drgb, dL_dmeans3D, dL_dmeans2D,
+                                 campos, radii, g.clamped, g.rec, b.gacc, C, shs ? nullptr : dL_dcolors, dL_dmeans3D,
+                                 dL_dmeans2D,
                                  dL_dopacities, cov3D_precomp ? nullptr : dL_dscales,
                                  cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr,
                                  dL_dshs, stream);

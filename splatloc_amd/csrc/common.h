@@ -52,8 +52,6 @@ struct GeomView {
     uint32_t* sort_keys;     // [P] scratch (depth bits)
     uint32_t* sort_tmp;      // scratch for the P-sized sort + scan partials
     uint32_t* total;         // [2] device-side R (uint64 as two words)
-    float* ggrad;            // [8P] backward scratch: per-Gaussian gradient-moment records
-    float* drgb;             // [3P] backward scratch: dL/d(SH colour)
 };
 struct BinView {
     uint32_t* point_list; // [R] sorted gaussian ids
@@ -65,6 +63,7 @@ struct BinView {
     float4* irec;         // [2R] per-instance copy of the 32-byte record, in sorted order
     uint8_t* imask;       // [R] bit q: the Gaussian may reach quadrant q of its tile
     float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows)
+    float* gacc;          // [P * gacc_row_floats(C)] backward gradient accumulator rows
 };
 struct ImgView {
     float* final_T;
@@ -83,8 +82,8 @@ int launch_preprocess(const splatraster_settings& s, int32_t P, const float* mea
 int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           const float* view, const float* proj, const float* campos, const int32_t* radii,
-                          const uint8_t* clamped, const float4* rec, const float* ggrad,
-                          const float* dcolors_rgb,
+                          const uint8_t* clamped, const float4* rec, const float* gacc, int C,
+                          float* dL_dcolors,
                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
                           float* dL_drotations, float* dL_dcov3D, float* dL_dshs, hipStream_t stream);
 int launch_mark_visible(int32_t P, const float* means3D, const float* view, uint8_t* present,
@@ -106,6 +105,12 @@ int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, 
 // 16-byte aligned copy of the [P, C] feature rows (returns feat itself when C % 4 == 0)
 int launch_pad_features(int32_t P, int C, const float* feat, float* featp, hipStream_t stream);
 static inline int padded_channels(int C) { return (C + 3) & ~3; }
+// Per-Gaussian gradient accumulator row of the backward (64-byte aligned rows so that the
+// float atomics of one Gaussian land in as few memory-side requests as possible):
+//   [0, C) dL/dfeature, [MO, MO + 7) moment record, padded to a multiple of 16 floats.
+// The moments share the last 64-byte line of the features when they fit.
+__host__ __device__ static inline int gacc_moment_offset(int C) { return ((C & 15) + 7 <= 16) ? C : ((C + 15) & ~15); }
+__host__ __device__ static inline int gacc_row_floats(int C) { return (gacc_moment_offset(C) + 7 + 15) & ~15; }
 
 int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b,
                          const ImgView& im, const float* featp /*padded rows*/, const float* bg, float* out_color,
@@ -114,8 +119,9 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, co
                          const BinView& b, const ImgView& im, const float* feat, int feat_stride,
                          const float* out_color, const float* out_depth, const float* dL_dcolor,
                          const float* dL_ddepth, const float* dL_dalpha,
-                         float* ggrad /*[P,8]: moments sum E dx, E dy, E dx^2, E dx dy, E dy^2, E, w g_D, pad*/,
-                         float* dcolors /*[P,C]*/, hipStream_t stream);
+                         float* gacc /*[P, gacc_row_floats(C)]: dL/dfeature | moments sum E dx, E dy, E dx^2,
+                                      E dx dy, E dy^2, E, w g_D*/,
+                         hipStream_t stream);
 
 int knn_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream);
 size_t knn_workspace_bytes(int32_t N);

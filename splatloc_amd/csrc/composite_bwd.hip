@@ -31,14 +31,25 @@
 #define SR_BWD_MINW 3  // waves per SIMD the register allocator must allow (4 spills at C = 35: 1.98 vs 1.52 ms)
 #endif
 
-#ifndef SR_BWD_PKDOT
-#define SR_BWD_PKDOT 0  // v_pk_fma_f32 dot products: measured SLOWER (1.76 vs 1.47 ms on S2; A/B tools/ablate.py)
+#ifndef SR_BWD_ABLATE_ATOMIC
+#define SR_BWD_ABLATE_ATOMIC 0  // perf experiment only: drop the float atomics (wrong results)
+#endif
+#ifndef SR_BWD_DOTM_MIN
+#define SR_BWD_DOTM_MIN 8  // channels from which the 4x4x1 MFMA dot product is used
 #endif
 
 namespace sr {
 
+#ifdef SR_BWD_PROFILE
+__device__ unsigned long long g_bwd_prof[12];
+#define BP_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define BP_ADD(i, x) bprof[i] += (x)
+#else
+#define BP_T(v)
+#define BP_ADD(i, x)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NC>
 struct BwdCfg {
@@ -157,13 +168,14 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      const float* __restrict__ out_color, const float* __restrict__ out_depth,
                      const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                     const float* __restrict__ dL_dalpha, float* __restrict__ ggrad /*[P,8] moments*/,
-                     float* __restrict__ dcolors /*[P,C_total]*/)
+                     const float* __restrict__ dL_dalpha, float* __restrict__ gacc /*[P, GROW]*/, int GROW,
+                     int MO)
 {
     using Cfg = BwdCfg<NC>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
     constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
     constexpr bool MFMA = Cfg::MFMA;
+    constexpr bool DOTM = NC >= SR_BWD_DOTM_MIN;  // dot products q = f . g on the matrix pipe
     constexpr int PPR = NCP / 4;  // 16-byte pieces per staged row
     static_assert(2 * KV <= WAVE, "at most 25 butterfly-reduced channels per pass");
     __shared__ __attribute__((aligned(16))) float4 s_rec0[WAVE];
@@ -229,6 +241,10 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     for (int d = 1; d < WAVE; d <<= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, d, WAVE));
     const uint32_t end = min(end0, beg + wave_last);
 
+#ifdef SR_BWD_PROFILE
+    unsigned long long bprof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    BP_T(tk0);
+#endif
     float T = 1.0f;
     // wave_reduce_pack leaves total k in lane bitreverse6(k); values [0, KV) belong to the first
     // Gaussian of a pair, [KV, 2 KV) to the second; inside a Gaussian: NV colours then 7 geometric
@@ -237,7 +253,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     const int sv = slot_second ? slotv - KV : slotv;
     const bool slot_col = sv < NV;
     const bool slot_ok = slotv < 2 * KV;
-    const int slot_off = slot_col ? (c0 + NM + sv) : (sv - NV);
+    const int slot_off = slot_col ? (c0 + NM + sv) : (MO + sv - NV);  // float offset inside the Gaussian's row
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
     int nslot = 0;  // Gaussians parked in the weight panel (wave-uniform)
 
@@ -245,6 +261,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     // (v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
     //  D[row = 4 (l >> 4) + reg][col = l & 15])
     auto flush_panel = [&](int count) {
+        BP_T(tf0);
         __builtin_amdgcn_wave_barrier();
         f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
         const int row = (lane >> 4) * WS + (lane & 15);
@@ -258,12 +275,18 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         for (int r = 0; r < 4; ++r) {
             const int gs = 4 * (lane >> 4) + r;
             if (gs < count) {
-                float* dst = dcolors + (size_t)s_gid[gs] * C_total + c0 + (lane & 15);
+                float* dst = gacc + (size_t)s_gid[gs] * GROW + c0 + (lane & 15);
+#if SR_BWD_ABLATE_ATOMIC
+                asm volatile("" ::"v"(dst), "v"(D0[r]), "v"(D1[r]));
+#else
                 atomicAdd(dst, D0[r]);
                 atomicAdd(dst + 16, D1[r]);
+#endif
             }
         }
         __builtin_amdgcn_wave_barrier();
+        BP_T(tf1);
+        BP_ADD(6, tf1 - tf0);
     };
 
     // chunk in flight: mask bit, id and record of list entry base + lane
@@ -284,7 +307,11 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 
 #pragma unroll 1
     for (uint32_t base = beg; base < end; base += WAVE) {
+        BP_T(tc0);
         uint64_t cand = __builtin_amdgcn_ballot_w64(reach);
+        BP_T(tc1);
+        BP_ADD(0, tc1 - tc0);
+        BP_ADD(8, 1);
         const uint32_t cur_gid = gid;
         const bool cur_reach = reach;
         if (cand != 0) {
@@ -297,6 +324,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #pragma unroll 1
         while (cand != 0) {
             // ---- stage the feature rows of the next <= FS candidates ----
+            BP_T(ts0);
             const int rank = __popcll(cand & lt_mask);
             const int ncand = min(FS, (int)__popcll(cand));
             __builtin_amdgcn_wave_barrier();
@@ -309,14 +337,16 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)s_cgid[row] * CP4 + (c0 >> 2) + pc];
             }
             __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-            for (int slot = 0; slot < ncand; slot += 2) {
-                const bool has1 = slot + 1 < ncand;  // wave-uniform
-                const int j0 = __builtin_ctzll(cand);
-                cand &= cand - 1;
-                const int j1 = has1 ? __builtin_ctzll(cand) : j0;
-                if (has1) cand &= cand - 1;
-                const int s1 = has1 ? slot + 1 : slot;
+#ifdef SR_BWD_PROFILE
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+            BP_T(ts1);
+            BP_ADD(1, ts1 - ts0);
+            BP_ADD(9, 1);
+            // One pair of candidates (list positions j0 < j1, staged rows r0, r1); qm0 / qm1 are
+            // their dot products when the matrix pipe already produced them.
+            auto process_pair = [&](int j0, int j1, bool has1, int r0, int r1, float qm0, float qm1) {
+                BP_T(tp0);
                 const float4 p0 = s_rec0[j0], q0 = s_rec1[j0];
                 const float4 p1 = s_rec0[j1], q1 = s_rec1[j1];
                 const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
@@ -326,33 +356,23 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 const float al0 = fminf(ALPHA_MAX, q0.w * G0), al1 = fminf(ALPHA_MAX, q1.w * G1);
                 const bool hit0 = (idx0 + (uint32_t)j0 < last) && pw0 <= 0.0f && al0 >= ALPHA_MIN;
                 const bool hit1 = has1 && (idx0 + (uint32_t)j1 < last) && pw1 <= 0.0f && al1 >= ALPHA_MIN;
-                if (__builtin_amdgcn_ballot_w64(hit0 || hit1) == 0) continue;
+                if (__builtin_amdgcn_ballot_w64(hit0 || hit1) == 0) return;
+                BP_T(tp1);
+                BP_ADD(2, tp1 - tp0);
+                BP_ADD(10, 1);
                 // ---- dot products q = f . g (+ depth) of both Gaussians ----
-                const float* f0 = &s_feat[slot * NCP];
-                const float* f1 = &s_feat[s1 * NCP];
-#if SR_BWD_PKDOT
-                // even/odd channel partial sums as 2-vectors: v_pk_fma_f32 does both per instruction
-                f32x2 qa0 = {p0.z * gD, 0.0f}, qa1 = {p1.z * gD, 0.0f};
+                float qd0 = qm0, qd1 = qm1;
+                if (!DOTM) {
+                    const float* f0 = &s_feat[r0 * NCP];
+                    const float* f1 = &s_feat[r1 * NCP];
+                    qd0 = p0.z * gD;
+                    qd1 = p1.z * gD;
 #pragma unroll
-                for (int k = 0; k < NC / 2; ++k) {
-                    const f32x2 gg = {g[2 * k], g[2 * k + 1]};
-                    const f32x2 x0 = {f0[2 * k], f0[2 * k + 1]}, x1 = {f1[2 * k], f1[2 * k + 1]};
-                    qa0 = __builtin_elementwise_fma(x0, gg, qa0);
-                    qa1 = __builtin_elementwise_fma(x1, gg, qa1);
+                    for (int ch = 0; ch < NC; ++ch) {
+                        qd0 += f0[ch] * g[ch];
+                        qd1 += f1[ch] * g[ch];
+                    }
                 }
-                float qd0 = qa0[0] + qa0[1], qd1 = qa1[0] + qa1[1];
-                if (NC & 1) {
-                    qd0 += f0[NC - 1] * g[NC - 1];
-                    qd1 += f1[NC - 1] * g[NC - 1];
-                }
-#else
-                float qd0 = p0.z * gD, qd1 = p1.z * gD;
-#pragma unroll
-                for (int ch = 0; ch < NC; ++ch) {
-                    qd0 += f0[ch] * g[ch];
-                    qd1 += f1[ch] * g[ch];
-                }
-#endif
                 // ---- Gaussian 0, then Gaussian 1 (sequential in T and S) ----
                 const float w0 = hit0 ? al0 * T : 0.0f;
                 float dA0 = 0.0f, dA1 = 0.0f;
@@ -396,12 +416,22 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     red[KV + NV + 5] = E;
                     red[KV + NV + 6] = w1 * gD;
                 }
+                BP_T(tp2);
+                BP_ADD(3, tp2 - tp1);
                 const float outv = wave_reduce_pack<2 * KV>(red, lane);
-                const uint32_t gi0 = s_cgid[slot], gi1 = s_cgid[s1];
+#ifdef SR_BWD_PROFILE
+                asm volatile("" ::"v"(outv));
+#endif
+                BP_T(tp3);
+                BP_ADD(4, tp3 - tp2);
+                const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];
                 const uint32_t gi = slot_second ? gi1 : gi0;
-                float* dst = slot_col ? (dcolors + (size_t)gi * C_total + slot_off)
-                                      : (ggrad + (size_t)gi * 8 + slot_off);
+                float* dst = gacc + (size_t)gi * GROW + slot_off;
+#if SR_BWD_ABLATE_ATOMIC
+                asm volatile("" ::"v"(dst), "v"(outv));
+#else
                 if (slot_ok && (has1 || !slot_second)) atomicAdd(dst, outv);
+#endif
                 if (MFMA) {
                     // park the weights (0 for pixels that miss); a pair never straddles a flush
                     s_w[lane * WS + nslot] = w0;
@@ -411,23 +441,84 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                         s_gid[nslot + 1] = gi1;
                     }
                     nslot += has1 ? 2 : 1;
+                    BP_T(tp4);
+                    BP_ADD(5, tp4 - tp3);
                     if (nslot >= GROUP - 1) {
                         flush_panel(nslot);
                         nslot = 0;
                     }
                 }
+            };
+#pragma unroll 1
+            for (int slot = 0; slot < ncand; slot += (DOTM ? 4 : 2)) {
+                // pop the next two (four) candidates; hasK are wave-uniform
+                const bool has1 = slot + 1 < ncand, has2 = DOTM && slot + 2 < ncand, has3 = DOTM && slot + 3 < ncand;
+                const int j0 = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                const int j1 = has1 ? __builtin_ctzll(cand) : j0;
+                if (has1) cand &= cand - 1;
+                const int j2 = has2 ? __builtin_ctzll(cand) : j1;
+                if (has2) cand &= cand - 1;
+                const int j3 = has3 ? __builtin_ctzll(cand) : j2;
+                if (has3) cand &= cand - 1;
+                float qm[4] = {0.f, 0.f, 0.f, 0.f};
+                BP_T(td0);
+                if (DOTM) {
+                    // q[pix][g] = sum_ch F[g][ch] G[pix][ch] + z_g g_D for the four Gaussians on the
+                    // matrix pipe: v_mfma_f32_4x4x1_16b_f32 computes D[lane 4b+j][r] += A[lane 4b+r] *
+                    // B[lane 4b+j]; with A = feature of Gaussian (lane & 3) and B = this pixel's
+                    // gradient, register r of every lane ends up holding q[own pixel][Gaussian r].
+                    const int k = lane & 3;
+                    const int srow = min(slot + k, ncand - 1);
+                    const float* fr = &s_feat[srow * NCP];
+                    const int jsel = k == 0 ? j0 : (k == 1 ? j1 : (k == 2 ? j2 : j3));
+                    const float zsel = reinterpret_cast<const float*>(&s_rec0[jsel])[2];
+                    f32x4 Q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ch = 0; ch < NC; ++ch) Q = __builtin_amdgcn_mfma_f32_4x4x1f32(fr[ch], g[ch], Q, 0, 0, 0);
+                    Q = __builtin_amdgcn_mfma_f32_4x4x1f32(zsel, gD, Q, 0, 0, 0);
+                    qm[0] = Q[0]; qm[1] = Q[1]; qm[2] = Q[2]; qm[3] = Q[3];
+#ifdef SR_BWD_PROFILE
+                    asm volatile("" ::"v"(qm[0]), "v"(qm[3]));
+#endif
+                }
+                BP_T(td1);
+                BP_ADD(7, td1 - td0);
+                process_pair(j0, j1, has1, slot, has1 ? slot + 1 : slot, qm[0], qm[1]);
+                if (has2) process_pair(j2, j3, has3, slot + 2, has3 ? slot + 3 : slot + 2, qm[2], qm[3]);
             }
         }
     }
     if (MFMA && nslot > 0) flush_panel(nslot);
+#ifdef SR_BWD_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BP_T(tk1);
+    bprof[11] = tk1 - tk0;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) atomicAdd(&g_bwd_prof[k], bprof[k]);
+    }
+#endif
 }
+
+#ifdef SR_BWD_PROFILE
+extern "C" int splatraster_debug_bwd_prof(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_prof), sizeof(unsigned long long) * 12) != hipSuccess) return 2;
+    if (reset) {
+        unsigned long long z[12] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_prof), z, sizeof(z)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#endif
+
 
 template <int NC>
 static int launch_one_bwd(const splatraster_settings& s, int c0, int first, const GeomView& g,
                           const BinView& b, const ImgView& im, const float* feat, int feat_stride,
                           const float* out_color, const float* out_depth, const float* dL_dcolor,
-                          const float* dL_ddepth, const float* dL_dalpha, float* ggrad, float* dcolors,
-                          hipStream_t stream)
+                          const float* dL_ddepth, const float* dL_dalpha, float* gacc, hipStream_t stream)
 {
     (void)g;
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
@@ -436,7 +527,7 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
     hipLaunchKernelGGL(composite_bwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
                        s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, b.ranges,
                        b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), out_color, out_depth, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth,
-                       dL_dalpha, ggrad, dcolors);
+                       dL_dalpha, gacc, gacc_row_floats(s.channels), gacc_moment_offset(s.channels));
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
@@ -444,13 +535,12 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
 int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g,
                          const BinView& b, const ImgView& im, const float* feat, int feat_stride,
                          const float* out_color, const float* out_depth, const float* dL_dcolor,
-                         const float* dL_ddepth, const float* dL_dalpha, float* ggrad, float* dcolors,
-                         hipStream_t stream)
+                         const float* dL_ddepth, const float* dL_dalpha, float* gacc, hipStream_t stream)
 {
     (void)P;
     if (R == 0) return SPLATRASTER_OK;
     const int C = s.channels;
-#define SR_BWD_ARGS g, b, im, feat, feat_stride, out_color, out_depth, dL_dcolor, dL_ddepth, dL_dalpha, ggrad, dcolors, stream
+#define SR_BWD_ARGS g, b, im, feat, feat_stride, out_color, out_depth, dL_dcolor, dL_ddepth, dL_dalpha, gacc, stream
 #define SR_BWD_CASE(N) \
     case N: return launch_one_bwd<N>(s, 0, 1, SR_BWD_ARGS);
     switch (C) {

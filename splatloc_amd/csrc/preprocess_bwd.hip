@@ -89,8 +89,8 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
                       const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
                       const float* __restrict__ proj, const float* __restrict__ campos_p,
                       const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
-                      const float4* __restrict__ rec, const float* __restrict__ ggrad,
-                      const float* __restrict__ drgb,
+                      const float4* __restrict__ rec, const float* __restrict__ gacc, int C, int GROW, int MO,
+                      float* __restrict__ dL_dcolors,
                       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                       float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D,
@@ -109,8 +109,9 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
     float dm2x = 0.f, dm2y = 0.f, dop = 0.f;
     const bool visible = radii[i] > 0;
     if (visible) {
-        const float4 g0 = reinterpret_cast<const float4*>(ggrad)[2 * i];
-        const float4 g1 = reinterpret_cast<const float4*>(ggrad)[2 * i + 1];
+        const float* mrow = gacc + (size_t)i * GROW + MO;  // moment record of this Gaussian
+        const float4 g0 = make_float4(mrow[0], mrow[1], mrow[2], mrow[3]);
+        const float4 g1 = make_float4(mrow[4], mrow[5], mrow[6], 0.f);
         const float4 con = rec[2 * (size_t)i + 1];  // conic a, b, c, opacity of the forward
         // power = -1/2 (A dx^2 + C dy^2) - B dx dy, alpha = o G:
         dm2x = -0.5f * (float)W * con.w * (con.x * g0.x + con.y * g0.y);
@@ -248,7 +249,7 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
         dmean[2] += (PM[8] * mw - PM[11] * mul1) * dm2x + (PM[9] * mw - PM[11] * mul2) * dm2y;
         if (shs) {
             sh_backward(sh_degree, M, shs + (size_t)i * 3 * M, dL_dshs + (size_t)i * 3 * M, clamped + 3 * (size_t)i,
-                        drgb + 3 * (size_t)i, px - campos_p[0], py - campos_p[1], pz - campos_p[2], dmean);
+                        gacc + (size_t)i * GROW, px - campos_p[0], py - campos_p[1], pz - campos_p[2], dmean);
         }
     } else if (shs && dL_dshs) {
         for (int k = 0; k < 3 * M; ++k) dL_dshs[(size_t)i * 3 * M + k] = 0.f;
@@ -270,19 +271,37 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
     }
 }
 
+// dL/dcolors [P, C] out of the 64-byte aligned accumulator rows: one thread per element,
+// contiguous reads inside a row, fully coalesced writes.
+__global__ void __launch_bounds__(256)
+gather_dcolors_kernel(int64_t n, int C, int GROW, const float* __restrict__ gacc, float* __restrict__ dL_dcolors)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int64_t i = e / C;
+    const int ch = (int)(e - i * C);
+    dL_dcolors[e] = gacc[i * GROW + ch];
+}
+
 int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           const float* view, const float* proj, const float* campos, const int32_t* radii,
-                          const uint8_t* clamped, const float4* rec, const float* ggrad,
-                          const float* dcolors_rgb,
+                          const uint8_t* clamped, const float4* rec, const float* gacc, int C,
+                          float* dL_dcolors,
                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
                           float* dL_drotations, float* dL_dcov3D, float* dL_dshs, hipStream_t stream)
 {
     if (P == 0) return SPLATRASTER_OK;
+    if (dL_dcolors) {
+        const int64_t n = (int64_t)P * C;
+        hipLaunchKernelGGL(gather_dcolors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, C,
+                           gacc_row_floats(C), gacc, dL_dcolors);
+        SR_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, s.image_width,
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs, means3D,
                        shs, scales, rotations, cov3D_precomp, view, proj, campos, radii, clamped, rec,
-                       ggrad, dcolors_rgb, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscales, dL_drotations,
+                       gacc, C, gacc_row_floats(C), gacc_moment_offset(C), dL_dcolors, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscales, dL_drotations,
                        dL_dcov3D, dL_dshs);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
