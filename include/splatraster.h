@@ -145,6 +145,11 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R,
                          float* dL_drotations, /* [P,4] or NULL */
                          float* dL_dcov3D,     /* [P,6] or NULL */
                          float* dL_dshs,       /* [P,M,3] or NULL */
+                         /* pose-gradient extension (no counterpart in the reference):
+                          * exact derivative w.r.t. the camera tensors, or NULL to skip */
+                         float* dL_dviewmatrix, /* [4,4] or NULL */
+                         float* dL_dprojmatrix, /* [4,4] or NULL */
+                         float* dL_dcampos,     /* [3] or NULL (non-zero only with shs) */
                          void* stream);
 
 /* ---- auxiliary entry points ---------------------------------------------------------- */

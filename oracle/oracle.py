@@ -185,16 +185,18 @@ def backward(fwd: dict, dL_dcolor, dL_ddepth=None, dL_dalpha=None, omp: bool = F
     dL_drot = np.zeros((P, 4), np.float32) if have_sr else None
     dL_dcov3D = np.zeros((P, 6), np.float32) if not have_sr else None
     dL_dshs = np.zeros((P, M, 3), np.float32) if shs is not None else None
+    dV, dPM, dcam = np.zeros(16, np.float64), np.zeros(16, np.float64), np.zeros(3, np.float64)
     lib.orc_preprocess_bwd(C.byref(cs), C.c_int32(P), _p(inp["means3D"]), _p(shs), _p(inp["scales"]),
                            _p(inp["rotations"]), _p(inp["cov3D_precomp"]), _p(inp["V"]), _p(inp["PM"]),
                            _p(inp["campos"]), _p(fwd["radii"]), _p(fwd["cov3D"]), _p(fwd["clamped"]),
                            _p(dmean2D), _p(dconic), _p(ddepth), _p(dcolors if shs is not None else None),
                            _p(dL_dmeans3D), _p(dL_dmeans2D), _p(dL_dscales), _p(dL_drot), _p(dL_dcov3D),
-                           _p(dL_dshs))
+                           _p(dL_dshs), _p(dV), _p(dPM), _p(dcam))
     return dict(dL_dmeans3D=dL_dmeans3D, dL_dmeans2D=dL_dmeans2D,
                 dL_dcolors=None if shs is not None else dcolors.astype(np.float32),
                 dL_dopacities=dopacity.astype(np.float32).reshape(P, 1), dL_dscales=dL_dscales,
                 dL_drotations=dL_drot, dL_dcov3D=dL_dcov3D, dL_dshs=dL_dshs,
+                dL_dviewmatrix=dV.reshape(4, 4), dL_dprojmatrix=dPM.reshape(4, 4), dL_dcampos=dcam,
                 _dconic=dconic, _dmean2D=dmean2D, _ddepth=ddepth, _dcolors=dcolors)
 
 

@@ -55,7 +55,7 @@ SYMBOLS = {
     "splatraster_image_bytes": (_sz, [_i32, _i32]),
     "splatraster_forward_geometry": (C.c_int, [C.POINTER(Settings), _i32] + [_vp] * 9 + [_vp, _vp, C.POINTER(_i64), _vp]),
     "splatraster_forward_render": (C.c_int, [C.POINTER(Settings), _i32, _i64] + [_vp] * 9),
-    "splatraster_backward": (C.c_int, [C.POINTER(Settings), _i32, _i64] + [_vp] * 30),
+    "splatraster_backward": (C.c_int, [C.POINTER(Settings), _i32, _i64] + [_vp] * 33),
     "splatraster_mark_visible": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_get_geometry_layout": (C.c_int, [_i32, C.POINTER(GeometryLayout)]),
     "splatraster_get_binning_layout": (C.c_int, [_i32, _i64, _i32, _i32, _i32, C.POINTER(BinningLayout)]),

@@ -345,7 +345,8 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
                          const float* out_depth, const float* out_alpha, const float* dL_dout_color,
                          const float* dL_dout_depth, const float* dL_dout_alpha, float* dL_dmeans3D,
                          float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
-                         float* dL_drotations, float* dL_dcov3D, float* dL_dshs, void* stream_)
+                         float* dL_drotations, float* dL_dcov3D, float* dL_dshs, float* dL_dviewmatrix,
+                         float* dL_dprojmatrix, float* dL_dcampos, void* stream_)
 {
     (void)bg; (void)opacities; (void)out_alpha;
     int st = check_settings(s);
@@ -379,7 +380,7 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
                                  dL_dmeans2D,
                                  dL_dopacities, cov3D_precomp ? nullptr : dL_dscales,
                                  cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr,
-                                 dL_dshs, stream);
+                                 dL_dshs, dL_dviewmatrix, dL_dprojmatrix, dL_dcampos, stream);
 }
 
 int splatraster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,

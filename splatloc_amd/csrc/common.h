@@ -85,7 +85,9 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float*
                           const uint8_t* clamped, const float4* rec, const float* gacc, int C,
                           float* dL_dcolors,
                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
-                          float* dL_drotations, float* dL_dcov3D, float* dL_dshs, hipStream_t stream);
+                          float* dL_drotations, float* dL_dcov3D, float* dL_dshs,
+                          float* dL_dview /*[16] or null*/, float* dL_dproj, float* dL_dcampos,
+                          hipStream_t stream);
 int launch_mark_visible(int32_t P, const float* means3D, const float* view, uint8_t* present,
                         hipStream_t stream);
 

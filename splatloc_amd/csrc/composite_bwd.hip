@@ -63,102 +63,6 @@ struct BwdCfg {
     static constexpr int WS = 17;              // LDS row stride of the weight panel [64 pix][GROUP]
 };
 
-// ---- DPP helpers (wave64 = 4 rows of 16 lanes) -----------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_get(float v)
-{
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
-
-// ---- packed butterfly reduction -----------------------------------------------------------
-// Reduces K per-lane values over the 64 lanes of a wave and leaves total k in lane
-// bitreverse6(k): every stage halves the lane span of each value AND merges two registers
-// into one, so the whole reduction costs ~2.2 VALU per value instead of 6 DPP adds + a
-// readlane/select gather per value.
-//   stage 1 (lane bit 5): v_permlane32_swap + add      (2 instr per pair)
-//   stage 2 (lane bit 4): v_permlane16_swap + add      (2 instr per pair)
-//   stage 3 (lane bit 3): select / select / add row_ror:8
-//   stage 4 (lane bit 2): select / select / two bank-masked row_ror movs / add
-//   stage 5 (lane bit 1): select / select / add quad_perm[2,3,0,1]
-//   stage 6 (lane bit 0): select / select / add quad_perm[1,0,3,2]
-__device__ __forceinline__ float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ unsigned as_u(float f) { return __builtin_bit_cast(unsigned, f); }
-
-template <int CTRL, int BANK_MASK>
-__device__ __forceinline__ float dpp_mov_old(float old, float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
-                                                                 __builtin_bit_cast(int, v), CTRL, 0xf,
-                                                                 BANK_MASK, false));
-}
-
-template <int K>
-__device__ __forceinline__ float wave_reduce_pack(const float (&v)[K], int lane)
-{
-    static_assert(K >= 1 && K <= 64, "at most 64 values per wave");
-    constexpr int N1 = (K + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2,
-                  N5 = (N4 + 1) / 2, N6 = (N5 + 1) / 2;
-    static_assert(N6 == 1, "");
-    float a[N1];
-#pragma unroll
-    for (int m = 0; m < N1; ++m) {
-        const float x = v[2 * m];
-        const float y = (2 * m + 1 < K) ? v[2 * m + 1] : 0.0f;
-        const auto r = __builtin_amdgcn_permlane32_swap(as_u(x), as_u(y), false, false);
-        a[m] = as_f(r[0]) + as_f(r[1]);
-    }
-    float b[N2];
-#pragma unroll
-    for (int m = 0; m < N2; ++m) {
-        const float x = a[2 * m];
-        const float y = (2 * m + 1 < N1) ? a[2 * m + 1] : 0.0f;
-        const auto r = __builtin_amdgcn_permlane16_swap(as_u(x), as_u(y), false, false);
-        b[m] = as_f(r[0]) + as_f(r[1]);
-    }
-    float c[N3];
-    {
-        const bool lo = (lane & 8) == 0;
-#pragma unroll
-        for (int m = 0; m < N3; ++m) {
-            const float x = b[2 * m];
-            const float y = (2 * m + 1 < N2) ? b[2 * m + 1] : 0.0f;
-            const float keep = lo ? x : y, send = lo ? y : x;
-            c[m] = keep + dpp_get<0x128, 0xf>(send);  // row_ror:8
-        }
-    }
-    float d[N4];
-    {
-        const bool lo = (lane & 4) == 0;
-#pragma unroll
-        for (int m = 0; m < N4; ++m) {
-            const float x = c[2 * m];
-            const float y = (2 * m + 1 < N3) ? c[2 * m + 1] : 0.0f;
-            const float keep = lo ? x : y, send = lo ? y : x;
-            // partner = lane ^ 4: banks 0,2 read lane+4 (row_ror:12), banks 1,3 read lane-4 (row_ror:4)
-            float t = dpp_mov_old<0x12C, 0x5>(0.0f, send);
-            t = dpp_mov_old<0x124, 0xA>(t, send);
-            d[m] = keep + t;
-        }
-    }
-    float e[N5];
-    {
-        const bool lo = (lane & 2) == 0;
-#pragma unroll
-        for (int m = 0; m < N5; ++m) {
-            const float x = d[2 * m];
-            const float y = (2 * m + 1 < N4) ? d[2 * m + 1] : 0.0f;
-            const float keep = lo ? x : y, send = lo ? y : x;
-            e[m] = keep + dpp_get<0x4E, 0xf>(send);  // quad_perm [2,3,0,1]
-        }
-    }
-    const bool lo1 = (lane & 1) == 0;
-    const float x6 = e[0];
-    const float y6 = (N5 > 1) ? e[N5 > 1 ? 1 : 0] : 0.0f;
-    const float keep6 = lo1 ? x6 : y6, send6 = lo1 ? y6 : x6;
-    return keep6 + dpp_get<0xB1, 0xf>(send6);  // quad_perm [1,0,3,2]
-}
-
 template <int NC>
 __global__ void __launch_bounds__(WAVE, SR_BWD_MINW)
 composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass, int tiles,

@@ -9,7 +9,7 @@
 // factors (conic, opacity, 0.5 W, 0.5 H), and chains through the projection.  Plus the forward
 // inputs; writes every gradient tensor once.
 // HBM-bound: ~100 B read, ~70 B written per Gaussian.
-#include "common.h"
+#include "composite_common.h"
 
 namespace sr {
 
@@ -82,6 +82,7 @@ __device__ void sh_backward(int deg, int M, const float* sh, float* dsh, const u
     dmean[2] += (ddir[2] - z * dot) / len;
 }
 
+template <bool POSE>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float mod, int sh_degree, int M,
                       const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -94,10 +95,15 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
                       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
                       float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D,
-                      float* __restrict__ dL_dshs)
+                      float* __restrict__ dL_dshs, float* __restrict__ dL_dview, float* __restrict__ dL_dproj,
+                      float* __restrict__ dL_dcampos)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    // pose partials of this Gaussian: dV[4c + r] (r < 3), dPM[4c + k] (k = 0, 1, 3), dcampos
+    float pose[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) pose[k] = 0.f;
+    if (i < P) {
     float V[16], PM[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = view[k]; PM[k] = proj[k]; }
@@ -238,6 +244,28 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
 #pragma unroll
         for (int k = 0; k < 3; ++k)  // Wv^T [dtx dty dtz]: Wv[r][k] = V[4k + r]
             dmean[k] += V[4 * k + 0] * dtx + V[4 * k + 1] * dty + V[4 * k + 2] * (dtz + gdepth);
+        if (POSE) {
+            // t = Wv p + trans (V[4c + r] multiplies p[c] into t[r]); cov2D = A Sigma3 A^T with
+            // A = J Wv: dL/dA = 2 G2 A Sigma3, dL/dWv = J^T dL/dA
+            const float dt[3] = {dtx, dty, dtz + gdepth};
+            const float pp[3] = {px, py, pz};
+            float dA0[3], dA1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dA0[k] = 2.f * (G2[0][0] * SA0[k] + G2[0][1] * SA1[k]);
+                dA1[k] = 2.f * (G2[1][0] * SA0[k] + G2[1][1] * SA1[k]);
+            }
+            // J = [[J00, 0, J02], [0, J11, J12]]
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pose[3 * c + 0] = dt[0] * pp[c] + J00 * dA0[c];
+                pose[3 * c + 1] = dt[1] * pp[c] + J11 * dA1[c];
+                pose[3 * c + 2] = dt[2] * pp[c] + J02 * dA0[c] + J12 * dA1[c];
+            }
+            pose[9] = dt[0];
+            pose[10] = dt[1];
+            pose[11] = dt[2];
+        }
         // NDC mean2D -> mean3D
         const float hx = PM[0] * px + PM[4] * py + PM[8] * pz + PM[12];
         const float hy = PM[1] * px + PM[5] * py + PM[9] * pz + PM[13];
@@ -247,9 +275,23 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
         dmean[0] += (PM[0] * mw - PM[3] * mul1) * dm2x + (PM[1] * mw - PM[3] * mul2) * dm2y;
         dmean[1] += (PM[4] * mw - PM[7] * mul1) * dm2x + (PM[5] * mw - PM[7] * mul2) * dm2y;
         dmean[2] += (PM[8] * mw - PM[11] * mul1) * dm2x + (PM[9] * mw - PM[11] * mul2) * dm2y;
+        if (POSE) {
+            const float dh[3] = {dm2x * mw, dm2y * mw, -(mul1 * dm2x + mul2 * dm2y)};  // d/d(hx, hy, hw)
+            const float p4[4] = {px, py, pz, 1.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) pose[12 + 3 * c + j] = dh[j] * p4[c];
+        }
         if (shs) {
+            const float sm0 = dmean[0], sm1 = dmean[1], sm2 = dmean[2];
             sh_backward(sh_degree, M, shs + (size_t)i * 3 * M, dL_dshs + (size_t)i * 3 * M, clamped + 3 * (size_t)i,
                         gacc + (size_t)i * GROW, px - campos_p[0], py - campos_p[1], pz - campos_p[2], dmean);
+            if (POSE) {  // direction = normalize(p - campos)
+                pose[24] = -(dmean[0] - sm0);
+                pose[25] = -(dmean[1] - sm1);
+                pose[26] = -(dmean[2] - sm2);
+            }
         }
     } else if (shs && dL_dshs) {
         for (int k = 0; k < 3 * M; ++k) dL_dshs[(size_t)i * 3 * M + k] = 0.f;
@@ -268,6 +310,29 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
     if (dL_dcov3D) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = dcov[k];
+    }
+    }  // i < P
+    if (POSE) {
+        // 27 partials summed over the wave with the packed butterfly, then over the block in
+        // LDS, then one atomic per value per block
+        __shared__ float s_pose[4][32];
+        const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+        const float tot = wave_reduce_pack<27>(pose, lane);
+        const int slot = (int)(__brev((unsigned)lane) >> 26);
+        if (slot < 27) s_pose[w][slot] = tot;
+        __syncthreads();
+        if (threadIdx.x < 27) {
+            const int k = threadIdx.x;
+            const float v = s_pose[0][k] + s_pose[1][k] + s_pose[2][k] + s_pose[3][k];
+            if (k < 12) {
+                atomicAdd(&dL_dview[4 * (k / 3) + (k % 3)], v);
+            } else if (k < 24) {
+                const int kk = k - 12, c = kk / 3, j = kk % 3;
+                atomicAdd(&dL_dproj[4 * c + (j == 2 ? 3 : j)], v);
+            } else if (dL_dcampos) {
+                atomicAdd(&dL_dcampos[k - 24], v);
+            }
+        }
     }
 }
 
@@ -289,7 +354,8 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float*
                           const uint8_t* clamped, const float4* rec, const float* gacc, int C,
                           float* dL_dcolors,
                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
-                          float* dL_drotations, float* dL_dcov3D, float* dL_dshs, hipStream_t stream)
+                          float* dL_drotations, float* dL_dcov3D, float* dL_dshs, float* dL_dview,
+                          float* dL_dproj, float* dL_dcampos, hipStream_t stream)
 {
     if (P == 0) return SPLATRASTER_OK;
     if (dL_dcolors) {
@@ -298,11 +364,22 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float*
                            gacc_row_floats(C), gacc, dL_dcolors);
         SR_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, s.image_width,
-                       s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs, means3D,
-                       shs, scales, rotations, cov3D_precomp, view, proj, campos, radii, clamped, rec,
-                       gacc, C, gacc_row_floats(C), gacc_moment_offset(C), dL_dcolors, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscales, dL_drotations,
-                       dL_dcov3D, dL_dshs);
+    const bool pose = dL_dview && dL_dproj;
+    if (pose) {
+        SR_HIP_CHECK(hipMemsetAsync(dL_dview, 0, 16 * sizeof(float), stream));
+        SR_HIP_CHECK(hipMemsetAsync(dL_dproj, 0, 16 * sizeof(float), stream));
+        if (dL_dcampos) SR_HIP_CHECK(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), stream));
+    }
+#define SR_PBWD_ARGS                                                                                              \
+    P, s.image_width, s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs, means3D,   \
+        shs, scales, rotations, cov3D_precomp, view, proj, campos, radii, clamped, rec, gacc, C, gacc_row_floats(C), \
+        gacc_moment_offset(C), dL_dcolors, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscales, dL_drotations,       \
+        dL_dcov3D, dL_dshs, dL_dview, dL_dproj, dL_dcampos
+    if (pose)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, SR_PBWD_ARGS);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, stream, SR_PBWD_ARGS);
+#undef SR_PBWD_ARGS
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

@@ -65,14 +65,18 @@ def _require_gpu(t: torch.Tensor, name: str) -> None:
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    # the camera tensors are passed as explicit autograd inputs as well, so that a pose
+    # parametrisation upstream of viewmatrix / projmatrix / campos receives gradients
+    # (pose-gradient extension; the reference has no such path)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, raster_settings.viewmatrix,
+                                     raster_settings.projmatrix, raster_settings.campos)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings):
+                raster_settings: GaussianRasterizationSettings, viewmatrix=None, projmatrix=None, campos=None):
         lib = _native.load()
         _require_gpu(means3D, "means3D")
         dev = means3D.device
@@ -88,9 +92,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         rot = _prep(rotations, dev)
         cov = _prep(cov3Ds_precomp, dev)
         bg = _prep(rs.bg, dev)
-        view = _prep(rs.viewmatrix, dev)
-        proj = _prep(rs.projmatrix, dev)
-        campos = _prep(rs.campos, dev)
+        view = _prep(rs.viewmatrix if viewmatrix is None else viewmatrix, dev)
+        proj = _prep(rs.projmatrix if projmatrix is None else projmatrix, dev)
+        campos = _prep(rs.campos if campos is None else campos, dev)
 
         if shs is not None:
             Cn, M = 3, int(shs.shape[1])
@@ -157,15 +161,21 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_rot = torch.empty((P, 4), **f32) if rot is not None else None
         d_cov = torch.empty((P, 6), **f32) if cov is not None else None
         d_sh = torch.empty(tuple(shs.shape), **f32) if shs is not None else None
+        want_pose = any(ctx.needs_input_grad[9:12]) if len(ctx.needs_input_grad) >= 12 else False
+        d_view = torch.empty((4, 4), **f32) if want_pose else None
+        d_proj = torch.empty((4, 4), **f32) if want_pose else None
+        d_cam = torch.zeros((3,), **f32) if (want_pose and campos is not None) else None
         with torch.cuda.device(dev):
             _native.check(lib.splatraster_backward(
                 C.byref(st), P, ctx.num_rendered, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(opa),
                 _ptr(sca), _ptr(rot), _ptr(cov), _ptr(view), _ptr(proj), _ptr(campos), _ptr(radii),
                 _ptr(geom), _ptr(binning), _ptr(img), _ptr(color), _ptr(depth), _ptr(alpha), _ptr(g_color),
                 _ptr(g_depth), _ptr(g_alpha), _ptr(d_m3), _ptr(d_m2), _ptr(d_col), _ptr(d_op), _ptr(d_sca),
-                _ptr(d_rot), _ptr(d_cov), _ptr(d_sh), _stream(dev)), "backward")
-        # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings)
-        return d_m3, d_m2, d_sh, d_col, d_op, d_sca, d_rot, d_cov, None
+                _ptr(d_rot), _ptr(d_cov), _ptr(d_sh), _ptr(d_view), _ptr(d_proj), _ptr(d_cam), _stream(dev)),
+                "backward")
+        # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings,
+        #  viewmatrix, projmatrix, campos)
+        return d_m3, d_m2, d_sh, d_col, d_op, d_sca, d_rot, d_cov, None, d_view, d_proj, d_cam
 
 
 class GaussianRasterizer(nn.Module):

@@ -1,0 +1,107 @@
+"""Pose-gradient extension on the GPU: dL/dviewmatrix, dL/dprojmatrix, dL/dcampos vs the oracle
+(itself checked against fp64 autograd in tests/test_oracle_autograd.py), and a pose refinement
+loop in the shape the reference's utils/optimization_utils.py helpers are meant for
+(axis-angle + translation -> 4x4 transform -> viewmatrix -> rasterizer)."""
+import numpy as np
+import pytest
+import torch
+
+from splatloc_amd.camera import PinholeCamera
+from splatloc_amd.synthetic import make_scene
+from tests.helpers import assert_grad_close, oracle_backward, oracle_forward
+
+pytestmark = pytest.mark.gpu
+
+
+def _axis_angle_to_matrix(w):
+    """Rodrigues, same formula as utils/optimization_utils.py:5-22 (own restatement)."""
+    theta = torch.linalg.norm(w) + 1e-12
+    k = w / theta
+    zero = torch.zeros((), dtype=w.dtype, device=w.device)
+    K = torch.stack([torch.stack([zero, -k[2], k[1]]), torch.stack([k[2], zero, -k[0]]),
+                     torch.stack([-k[1], k[0], zero])])
+    return torch.eye(3, dtype=w.dtype, device=w.device) + torch.sin(theta) * K + (1 - torch.cos(theta)) * (K @ K)
+
+
+def _camera_tensors(cam, R, t):
+    """world_view_transform / full_proj_transform / camera_center as differentiable functions of (R, t)
+    (utils/camera_utils.py:129-139 semantics)."""
+    dev = R.device
+    Rt = torch.eye(4, device=dev)
+    Rt = torch.cat([torch.cat([R, t[:, None]], dim=1), torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=dev)], dim=0)
+    view = Rt.transpose(0, 1)
+    proj = view @ cam.projection_matrix.to(dev)
+    campos = torch.linalg.inv(view)[3, :3]
+    return view, proj, campos
+
+
+@pytest.mark.parametrize("use_sh", [False, True])
+def test_pose_gradients_match_oracle(use_sh):
+    from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    C = 3 if use_sh else 4
+    sc = make_scene(3000, 256, 192, C, 70 + int(use_sh), scale_median=0.03)
+    ang = 0.15
+    R = torch.tensor([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], dtype=torch.float32)
+    sc.camera = PinholeCamera(256, 192, 128.0, 128.0, 127.5 + 0.4, 95.5 - 0.2, R, torch.tensor([0.05, -0.03, 0.2]))
+    g = torch.Generator().manual_seed(3)
+    shs = 0.5 * torch.randn(3000, 16, 3, generator=g) if use_sh else None
+    kw = dict(sh_degree=2, colors_precomp=None, shs=shs.numpy()) if use_sh else {}
+    f = oracle_forward(sc, **kw)
+    b = oracle_backward(f, sc)
+    cam = sc.camera
+    view = cam.world_view_transform.to(dev).clone().requires_grad_(True)
+    proj = cam.full_proj_transform.to(dev).clone().requires_grad_(True)
+    campos = cam.camera_center.to(dev).clone().requires_grad_(True)
+    rs = GaussianRasterizationSettings(192, 256, cam.tanfovx, cam.tanfovy, sc.bg.to(dev), 1.0, view, proj,
+                                       2 if use_sh else 0, campos, False, False)
+    t = lambda x: x.to(dev)  # noqa: E731
+    color, depth, alpha, radii = GaussianRasterizer(raster_settings=rs)(
+        means3D=t(sc.means3D), means2D=torch.zeros(3000, 3, device=dev), shs=t(shs) if use_sh else None,
+        colors_precomp=None if use_sh else t(sc.features), opacities=t(sc.opacities), scales=t(sc.scales),
+        rotations=t(sc.rotations), cov3D_precomp=None)
+    ((color * t(sc.dL_dcolor)).sum() + (depth * t(sc.dL_ddepth)).sum() + (alpha * t(sc.dL_dalpha)).sum()).backward()
+    assert_grad_close("dL_dviewmatrix", view.grad.cpu().numpy(), b["dL_dviewmatrix"], rtol=3e-3, atol_scale=3e-4)
+    assert_grad_close("dL_dprojmatrix", proj.grad.cpu().numpy(), b["dL_dprojmatrix"], rtol=3e-3, atol_scale=3e-4)
+    if use_sh:
+        assert_grad_close("dL_dcampos", campos.grad.cpu().numpy(), b["dL_dcampos"], rtol=3e-3, atol_scale=3e-4)
+        assert float(np.abs(b["dL_dcampos"]).max()) > 0
+    else:
+        assert campos.grad is None or float(campos.grad.abs().max()) == 0.0
+
+
+def test_pose_refinement_converges():
+    """Recover a perturbed camera pose by gradient descent on a photometric + depth loss."""
+    from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    sc = make_scene(6000, 256, 192, 3, 80, scale_median=0.05).to(dev)
+    cam = PinholeCamera(256, 192, 128.0, 128.0, 127.5, 95.5)
+
+    def render(w, tr):
+        view, proj, campos = _camera_tensors(cam, _axis_angle_to_matrix(w), tr)
+        rs = GaussianRasterizationSettings(192, 256, cam.tanfovx, cam.tanfovy, sc.bg, 1.0, view, proj, 0, campos,
+                                           False, False)
+        return GaussianRasterizer(raster_settings=rs)(
+            means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), shs=None, colors_precomp=sc.features,
+            opacities=sc.opacities, scales=sc.scales, rotations=sc.rotations, cov3D_precomp=None)
+
+    w_true = torch.tensor([0.02, -0.03, 0.01], device=dev)
+    t_true = torch.tensor([0.03, -0.02, 0.05], device=dev)
+    with torch.no_grad():
+        tgt_c, tgt_d, _, _ = render(w_true, t_true)
+    w = torch.tensor([1e-4, 1e-4, 1e-4], device=dev, requires_grad=True)
+    tr = torch.zeros(3, device=dev, requires_grad=True)
+    opt = torch.optim.Adam([{"params": [w], "lr": 2e-3}, {"params": [tr], "lr": 3e-3}])
+    err0 = float((w.detach() - w_true).norm() + (tr.detach() - t_true).norm())
+    first = None
+    for it in range(150):
+        color, depth, alpha, _ = render(w, tr)
+        loss = (color - tgt_c).abs().mean() + 0.2 * (depth - tgt_d).abs().mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        assert torch.isfinite(w.grad).all() and torch.isfinite(tr.grad).all()
+        opt.step()
+        first = float(loss) if first is None else first
+    err1 = float((w.detach() - w_true).norm() + (tr.detach() - t_true).norm())
+    assert float(loss) < 0.35 * first, (first, float(loss))
+    assert err1 < 0.35 * err0, (err0, err1)

@@ -50,14 +50,14 @@ def _run(P, W, H, C, seed, use_sh=False, deg=0, use_cov=False, mod=1.0, bgval=0.
     col, sh_t = (None, leaf(shs)) if use_sh else (leaf(sc.features), None)
     sca, rot, cv = (None, None, leaf(cov)) if use_cov else (leaf(sc.scales), leaf(sc.rotations), None)
     probe = torch.zeros(P, 2, dtype=d, requires_grad=True)
+    Vm, PMm, cpos = leaf(cam.world_view_transform), leaf(cam.full_proj_transform), leaf(cam.camera_center)
     color, depth, alpha, radii = render_dense(
-        H, W, cam.tanfovx, cam.tanfovy, bg, m3, op, cam.world_view_transform.to(d), cam.full_proj_transform.to(d),
-        cam.camera_center.to(d), colors_precomp=col, shs=sh_t, sh_degree=deg, scales=sca, rotations=rot,
-        cov3D_precomp=cv, scale_modifier=mod, means2D_probe=probe)
+        H, W, cam.tanfovx, cam.tanfovy, bg, m3, op, Vm, PMm, cpos, colors_precomp=col, shs=sh_t, sh_degree=deg,
+        scales=sca, rotations=rot, cov3D_precomp=cv, scale_modifier=mod, means2D_probe=probe)
     loss = (color * dcol.to(d)).sum() + (depth * ddep.to(d)).sum() + (alpha * dalp.to(d)).sum()
     loss.backward()
     return sc, f, b, dict(color=color, depth=depth, alpha=alpha, radii=radii, m3=m3, op=op, col=col, sh=sh_t,
-                          sca=sca, rot=rot, cov=cv, probe=probe)
+                          sca=sca, rot=rot, cov=cv, probe=probe, V=Vm, PM=PMm, campos=cpos)
 
 
 def _close(name, got, ref, rtol=2e-4, atol_scale=2e-5):
@@ -94,6 +94,13 @@ def test_oracle_forward_and_backward_match_autograd(cfg):
     else:
         _close("dL_dscales", b["dL_dscales"], t["sca"].grad.numpy())
         _close("dL_drotations", b["dL_drotations"], t["rot"].grad.numpy())
+    # pose-gradient extension: exact derivative w.r.t. the camera tensors
+    _close("dL_dviewmatrix", b["dL_dviewmatrix"], t["V"].grad.numpy(), rtol=5e-4, atol_scale=5e-5)
+    _close("dL_dprojmatrix", b["dL_dprojmatrix"], t["PM"].grad.numpy(), rtol=5e-4, atol_scale=5e-5)
+    if t["sh"] is not None:
+        _close("dL_dcampos", b["dL_dcampos"], t["campos"].grad.numpy(), rtol=5e-4, atol_scale=5e-5)
+    else:
+        assert (b["dL_dcampos"] == 0).all()
 
 
 def test_oracle_omp_equals_single_thread():
