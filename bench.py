@@ -124,7 +124,10 @@ def main():
         if not args.fwd_only:
             torch.autograd.backward((color, depth, alpha), g_out)
             if world > 1:
-                allreduce_grads([p.grad for p in params])
+                # parameter gradients only: the viewspace (means2D) gradient feeds per-view
+                # densification statistics, which replicas sync through their own accumulators
+                # (frame_parallel.sync_densification_stats), not through a gradient sum
+                allreduce_grads([p.grad for p in params if p is not means2D])
 
     def barrier():
         if world > 1:
