@@ -43,6 +43,22 @@ __device__ __forceinline__ void swap_halves(float& x, float& y)
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
 }
 
+// acc += A * B with v_mfma_f32_32x32x2_f32, accumulating IN PLACE.  Through the builtin, hipcc
+// (ROCm 7.2) put the result of the MFMA inside the wave-uniform `if (any hit)` into a different
+// register block than the accumulator and merged the two paths with s_nop 10 + 32 v_mov per
+// candidate pair, exposing the whole 64-cycle MFMA latency; the tied "+v" operand forbids that.
+// Hazards the compiler does not see inside asm: VALU-written A/B -> MFMA read (s_nop 1 here);
+// MFMA D -> VALU read is covered once by mfma_drain() before the epilogue; D -> next MFMA as C
+// needs no wait states.
+__device__ __forceinline__ void mfma_acc_32x32x2(f32x16& acc, float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_drain(f32x16& x, f32x16& y)
+{
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(x), "+v"(y));
+}
+
 template <int NC>
 struct FwdCfg {
     static constexpr bool MFMA = NC >= 32;
@@ -169,10 +185,9 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 T = hit1 ? tT1 : T1;
                 const uint32_t idx = base - beg;
                 last = hit1 ? idx + (uint32_t)j1 + 1u : (hit0 ? idx + (uint32_t)j0 + 1u : last);
-                if (__builtin_amdgcn_ballot_w64(hit0 || hit1) == 0) {
-                    if (__builtin_amdgcn_ballot_w64(active) == 0) { wave_done = true; break; }
-                    continue;
-                }
+                // No "skip if nobody hit" branch here on purpose: with the reach masks ~95 % of the
+                // candidates hit, and a conditional around the accumulation makes hipcc merge the two
+                // paths by copying all 32 accumulator registers per pair (seen in the .s).
                 const int s1 = has1 ? slot + 1 : slot;
                 const float* f0 = &s_feat[slot * NCP + NM];
                 const float* f1 = &s_feat[s1 * NCP + NM];
@@ -183,15 +198,17 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                     const float a = s_feat[((lane >> 5) ? s1 : slot) * NCP + (lane & 31)];  // A[i = ch][k = g]
                     float b0 = w0, b1 = w1;
                     swap_halves(b0, b1);  // b0 -> B for pixels 0-31, b1 -> B for pixels 32-63
-                    accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, accA, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, accB, 0, 0, 0);
+                    mfma_acc_32x32x2(accA, a, b0);
+                    mfma_acc_32x32x2(accB, a, b1);
                 }
+                if (__builtin_amdgcn_ballot_w64(active) == 0) { wave_done = true; break; }
             }
         }
     }
 
     const size_t plane = (size_t)H * W;
     if (MFMA) {
+        mfma_drain(accA, accB);
         // D[ch][pix]: lane l, register r holds channel (r&3) + 8 (r>>2) + 4 (l>>5) of wave pixel
         // (l & 31) [accA] / 32 + (l & 31) [accB]; T of those pixels comes from lanes (l&31), 32+(l&31).
         float TA = T, TB = T;
