@@ -27,12 +27,19 @@
 //     runs on the matrix pipe with v_mfma_f32_16x16x4_f32 — exact fp32 (k-ordered fmaf chain).
 #include "composite_common.h"
 
+#ifndef SR_STAGE_UNROLL
+#define SR_STAGE_UNROLL 2  // gather iterations in flight together while staging feature rows
+#endif
+
 #ifndef SR_BWD_MINW
-#define SR_BWD_MINW 3  // waves per SIMD the register allocator must allow (4 spills at C = 35: 1.98 vs 1.52 ms)
+#define SR_BWD_MINW 4  // waves per SIMD the register allocator must allow (A/B on S2: 1.035 vs 1.07 ms at 3)
 #endif
 
 #ifndef SR_BWD_ABLATE_ATOMIC
 #define SR_BWD_ABLATE_ATOMIC 0  // perf experiment only: drop the float atomics (wrong results)
+#endif
+#ifndef SR_BWD_SKIP_BRANCH
+#define SR_BWD_SKIP_BRANCH 0  // 1 = skip a candidate pair that no pixel of the quadrant hits (A/B: slower, more VGPRs)
 #endif
 #ifndef SR_BWD_DOTM_MIN
 #define SR_BWD_DOTM_MIN 8  // channels from which the 4x4x1 MFMA dot product is used
@@ -235,7 +242,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid;
             __builtin_amdgcn_wave_barrier();
             // 16-byte pieces of the 16-byte-aligned padded rows
-#pragma unroll 2
+#pragma unroll SR_STAGE_UNROLL
             for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
                 reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)s_cgid[row] * CP4 + (c0 >> 2) + pc];
@@ -260,7 +267,9 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 const float al0 = fminf(ALPHA_MAX, q0.w * G0), al1 = fminf(ALPHA_MAX, q1.w * G1);
                 const bool hit0 = (idx0 + (uint32_t)j0 < last) && pw0 <= 0.0f && al0 >= ALPHA_MIN;
                 const bool hit1 = has1 && (idx0 + (uint32_t)j1 < last) && pw1 <= 0.0f && al1 >= ALPHA_MIN;
+#if SR_BWD_SKIP_BRANCH
                 if (__builtin_amdgcn_ballot_w64(hit0 || hit1) == 0) return;
+#endif
                 BP_T(tp1);
                 BP_ADD(2, tp1 - tp0);
                 BP_ADD(10, 1);

@@ -24,6 +24,10 @@
 // the two weight registers of the pair after ONE v_permlane32_swap.
 #include "composite_common.h"
 
+#ifndef SR_STAGE_UNROLL
+#define SR_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2: 1: 0.429, 2: 0.456, 3: 0.416, 5: 0.478 ms)
+#endif
+
 #ifndef SR_FWD_MINW
 #define SR_FWD_MINW 4  // waves per SIMD the register allocator must allow
 #endif
@@ -148,7 +152,7 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
             if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid;
             __builtin_amdgcn_wave_barrier();
             // 16-byte pieces of the 16-byte-aligned padded rows
-#pragma unroll 2
+#pragma unroll SR_STAGE_UNROLL
             for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
                 reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)s_cgid[row] * CP4 + (c0 >> 2) + pc];
