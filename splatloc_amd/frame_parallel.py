@@ -27,17 +27,59 @@ def shard_views(view_ids: Sequence[int], rank: int, world_size: int) -> List[int
     return [v for i, v in enumerate(view_ids) if i % world_size == rank]
 
 
-def allreduce_grads(tensors: Iterable[Optional[torch.Tensor]], group=None, bucket_bytes: int = 256 << 20):
-    """SUM-all-reduce gradient tensors in place, coalesced into large flat buckets.
+def _shared_spans(ts: List[torch.Tensor]):
+    """Find tensors that are dense views carved out of ONE allocation (the rasterizer's
+    backward returns all parameter gradients of a frame that way) and return
+    (spans, rest): `spans` are flat tensors aliasing [lowest, highest) of each such
+    allocation — reducing a span reduces every member in place, with no staging copy —
+    and `rest` are the tensors that are not part of any span.
 
+    Members must be contiguous, non-overlapping, and separated by less than 16 bytes
+    (alignment padding): anything else in between is not ours to sum.
+    """
+    groups = {}
+    for t in ts:
+        key = (t.untyped_storage().data_ptr(), t.dtype, t.device)
+        groups.setdefault(key, []).append(t)
+    spans, rest = [], []
+    for (_, dtype, device), members in groups.items():
+        if len(members) < 2 or not all(m.is_contiguous() and m.numel() for m in members):
+            rest.extend(members)
+            continue
+        members = sorted(members, key=lambda m: m.storage_offset())
+        esize = members[0].element_size()
+        ok = True
+        for a, b in zip(members[:-1], members[1:]):
+            gap = b.storage_offset() - (a.storage_offset() + a.numel())
+            if gap < 0 or gap * esize >= 16:
+                ok = False
+                break
+        if not ok:
+            rest.extend(members)
+            continue
+        lo = members[0].storage_offset()
+        hi = members[-1].storage_offset() + members[-1].numel()
+        span = torch.empty(0, dtype=dtype, device=device).set_(members[0].untyped_storage(), lo, (hi - lo,), (1,))
+        spans.append(span)
+    return spans, rest
+
+
+def allreduce_grads(tensors: Iterable[Optional[torch.Tensor]], group=None, bucket_bytes: int = 256 << 20):
+    """SUM-all-reduce gradient tensors in place, as few large buffers.
+
+    Gradients that already live side by side in one allocation (see _shared_spans) are
+    reduced where they are, as one call; the rest are coalesced into flat buckets.
     Tensors that are None are skipped (a rank whose views saw no Gaussian still has dense
     zero grads from the rasterizer, so shapes agree across ranks).
     """
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    ts = [t for t in tensors if t is not None]
+    with torch.no_grad():
+        spans, ts = _shared_spans([t for t in tensors if t is not None])
     bucket, size = [], 0
     pending = []
+    for span in spans:
+        pending.append((dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group, async_op=True), None, None))
 
     def flush():
         nonlocal bucket, size

@@ -153,14 +153,40 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_alpha = _prep(grad_alpha, dev) if grad_alpha is not None else None
 
         f32 = dict(dtype=torch.float32, device=dev)
-        d_m3 = torch.empty((P, 3), **f32)
+        # every parameter gradient of the frame is carved out of ONE allocation (16-byte
+        # aligned pieces), so a frame-parallel replica can all-reduce them where they are as a
+        # single RCCL call (frame_parallel.allreduce_grads); the viewspace gradient is per-view
+        # state and stays outside
+        shapes = {"m3": (P, 3), "op": (P, 1)}
+        if col is not None:
+            shapes["col"] = (P, Cn)
+        if sca is not None:
+            shapes["sca"] = (P, 3)
+        if rot is not None:
+            shapes["rot"] = (P, 4)
+        if cov is not None:
+            shapes["cov"] = (P, 6)
+        if shs is not None:
+            shapes["sh"] = tuple(shs.shape)
+        offs, total = {}, 0
+        for k, shp in shapes.items():
+            offs[k] = total
+            n = 1
+            for d in shp:
+                n *= int(d)
+            total += (n + 3) & ~3
+        flat = torch.empty((total,), **f32)
+
+        def piece(k):
+            if k not in shapes:
+                return None
+            n = 1
+            for d in shapes[k]:
+                n *= int(d)
+            return flat[offs[k]:offs[k] + n].view(shapes[k])
+
+        d_m3, d_op, d_col, d_sca, d_rot, d_cov, d_sh = (piece(k) for k in ("m3", "op", "col", "sca", "rot", "cov", "sh"))
         d_m2 = torch.empty((P, 3), **f32)
-        d_op = torch.empty((P, 1), **f32)
-        d_col = torch.empty((P, Cn), **f32) if col is not None else None
-        d_sca = torch.empty((P, 3), **f32) if sca is not None else None
-        d_rot = torch.empty((P, 4), **f32) if rot is not None else None
-        d_cov = torch.empty((P, 6), **f32) if cov is not None else None
-        d_sh = torch.empty(tuple(shs.shape), **f32) if shs is not None else None
         want_pose = any(ctx.needs_input_grad[9:12]) if len(ctx.needs_input_grad) >= 12 else False
         d_view = torch.empty((4, 4), **f32) if want_pose else None
         d_proj = torch.empty((4, 4), **f32) if want_pose else None

@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from splatloc_amd.frame_parallel import allreduce_grads, shard_views, sync_densification_stats
+from splatloc_amd.frame_parallel import _shared_spans, allreduce_grads, shard_views, sync_densification_stats
 
 
 def _free_port():
@@ -40,6 +40,27 @@ def _worker(rank, world, port, out):
             want = sum(e[i] for e in exp)
             assert torch.allclose(t, want, atol=1e-6), i
             assert not torch.equal(t, local[i])
+        # gradients carved out of one allocation (what the rasterizer's backward returns) are
+        # reduced in place as one span; the padding between pieces is left alone semantically
+        flat = torch.full((3 * 10 + 2 + 10 + 2 + 10 * 4 + 7,), 100.0)
+        a, b, c = flat[0:30].view(10, 3), flat[32:42].view(10, 1), flat[44:84].view(10, 4)
+        outsider = flat[84:91]
+        for t in (a, b, c):
+            t.fill_(float(rank + 1))
+        spans, rest = _shared_spans([a, b, c])
+        assert len(spans) == 1 and not rest and spans[0].numel() == 84
+        assert spans[0].data_ptr() == flat.data_ptr()
+        allreduce_grads([a, None, b, c])
+        assert torch.all(a == 3.0) and torch.all(b == 3.0) and torch.all(c == 3.0)
+        assert torch.all(outsider == 100.0)
+        # a far-apart pair in one allocation is NOT a span (what lies between is not ours)
+        big = torch.zeros(100)
+        u, v = big[0:10], big[50:60]
+        spans, rest = _shared_spans([u, v])
+        assert not spans and len(rest) == 2
+        u.fill_(1.0), v.fill_(2.0)
+        allreduce_grads([u, v])
+        assert torch.all(u == 2.0) and torch.all(v == 4.0) and torch.all(big[10:50] == 0)
         acc = torch.full((P, 1), float(rank + 1))
         den = torch.ones(P, 1)
         rad = torch.arange(P, dtype=torch.float32) * (1 if rank == 0 else -1)

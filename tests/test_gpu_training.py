@@ -102,6 +102,31 @@ def test_five_views_alive_before_one_backward():
         assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-12
 
 
+def test_parameter_grads_of_a_frame_form_one_span():
+    """The backward hands autograd all parameter gradients as pieces of one allocation, and
+    autograd keeps them (no clone), so frame_parallel.allreduce_grads reduces ONE buffer in
+    place; the viewspace gradient is separate."""
+    from splatloc_amd import GaussianRasterizer
+    from splatloc_amd.frame_parallel import _shared_spans
+    dev = torch.device("cuda:0")
+    P, C = 3001, 35                          # odd P: pieces need alignment padding
+    sc = make_scene(P, 160, 96, C, 4, scale_median=0.04).to(dev)
+    leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.features, sc.opacities, sc.scales, sc.rotations)]
+    m2 = torch.zeros_like(leaves[0], requires_grad=True)
+    rast = GaussianRasterizer(raster_settings=hip_settings(sc, dev))
+    for rep in range(2):                     # second backward accumulates in place into the same span
+        color, depth, alpha, _ = rast(means3D=leaves[0], means2D=m2, shs=None, colors_precomp=leaves[1],
+                                      opacities=leaves[2], scales=leaves[3], rotations=leaves[4], cov3D_precomp=None)
+        (color.sum() + depth.sum()).backward()
+        spans, rest = _shared_spans([l.grad for l in leaves])
+        assert len(spans) == 1 and not rest
+        n = sum((l.numel() + 3) & ~3 for l in leaves)
+        assert n - 3 <= spans[0].numel() <= n
+        assert m2.grad.untyped_storage().data_ptr() != leaves[0].grad.untyped_storage().data_ptr()
+        for l in leaves:
+            assert l.grad.data_ptr() % 16 == 0 and torch.isfinite(l.grad).all()
+
+
 def test_bench_two_ranks_on_one_gpu_gloo():
     """bench.py --gpus 2 through torch.distributed.run (the driver's launch line), gloo backend,
     both ranks on cuda:0: exercises rank/world plumbing, the gradient all-reduce and the
