@@ -37,8 +37,8 @@ def _hipcc() -> str:
 
 
 def _deps_mtime() -> float:
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(_HERE, "..", "include", "splatraster.h"),
-            os.path.abspath(__file__)]
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    hdrs += [os.path.join(_HERE, "..", "include", "splatraster.h"), os.path.abspath(__file__)]
     return max(os.path.getmtime(h) for h in hdrs)
 
 

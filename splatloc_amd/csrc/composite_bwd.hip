@@ -89,8 +89,10 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     constexpr bool DOTM = NC >= SR_BWD_DOTM_MIN;  // dot products q = f . g on the matrix pipe
     constexpr int PPR = NCP / 4;  // 16-byte pieces per staged row
     static_assert(2 * KV <= WAVE, "at most 25 butterfly-reduced channels per pass");
-    __shared__ __attribute__((aligned(16))) float4 s_rec0[WAVE];
-    __shared__ __attribute__((aligned(16))) float4 s_rec1[WAVE];
+    // records of the staged candidates only (row-indexed, like s_feat): with the 64-entry chunk
+    // records here the workgroup needs 11.2 KB and only 14 fit a CU; at 10 KB all 16 (4 / SIMD) do
+    __shared__ __attribute__((aligned(16))) float4 s_rec0[FS];
+    __shared__ __attribute__((aligned(16))) float4 s_rec1[FS];
     __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
     __shared__ uint32_t s_cgid[FS];
     __shared__ float s_w[MFMA ? WAVE * WS : 1];   // matrix-pipe weight panel w[64 pix][GROUP]
@@ -225,10 +227,17 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         BP_ADD(8, 1);
         const uint32_t cur_gid = gid;
         const bool cur_reach = reach;
+        bool first_round = true;
         if (cand != 0) {
+            // the first <= FS candidates' records go to their staged rows straight from the
+            // registers the prefetch filled
+            const int rank = __popcll(cand & lt_mask);
             __builtin_amdgcn_wave_barrier();
-            s_rec0[lane] = a0;
-            s_rec1[lane] = a1;
+            if (cur_reach && rank < FS) {
+                s_rec0[rank] = a0;
+                s_rec1[rank] = a1;
+                s_cgid[rank] = cur_gid;
+            }
         }
         fetch(base + WAVE, reach, gid, a0, a1);  // next chunk, consumed after this one
         const uint32_t idx0 = base - beg;
@@ -236,10 +245,19 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         while (cand != 0) {
             // ---- stage the feature rows of the next <= FS candidates ----
             BP_T(ts0);
-            const int rank = __popcll(cand & lt_mask);
             const int ncand = min(FS, (int)__popcll(cand));
             __builtin_amdgcn_wave_barrier();
-            if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid;
+            if (!first_round) {
+                // more than FS candidates in one chunk (rare): the rest re-read their records
+                const int rank = __popcll(cand & lt_mask);
+                if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) {
+                    const size_t j = (size_t)base + lane;
+                    s_rec0[rank] = irec[2 * j];
+                    s_rec1[rank] = irec[2 * j + 1];
+                    s_cgid[rank] = cur_gid;
+                }
+            }
+            first_round = false;
             __builtin_amdgcn_wave_barrier();
             // 16-byte pieces of the 16-byte-aligned padded rows
 #pragma unroll SR_STAGE_UNROLL
@@ -258,8 +276,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             // their dot products when the matrix pipe already produced them.
             auto process_pair = [&](int j0, int j1, bool has1, int r0, int r1, float qm0, float qm1) {
                 BP_T(tp0);
-                const float4 p0 = s_rec0[j0], q0 = s_rec1[j0];
-                const float4 p1 = s_rec0[j1], q1 = s_rec1[j1];
+                const float4 p0 = s_rec0[r0], q0 = s_rec1[r0];
+                const float4 p1 = s_rec0[r1], q1 = s_rec1[r1];
                 const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
                 const float pw0 = -0.5f * (q0.x * dx0 * dx0 + q0.z * dy0 * dy0) - q0.y * dx0 * dy0;
                 const float pw1 = -0.5f * (q1.x * dx1 * dx1 + q1.z * dy1 * dy1) - q1.y * dx1 * dy1;
@@ -384,8 +402,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     const int k = lane & 3;
                     const int srow = min(slot + k, ncand - 1);
                     const float* fr = &s_feat[srow * NCP];
-                    const int jsel = k == 0 ? j0 : (k == 1 ? j1 : (k == 2 ? j2 : j3));
-                    const float zsel = reinterpret_cast<const float*>(&s_rec0[jsel])[2];
+                    const float zsel = reinterpret_cast<const float*>(&s_rec0[srow])[2];
                     f32x4 Q = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ch = 0; ch < NC; ++ch) Q = __builtin_amdgcn_mfma_f32_4x4x1f32(fr[ch], g[ch], Q, 0, 0, 0);
