@@ -27,6 +27,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BREAKDOWN_STEPS = 5    # untimed steps that collect the per-stage table
 
 
 def algorithmic_bytes(P, R, W, H, C, tiles):
@@ -136,9 +137,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # (1) untimed breakdown pass: every stage bracketed by HIP events.  An event record between
+    #     two kernels idles the GPU for ~10 us, so this is NOT done inside the timed region.
     barrier()
     _native.timing_enable(True)
     _native.timing_collect()
+    for _ in range(BREAKDOWN_STEPS):
+        step()
+    barrier()
+    _native.timing_enable(False)
+    stages = _native.timing_collect()
+    dom = max(stages, key=lambda s: stages[s][0])
+    # (2) timed region: only the dominant kernel is bracketed (roofline.achieved is measured live
+    #     here, on the launch stream)
+    _native.timing_select([dom])
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -146,7 +158,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     _native.timing_enable(False)
-    stages = _native.timing_collect()
+    stages[dom] = _native.timing_collect()[dom]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,7 +176,7 @@ def main():
                 avg = ms / cnt
                 per_stage[s] = {"avg_ms": round(avg, 4), "launches": int(cnt),
                                 "algorithmic_GBps": round(st_bytes[s] / (avg * 1e-3) / 1e9, 1)}
-        dom = max(per_stage, key=lambda s: per_stage[s]["avg_ms"] * per_stage[s]["launches"] / args.steps)
+        per_stage[dom]["measured"] = "live in the timed region"
         ach = per_stage[dom]["algorithmic_GBps"]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -190,6 +202,8 @@ def main():
                           "achieved_GBps": round(frame_bytes * value / world / 1e9, 1),
                           "frac_of_peak": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
             "stages": per_stage,
+            "stages_note": f"per-stage table from {BREAKDOWN_STEPS} untimed steps with every stage bracketed by HIP "
+                           f"events; only '{dom}' is bracketed inside the timed region",
         }
         if args.fwd_only:
             out["metric"] = "DEBUG fwd-only frames/s (not the BASELINE metric)"

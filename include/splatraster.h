@@ -202,7 +202,9 @@ int splatknn_dist2(int32_t N, const float* points /* [N,3] */, float* out /* [N]
 /* ---- per-stage timing (HIP events on the launch stream) ----------------------------- */
 
 /* Stage ids: every kernel group of the path is bracketed by a hipEvent pair when timing
- * is enabled (process-wide switch; off by default, ~2 us per stage when on). */
+ * is enabled (process-wide switch; off by default).  An event record between two kernels
+ * costs ~10 us of idle GPU on MI355X, so a throughput measurement should select only the
+ * stage it needs (splatraster_timing_select) and take the full breakdown in a separate run. */
 #define SPLATRASTER_STAGE_PREPROCESS 0     /* preprocess_kernel */
 #define SPLATRASTER_STAGE_DEPTH_SORT 1     /* depth keys + P-sized radix sort */
 #define SPLATRASTER_STAGE_SCAN 2           /* inclusive scan of tiles_touched */
@@ -210,12 +212,13 @@ int splatknn_dist2(int32_t N, const float* points /* [N,3] */, float* out /* [N]
 #define SPLATRASTER_STAGE_TILE_SORT 4      /* R-sized radix sort on tile id */
 #define SPLATRASTER_STAGE_RANGES 5         /* ranges_kernel */
 #define SPLATRASTER_STAGE_COMPOSITE_FWD 6  /* composite_fwd_kernel */
-#define SPLATRASTER_STAGE_COMPOSITE_BWD 7  /* memset of gradient buffers + composite_bwd_kernel */
+#define SPLATRASTER_STAGE_COMPOSITE_BWD 7  /* composite_bwd_kernel (the accumulator memset before it is not bracketed) */
 #define SPLATRASTER_STAGE_PREPROCESS_BWD 8 /* preprocess_bwd_kernel */
 #define SPLATRASTER_STAGE_PAYLOAD 9        /* payload_kernel: per-instance records + quadrant reach masks */
 #define SPLATRASTER_STAGE_COUNT 10
 
-int splatraster_timing_enable(int on);
+int splatraster_timing_enable(int on);            /* all stages on / off */
+int splatraster_timing_select(uint32_t stage_mask); /* bit s set: time stage s only */
 /* Waits for all recorded events, ADDS elapsed milliseconds / launch counts per stage into
  * ms[SPLATRASTER_STAGE_COUNT] / counts[SPLATRASTER_STAGE_COUNT], then clears the records. */
 int splatraster_timing_collect(double* ms, int64_t* counts);

@@ -63,6 +63,7 @@ SYMBOLS = {
     "splatraster_sort_tmp_bytes": (_sz, [_i64]),
     "splatraster_sort_pairs_u32": (C.c_int, [_i64, _vp, _vp, _i32, _vp, _vp]),
     "splatraster_timing_enable": (C.c_int, [C.c_int]),
+    "splatraster_timing_select": (C.c_int, [C.c_uint32]),
     "splatraster_timing_collect": (C.c_int, [_vp, _vp]),
     "splatknn_workspace_bytes": (_sz, [_i32]),
     "splatknn_dist2": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
@@ -113,6 +114,14 @@ STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "co
 
 def timing_enable(on: bool) -> None:
     check(load().splatraster_timing_enable(int(on)), "timing_enable")
+
+
+def timing_select(stages) -> None:
+    """Time only the named stages (an event record between kernels costs ~10 us of idle GPU)."""
+    mask = 0
+    for st in stages:
+        mask |= 1 << STAGES.index(st)
+    check(load().splatraster_timing_select(mask), "timing_select")
 
 
 def timing_collect() -> dict:

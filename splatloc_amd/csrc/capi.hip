@@ -19,7 +19,7 @@ void set_hip_error(hipError_t e, const char* what)
 
 // ---- stage timing ---------------------------------------------------------------------
 struct StageRec { int stage; hipEvent_t a, b; };
-static bool g_timing = false;
+static uint32_t g_timing_mask = 0;  // bit s: stage s is bracketed by an event pair
 static std::mutex g_timing_mu;
 static std::vector<StageRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -36,7 +36,7 @@ struct StageTimer {
     hipStream_t stream;
     StageRec rec{};
     bool on;
-    StageTimer(int stage, hipStream_t s) : stream(s), on(g_timing)
+    StageTimer(int stage, hipStream_t s) : stream(s), on((g_timing_mask >> stage) & 1u)
     {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_timing_mu);
@@ -53,6 +53,42 @@ struct StageTimer {
     }
 };
 
+// ---- host landing slot of the early instance count ---------------------------------------
+// One pinned buffer + one event per host thread (and device): the copy of the per-block sums is
+// enqueued right after preprocess, the depth sort and scan are enqueued behind it, and the
+// host waits on the EVENT only — the GPU keeps working while the caller sizes and allocates
+// the binning buffer.
+struct HostSlot {
+    uint32_t* p = nullptr;
+    size_t cap = 0;  // elements
+    hipEvent_t ev = nullptr;
+    int device = -1;
+};
+static thread_local HostSlot t_slot;
+
+static int host_slot(size_t n, HostSlot** out)
+{
+    HostSlot& s = t_slot;
+    int dev = 0;
+    SR_HIP_CHECK(hipGetDevice(&dev));
+    if (s.cap < n) {
+        if (s.p) (void)hipHostFree(s.p);
+        s.p = nullptr;
+        s.cap = 0;
+        const size_t cap = n < 4096 ? 4096 : n + n / 2;
+        SR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.p), sizeof(uint32_t) * cap, hipHostMallocPortable));
+        s.cap = cap;
+    }
+    if (!s.ev || s.device != dev) {
+        if (s.ev) (void)hipEventDestroy(s.ev);
+        s.ev = nullptr;
+        SR_HIP_CHECK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+        s.device = dev;
+    }
+    *out = &s;
+    return SPLATRASTER_OK;
+}
+
 static inline int tile_bits(int tiles)
 {
     int b = 1;
@@ -62,7 +98,7 @@ static inline int tile_bits(int tiles)
 
 struct GeomLayout {
     size_t rec0, rec1, tiles_touched, depth_order, offsets, rgb, clamped, sort_keys, keys_alt, vals_alt,
-        sort_tmp, scan_tmp, total, bytes;
+        sort_tmp, scan_tmp, total, block_tiles, bytes;
 };
 static GeomLayout geom_layout(int32_t P)
 {
@@ -83,6 +119,7 @@ static GeomLayout geom_layout(int32_t P)
     L.sort_tmp = take(sort_tmp_bytes((int64_t)n));
     L.scan_tmp = take(scan_tmp_bytes((int64_t)n));
     L.total = take(16);
+    L.block_tiles = take(4 * (size_t)preprocess_blocks((int32_t)n));
     L.bytes = o;
     return L;
 }
@@ -101,6 +138,7 @@ GeomView geom_view(void* base, int32_t P)
     g.sort_keys = reinterpret_cast<uint32_t*>(b + L.sort_keys);
     g.sort_tmp = reinterpret_cast<uint32_t*>(b + L.sort_tmp);
     g.total = reinterpret_cast<uint32_t*>(b + L.total);
+    g.block_tiles = reinterpret_cast<uint32_t*>(b + L.block_tiles);
     return g;
 }
 
@@ -252,6 +290,12 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
                                projmatrix, campos, g, radii, stream);
     }
     if (st) return st;
+    HostSlot* slot = nullptr;
+    const size_t nblk = (size_t)preprocess_blocks(P);
+    st = host_slot(nblk, &slot);
+    if (st) return st;
+    SR_HIP_CHECK(hipMemcpyAsync(slot->p, g.block_tiles, sizeof(uint32_t) * nblk, hipMemcpyDeviceToHost, stream));
+    SR_HIP_CHECK(hipEventRecord(slot->ev, stream));
     {
         StageTimer t(SPLATRASTER_STAGE_DEPTH_SORT, stream);
         st = launch_depth_keys(P, g, stream);
@@ -268,9 +312,9 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
         st = inclusive_scan_u32(P, g.tiles_touched, g.depth_order, g.offsets, g.total, base + L.scan_tmp, stream);
     }
     if (st) return st;
+    SR_HIP_CHECK(hipEventSynchronize(slot->ev));  // the copy only: sort and scan may still be running
     uint64_t total = 0;
-    SR_HIP_CHECK(hipMemcpyAsync(&total, g.total, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    SR_HIP_CHECK(hipStreamSynchronize(stream));
+    for (size_t k = 0; k < nblk; ++k) total += slot->p[k];
     if (total >= ((uint64_t)1 << 31)) return SPLATRASTER_ERR_OVERFLOW;
     *num_rendered = (int64_t)total;
     return SPLATRASTER_OK;
@@ -367,9 +411,11 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     ImgView im = img_view(const_cast<void*>(image), W, H);
     const int C = s->channels;
     const float* feat = shs ? g.rgb : colors_precomp;
+    // zero the accumulator rows (outside the stage bracket: the stage is the kernel alone, so its
+    // figure can be held against the per-kernel rocprofv3 average)
+    SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * (size_t)gacc_row_floats(C) * (size_t)P, stream));
     {
         StageTimer t(SPLATRASTER_STAGE_COMPOSITE_BWD, stream);
-        SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * (size_t)gacc_row_floats(C) * (size_t)P, stream));
         st = launch_composite_bwd(*s, P, R, g, b, im, (C % 4) ? b.featp : feat, C, out_color, out_depth, dL_dout_color,
                                   dL_dout_depth, dL_dout_alpha, b.gacc, stream);
     }
@@ -423,7 +469,14 @@ int splatraster_sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, int32_
 int splatraster_timing_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_timing_mu);
-    g_timing = on != 0;
+    g_timing_mask = on ? 0xffffffffu : 0u;
+    return SPLATRASTER_OK;
+}
+
+int splatraster_timing_select(uint32_t stage_mask)
+{
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    g_timing_mask = stage_mask;
     return SPLATRASTER_OK;
 }
 

@@ -16,6 +16,8 @@ constexpr float ALPHA_MAX = 0.99f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_EPS = 0.0001f;
 constexpr int WAVE = 64;
+constexpr int PREPROCESS_BLOCK = 256;
+static inline int preprocess_blocks(int32_t P) { return (P + PREPROCESS_BLOCK - 1) / PREPROCESS_BLOCK; }
 
 // thread-local last-error text, filled by SR_HIP_CHECK
 void set_hip_error(hipError_t e, const char* what);
@@ -51,7 +53,8 @@ struct GeomView {
     uint8_t* clamped;        // [3P]
     uint32_t* sort_keys;     // [P] scratch (depth bits)
     uint32_t* sort_tmp;      // scratch for the P-sized sort + scan partials
-    uint32_t* total;         // [2] device-side R (uint64 as two words)
+    uint32_t* total;         // [2] device-side R (uint64 as two words), written by the scan
+    uint32_t* block_tiles;   // [preprocess_blocks(P)] per-block sums of tiles_touched, written by preprocess
 };
 struct BinView {
     uint32_t* point_list; // [R] sorted gaussian ids

@@ -86,7 +86,7 @@ __device__ void sh_to_rgb(int deg, const float* sh, float px, float py, float pz
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(PREPROCESS_BLOCK)
 preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale_modifier, int sh_degree,
                   int sh_coeffs, const float* __restrict__ means3D, const float* __restrict__ shs,
                   const float* __restrict__ opacities, const float* __restrict__ scales,
@@ -94,10 +94,12 @@ preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale
                   const float* __restrict__ view, const float* __restrict__ proj,
                   const float* __restrict__ campos_p,
                   float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
-                  float* __restrict__ rgb, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii)
+                  float* __restrict__ rgb, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii,
+                  uint32_t* __restrict__ block_tiles /*[gridDim.x] per-block sums of tiles_touched*/)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = gi < P;
+    const int i = live ? gi : P - 1;  // padding lanes recompute the last Gaussian and store nothing
     // camera tensors: wave-uniform addresses -> scalar loads, SGPR-resident
     float V[16], PM[16], campos[3];
 #pragma unroll
@@ -112,7 +114,7 @@ preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale
     const float tx0 = ((V[0] * px + V[4] * py) + V[8] * pz) + V[12];
     const float ty0 = ((V[1] * px + V[5] * py) + V[9] * pz) + V[13];
     const float tz = ((V[2] * px + V[6] * py) + V[10] * pz) + V[14];
-    if (tz > NEAR_Z) {
+    if (live && tz > NEAR_Z) {
         const float hx = ((PM[0] * px + PM[4] * py) + PM[8] * pz) + PM[12];
         const float hy = ((PM[1] * px + PM[5] * py) + PM[9] * pz) + PM[13];
         const float hw = ((PM[3] * px + PM[7] * py) + PM[11] * pz) + PM[15];
@@ -181,10 +183,27 @@ preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale
             }
         }
     }
-    radii[i] = out_radius;
-    tiles_touched[i] = out_tiles;
-    rec[2 * i] = r0;
-    rec[2 * i + 1] = r1;
+    if (live) {
+        radii[i] = out_radius;
+        tiles_touched[i] = out_tiles;
+        rec[2 * i] = r0;
+        rec[2 * i + 1] = r1;
+    }
+    // The instance count R = sum of tiles_touched is needed on the HOST (it sizes the binning
+    // buffer).  Per-block sums written here (no atomics, nothing to zero) are copied out and
+    // added up by the host while the depth sort and the scan are still executing (capi.hip).
+    __shared__ uint32_t s_part[PREPROCESS_BLOCK / WAVE];
+    uint32_t t = out_tiles;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) t += (uint32_t)__shfl_xor((int)t, d, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_part[threadIdx.x / WAVE] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < PREPROCESS_BLOCK / WAVE; ++k) sum += s_part[k];
+        block_tiles[blockIdx.x] = sum;
+    }
 }
 
 int launch_preprocess(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
@@ -193,11 +212,11 @@ int launch_preprocess(const splatraster_settings& s, int32_t P, const float* mea
                       const float* campos, GeomView g, int32_t* radii, hipStream_t stream)
 {
     if (P == 0) return SPLATRASTER_OK;
-    const int blocks = (P + 255) / 256;
-    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, stream, P, s.image_width,
+    const int blocks = preprocess_blocks(P);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(PREPROCESS_BLOCK), 0, stream, P, s.image_width,
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs,
                        means3D, shs, opacities, scales, rotations, cov3D_precomp, view, proj, campos, g.rec,
-                       g.tiles_touched, g.rgb, g.clamped, radii);
+                       g.tiles_touched, g.rgb, g.clamped, radii, g.block_tiles);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
