@@ -221,13 +221,36 @@ sort_scatter_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint3
         if (valid && (mask & lt_mask) == 0) wave_hist[w][digit] = prev + (uint32_t)__popcll(mask);
     }
     __syncthreads();
+    // Block-local reorder through LDS before the global scatter: elements of one digit become
+    // consecutive, so consecutive threads write consecutive addresses (runs of ~16 elements at
+    // 256 bins) instead of 64 scattered 4-byte stores per instruction.
+    __shared__ uint32_t s_keys[SORT_TILE], s_vals[SORT_TILE];
+    __shared__ uint32_t s_gbase[RADIX];   // global address of local slot 0 of the digit's run
+    __shared__ uint32_t s_wsum[SORT_WAVES];
     {
         const int d = threadIdx.x;
-        uint32_t run = table[(size_t)d * nblocks + blockIdx.x];
+        uint32_t total = 0;
+#pragma unroll
+        for (int k = 0; k < SORT_WAVES; ++k) total += wave_hist[k][d];
+        // exclusive prefix of `total` over the 256 digits
+        uint32_t incl = total;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, WAVE);
+            if (lane >= o) incl += up;
+        }
+        if (lane == WAVE - 1) s_wsum[w] = incl;
+        __syncthreads();
+        uint32_t wbase_d = 0;
+#pragma unroll
+        for (int k = 0; k < SORT_WAVES; ++k) wbase_d += (k < w) ? s_wsum[k] : 0u;
+        const uint32_t excl = wbase_d + incl - total;
+        s_gbase[d] = table[(size_t)d * nblocks + blockIdx.x] - excl;
+        uint32_t run = excl;
 #pragma unroll
         for (int k = 0; k < SORT_WAVES; ++k) {
             const uint32_t c = wave_hist[k][d];
-            wave_hist[k][d] = run;  // becomes the global base of (wave k, digit d)
+            wave_hist[k][d] = run;  // becomes the block-local base of (wave k, digit d)
             run += c;
         }
     }
@@ -237,9 +260,22 @@ sort_scatter_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint3
         const int64_t i = wbase + (int64_t)k * WAVE + lane;
         if (i < n) {
             const uint32_t digit = (key[k] >> shift) & (RADIX - 1);
-            const uint32_t dst = wave_hist[w][digit] + rank[k];
-            keys_out[dst] = key[k];
-            vals_out[dst] = val[k];
+            const uint32_t pos = wave_hist[w][digit] + rank[k];
+            s_keys[pos] = key[k];
+            s_vals[pos] = val[k];
+        }
+    }
+    __syncthreads();
+    const int64_t bbase = (int64_t)blockIdx.x * SORT_TILE;
+    const uint32_t cnt = (uint32_t)((n - bbase) < (int64_t)SORT_TILE ? (n - bbase) : (int64_t)SORT_TILE);
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) {
+        const uint32_t sl = (uint32_t)k * SORT_THREADS + threadIdx.x;
+        if (sl < cnt) {
+            const uint32_t kk = s_keys[sl];
+            const uint32_t dst = s_gbase[(kk >> shift) & (RADIX - 1)] + sl;
+            keys_out[dst] = kk;
+            vals_out[dst] = s_vals[sl];
         }
     }
 }

@@ -196,7 +196,8 @@ def test_mark_visible():
     assert vis.dtype == torch.bool and np.array_equal(vis.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("n,bits", [(1, 32), (63, 8), (4096, 13), (4097, 32), (100_003, 32), (1_000_000, 16)])
+@pytest.mark.parametrize("n,bits", [(1, 32), (63, 8), (4096, 13), (4097, 32), (100_003, 32), (1_000_000, 16),
+                                    (1_100_000, 13), (3_000_001, 16)])  # > 256 blocks: histogram/scan/scatter passes
 def test_radix_sort_is_stable_and_exact(n, bits):
     """splatraster_sort_pairs_u32 vs numpy stable argsort (bit-exact, ties keep input order)."""
     import ctypes as C
