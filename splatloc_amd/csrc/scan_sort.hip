@@ -18,7 +18,10 @@ constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 16;
+#ifndef SR_SORT_ITEMS
+#define SR_SORT_ITEMS 16
+#endif
+constexpr int SORT_ITEMS = SR_SORT_ITEMS;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096
 constexpr int SORT_WAVES = SORT_THREADS / WAVE;
 constexpr int RADIX = 256;
@@ -383,20 +386,36 @@ sort_sweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_
             __hip_atomic_store(mine, cnt | ST_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             __hip_atomic_store(mine, cnt | ST_LOCAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // LOOKBACK independent loads in flight per step: the walk over predecessors that have
+            // only published their local count costs one L2 round trip per LOOKBACK blocks
+            constexpr int LOOKBACK = 8;
             int64_t pb = (int64_t)bid - 1;
             uint32_t spins = 0;
-            while (pb >= 0) {
-                const uint32_t v = __hip_atomic_load(status + (size_t)pb * RADIX + d, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t flag = v & ~ST_MASK;
-                if (flag == 0) {
+            bool done = false;
+            while (pb >= 0 && !done) {
+                uint32_t v[LOOKBACK];
+#pragma unroll
+                for (int q = 0; q < LOOKBACK; ++q) {
+                    const int64_t idx = pb - q;
+                    v[q] = idx >= 0 ? __hip_atomic_load(status + (size_t)idx * RADIX + d, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT)
+                                    : ST_INCL;  // before block 0: inclusive prefix 0
+                }
+                int used = 0;
+#pragma unroll
+                for (int q = 0; q < LOOKBACK; ++q) {
+                    if (done || used != q) continue;
+                    const uint32_t flag = v[q] & ~ST_MASK;
+                    if (flag == 0) continue;  // not published yet: retry from here
+                    excl += v[q] & ST_MASK;
+                    used = q + 1;
+                    if (flag == ST_INCL) done = true;
+                }
+                pb -= used;
+                if (used == 0) {
                     if (++spins > (1u << 24)) { st->error = 1u; break; }
                     __builtin_amdgcn_s_sleep(1);
-                    continue;
                 }
-                excl += v & ST_MASK;
-                if (flag == ST_INCL) break;
-                --pb;
             }
             __hip_atomic_store(mine, (excl + cnt) | ST_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
