@@ -1,0 +1,110 @@
+"""Edge cases of the HIP path against the CPU oracle (needs an MI355X): tiny and ragged
+images, screen-filling Gaussians, exact depth ties, single Gaussian, saturated / vanishing
+opacity, odd channel counts, very deep per-tile lists.  Same bar as test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from splatloc_amd.synthetic import make_scene
+from tests.helpers import HipRun, oracle_backward, oracle_forward
+from tests.test_gpu_parity import _check_backward, _check_forward
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_and_check(sc, backward=True):
+    f = oracle_forward(sc)
+    run = HipRun(sc, backward=backward)
+    _check_forward(run, f, sc)
+    if backward:
+        _check_backward(run, oracle_backward(f, sc))
+    return run, f
+
+
+@pytest.mark.parametrize("W,H", [(7, 5), (16, 16), (17, 9), (40, 24), (8, 64)])
+def test_tiny_and_ragged_images(W, H):
+    """Images smaller than a tile / a quadrant, one-pixel overhangs."""
+    sc = make_scene(300, W, H, 4, seed=100 + W, scale_median=0.08)
+    _run_and_check(sc)
+
+
+def test_screen_filling_gaussians():
+    """Radii far larger than the image: every Gaussian lands in every tile."""
+    sc = make_scene(200, 96, 64, 3, seed=41, scale_median=1.5)
+    run, f = _run_and_check(sc)
+    tiles = ((96 + 15) // 16) * ((64 + 15) // 16)
+    assert (f["tiles_touched"][f["radii"] > 0] == tiles).mean() > 0.5
+
+
+def test_exact_depth_ties_keep_index_order():
+    """Identical depths: the (tile, depth, index) order must fall back to the Gaussian index."""
+    sc = make_scene(600, 128, 96, 3, seed=42, scale_median=0.06)
+    sc.means3D[:, 2] = torch.round(sc.means3D[:, 2] * 2.0) / 2.0     # 12 distinct depths
+    sc.means3D[300:] = sc.means3D[:300]                              # exact duplicates as well
+    run, f = _run_and_check(sc)
+    pl = f["point_list"].astype(np.int64)
+    z = f["view_depth"]
+    r = f["ranges"].astype(np.int64)
+    t = int(np.argmax(r[:, 1] - r[:, 0]))
+    seg = pl[r[t, 0]:r[t, 1]]
+    same = z[seg[1:]] == z[seg[:-1]]
+    assert same.any() and (seg[1:][same] > seg[:-1][same]).all()
+
+
+def test_single_gaussian():
+    sc = make_scene(1, 64, 48, 3, seed=43, scale_median=0.2)
+    sc.means3D[0] = torch.tensor([0.0, 0.0, 2.0])
+    run, f = _run_and_check(sc)
+    assert run.num_rendered > 0
+
+
+def test_saturated_and_vanishing_opacity():
+    """opacity = 1 (alpha clamps at 0.99), opacity below 1/255 (never contributes), and 0."""
+    sc = make_scene(900, 128, 96, 4, seed=44, scale_median=0.06)
+    sc.opacities[:300] = 1.0
+    sc.opacities[300:600] = 1.0 / 512.0
+    sc.opacities[600:650] = 0.0
+    run, f = _run_and_check(sc)
+    g = run.np(run.opacities.grad)
+    assert np.all(np.isfinite(g))
+    assert np.all(run.np(run.colors.grad)[300:650] == 0.0)           # never composited
+
+
+@pytest.mark.parametrize("C", [2, 5, 6, 9, 16, 17, 32, 33, 48, 67])
+def test_channel_counts(C):
+    """Specialised kernels (1, 2, 3, 4, 8, 16, 32, 35) and the chunked generic path."""
+    sc = make_scene(1200, 112, 80, C, seed=50 + C, scale_median=0.05)
+    _run_and_check(sc)
+
+
+def test_very_deep_lists():
+    """Hundreds of overlapping Gaussians per pixel: more than one staging round per 64-entry
+    chunk in every quadrant, early termination (T < 1e-4) in most pixels."""
+    sc = make_scene(6000, 96, 96, 35, seed=45, scale_median=0.3)
+    run, f = _run_and_check(sc)
+    assert float(f["final_T"].mean()) < 0.05
+    r = f["ranges"].astype(np.int64)
+    assert (r[:, 1] - r[:, 0]).min() > 1000
+
+
+def test_background_shorter_than_channels():
+    """SplatLoc passes a 3-entry background with C = 4: missing entries are 0."""
+    sc = make_scene(800, 96, 64, 4, seed=46, scale_median=0.03)
+    sc.bg = torch.tensor([0.3, 0.6, 0.9])
+    run, f = _run_and_check(sc)
+    empty = f["final_T"] == 1.0
+    assert empty.any()
+    col = run.np(run.color)
+    assert np.allclose(col[:3][:, empty], np.array([[0.3], [0.6], [0.9]]), atol=1e-6)
+    assert np.all(col[3][empty] == 0.0)
+
+
+def test_everything_behind_or_beside_the_camera():
+    sc = make_scene(500, 64, 48, 3, seed=47, scale_median=0.02)
+    sc.means3D[:250, 2] = -sc.means3D[:250, 2]           # behind
+    sc.means3D[250:, 0] += 1000.0                        # far outside the frustum
+    run, f = _run_and_check(sc)
+    assert run.num_rendered == 0 and int(run.radii.abs().sum()) == 0
+    for t in (run.means3D, run.colors, run.opacities, run.scales, run.rotations):
+        assert float(t.grad.abs().sum()) == 0.0
