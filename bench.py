@@ -68,6 +68,92 @@ def cpu_baseline(workload):
             "host_cpu_count": os.cpu_count()}
 
 
+def bench_activations(args, dev):
+    """--stage activations: the fused parameter activations + SH / feature packing (SURVEY.md
+    §8f-1, splatloc_amd.fused.activate_pack) forward + backward on the S2 parameter shapes
+    (500k Gaussians, SH degree 0, 32 extra feature columns), next to the same arithmetic as the
+    reference's chain of torch ops on the same GPU.  HBM-bound: achieved GB/s vs the 8 TB/s peak."""
+    from splatloc_amd.fused import activate_pack
+    P, E = 500_000, 32
+    g = torch.Generator().manual_seed(7)
+    leaf = lambda *s: torch.randn(*s, generator=g).to(dev).requires_grad_(True)  # noqa: E731
+    xyz, f_dc, scaling, rotation, opacity, extra = leaf(P, 3), leaf(P, 1, 3), leaf(P, 3), leaf(P, 4), leaf(P, 1), leaf(P, E)
+    f_rest = torch.zeros(P, 0, 3, device=dev, requires_grad=True)
+    campos = torch.zeros(3, device=dev)
+    G = [torch.randn(P, 3, generator=g).to(dev), torch.randn(P, 4, generator=g).to(dev),
+         torch.randn(P, 1, generator=g).to(dev), torch.randn(P, 3 + E, generator=g).to(dev)]
+    leaves = [xyz, f_dc, scaling, rotation, opacity, extra]
+
+    def fused():
+        outs = activate_pack(xyz, f_dc, f_rest, scaling, rotation, opacity, extra=extra, campos=campos)
+        torch.autograd.backward(outs, G)
+
+    def composed():  # gaussian_model.py:78-105 + gaussian_renderer/__init__.py:84-102 at SH degree 0
+        feats = torch.cat((f_dc, f_rest), dim=1)
+        shs_view = feats.transpose(1, 2).view(-1, 3, 1)
+        rgb = torch.clamp_min(0.28209479177387814 * shs_view[..., 0] + 0.5, 0.0)
+        outs = (torch.exp(scaling), torch.nn.functional.normalize(rotation), torch.sigmoid(opacity),
+                torch.cat((rgb, extra), dim=1))
+        torch.autograd.backward(outs, G)
+
+    def time_it(fn):
+        for _ in range(args.warmup):
+            for t in leaves:
+                t.grad = None
+            fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        a.record()
+        for _ in range(args.steps):
+            for t in leaves:
+                t.grad = None
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / args.steps * 1e3, a.elapsed_time(b) / args.steps
+
+    wall_f, gpu_f = time_it(fused)
+    wall_c, gpu_c = time_it(composed)
+
+    # the two kernels alone, launched back to back through the C ABI (no autograd, no allocation):
+    # this is the figure held against the HBM roofline
+    import ctypes as C
+    from splatloc_amd import _native
+    lib = _native.load()
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    with torch.no_grad():
+        o = [torch.empty(P, 3, device=dev), torch.empty(P, 4, device=dev), torch.empty(P, 1, device=dev),
+             torch.empty(P, 3 + E, device=dev)]
+        d = [torch.empty_like(t) for t in (f_dc, scaling, rotation, opacity, extra)]
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def kernels():
+        _native.check(lib.splatraster_activate_forward(P, 1, 0, 3, E, p(xyz), p(f_dc), None, p(scaling), p(rotation),
+                                                       p(opacity), p(extra), p(campos), p(o[0]), p(o[1]), p(o[2]),
+                                                       p(o[3]), st), "activate_forward")
+        _native.check(lib.splatraster_activate_backward(P, 1, 0, 3, E, p(xyz), p(f_dc), None, p(scaling), p(rotation),
+                                                        p(opacity), p(campos), p(G[0]), p(G[1]), p(G[2]), p(G[3]),
+                                                        None, p(d[0]), None, p(d[1]), p(d[2]), p(d[3]), p(d[4]), st),
+                      "activate_backward")
+
+    _, gpu_k = time_it(kernels)
+    fwd_bytes = P * ((12 + 12 + 16 + 4 + 4 * E) + (12 + 16 + 4 + 4 * (3 + E)))
+    bwd_bytes = P * ((12 + 12 + 16 + 4) + (12 + 16 + 4 + 4 * (3 + E)) + (12 + 12 + 16 + 4 + 4 * E))
+    ach = (fwd_bytes + bwd_bytes) / (gpu_k * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "activation + SH/feature packing fwd+bwd passes/s (SURVEY 8f-1 stage; NOT the BASELINE metric)",
+        "value": round(1e3 / wall_f, 1), "unit": "passes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall_f, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"P={P} Gaussians, SH degree 0, {E} extra feature columns (S2 parameter shapes)"},
+        "roofline": {"bound": "hbm", "kernel": "activate_fwd_kernel + activate_bwd_kernel", "achieved": round(ach, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernels_ms": round(gpu_k, 4), "algorithmic_bytes": fwd_bytes + bwd_bytes},
+        "through_autograd": {"ms_per_step": round(wall_f, 4), "note": "host-bound: Python autograd + allocation"},
+        "torch_ops_same_gpu": {"ms_per_step": round(wall_c, 4), "speedup_wall": round(wall_c / wall_f, 2)},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +162,8 @@ def main():
     ap.add_argument("--workload", default="S2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
+    ap.add_argument("--stage", default="raster", choices=["raster", "activations"],
+                    help="raster = the BASELINE metric (default); activations = the fused front-end stage alone")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,6 +184,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    if args.stage == "activations":
+        if rank == 0:
+            bench_activations(args, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer, _native
     from splatloc_amd.frame_parallel import allreduce_grads

@@ -192,6 +192,43 @@ size_t splatraster_sort_tmp_bytes(int64_t n);
 int splatraster_sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, int32_t key_bits,
                                void* tmp, void* stream);
 
+/* ---- parameter activations + SH / feature packing -------------------- */
+
+/* The elementwise work between SplatLoc's raw optimiser tensors and the rasterizer call, as one
+ * kernel each way.  Replaces, with identical results:
+ *   scales    = exp(_scaling)             gaussian_model.py:78-80; an isotropic [P,1] model is
+ *                                         repeated to 3 columns (gaussian_renderer/__init__.py:73-76)
+ *   rotations = normalize(_rotation)      gaussian_model.py:82-84 (eps 1e-12)
+ *   opacities = sigmoid(_opacity)         gaussian_model.py:101-103
+ *   colors    = cat(clamp_min(eval_sh(active_sh_degree, cat(f_dc, f_rest), normalize(xyz - campos))
+ *                             + 0.5, 0), extra)
+ *                                         gaussian_renderer/__init__.py:84-102, sh_utils.py:55-118
+ * sh_coeffs = (max_sh_degree + 1)^2 >= (active_sh_degree + 1)^2, active_sh_degree in [0, 3];
+ * f_dc is [P,1,3], f_rest [P,sh_coeffs-1,3] (NULL when sh_coeffs == 1); scaling_cols is 3 or 1;
+ * extra is [P,extras] (SplatLoc: the kp_score column) or NULL with extras == 0. */
+int splatraster_activate_forward(int32_t P, int32_t sh_coeffs, int32_t active_sh_degree,
+                                 int32_t scaling_cols, int32_t extras,
+                                 const float* xyz, const float* f_dc, const float* f_rest,
+                                 const float* scaling, const float* rotation, const float* opacity,
+                                 const float* extra, const float* campos,
+                                 float* scales /* [P,3] */, float* rotations /* [P,4] */,
+                                 float* opacities /* [P,1] */, float* colors /* [P,3+extras] */,
+                                 void* stream);
+/* Gradients w.r.t. the raw tensors given dL/d(scales, rotations, opacities, colors); recomputes
+ * the activations from the raw inputs (nothing is saved by the forward).  dL_dxyz receives ONLY
+ * the view-direction term of the SH colour (zero at degree 0; the rasterizer's own dL/dmeans3D
+ * is added by the caller) and may be NULL; dL_df_rest / dL_dextra may be NULL when empty.
+ * The camera centre gets no gradient. */
+int splatraster_activate_backward(int32_t P, int32_t sh_coeffs, int32_t active_sh_degree,
+                                  int32_t scaling_cols, int32_t extras,
+                                  const float* xyz, const float* f_dc, const float* f_rest,
+                                  const float* scaling, const float* rotation, const float* opacity,
+                                  const float* campos,
+                                  const float* dL_dscales, const float* dL_drotations,
+                                  const float* dL_dopacities, const float* dL_dcolors,
+                                  float* dL_dxyz, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling,
+                                  float* dL_drotation, float* dL_dopacity, float* dL_dextra, void* stream);
+
 /* ---- simple_knn._C.distCUDA2 (gaussian_model.py:206) ---------------------------------- */
 
 size_t splatknn_workspace_bytes(int32_t N);

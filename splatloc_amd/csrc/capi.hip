@@ -498,6 +498,57 @@ int splatraster_timing_collect(double* ms, int64_t* counts)
 
 size_t splatknn_workspace_bytes(int32_t N) { return knn_workspace_bytes(N); }
 
+static int check_activate(int32_t P, int32_t K, int32_t deg, int32_t SC, int32_t E, const void* f_rest,
+                          const void* extra)
+{
+    if (P < 0 || K < 1 || deg < 0 || E < 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (deg > 3) return SPLATRASTER_ERR_UNSUPPORTED;
+    if ((deg + 1) * (deg + 1) > K) return SPLATRASTER_ERR_BAD_ARG;
+    if (SC != 1 && SC != 3) return SPLATRASTER_ERR_BAD_ARG;
+    if (P > 0 && K > 1 && !f_rest) return SPLATRASTER_ERR_BAD_ARG;
+    if (P > 0 && E > 0 && !extra) return SPLATRASTER_ERR_BAD_ARG;
+    return SPLATRASTER_OK;
+}
+
+int splatraster_activate_forward(int32_t P, int32_t sh_coeffs, int32_t active_sh_degree, int32_t scaling_cols,
+                                 int32_t extras, const float* xyz, const float* f_dc, const float* f_rest,
+                                 const float* scaling, const float* rotation, const float* opacity,
+                                 const float* extra, const float* campos, float* scales, float* rotations,
+                                 float* opacities, float* colors, void* stream)
+{
+    int st = check_activate(P, sh_coeffs, active_sh_degree, scaling_cols, extras, f_rest, extra);
+    if (st) return st;
+    if (P == 0) return SPLATRASTER_OK;
+    if (!xyz || !f_dc || !scaling || !rotation || !opacity || !scales || !rotations || !opacities || !colors)
+        return SPLATRASTER_ERR_BAD_ARG;
+    if (active_sh_degree > 0 && !campos) return SPLATRASTER_ERR_BAD_ARG;
+    return launch_activate_fwd(P, sh_coeffs, active_sh_degree, scaling_cols, extras, xyz, f_dc, f_rest, scaling,
+                               rotation, opacity, extra, campos, scales, rotations, opacities, colors,
+                               reinterpret_cast<hipStream_t>(stream));
+}
+
+int splatraster_activate_backward(int32_t P, int32_t sh_coeffs, int32_t active_sh_degree, int32_t scaling_cols,
+                                  int32_t extras, const float* xyz, const float* f_dc, const float* f_rest,
+                                  const float* scaling, const float* rotation, const float* opacity,
+                                  const float* campos, const float* dL_dscales, const float* dL_drotations,
+                                  const float* dL_dopacities, const float* dL_dcolors, float* dL_dxyz,
+                                  float* dL_df_dc, float* dL_df_rest, float* dL_dscaling, float* dL_drotation,
+                                  float* dL_dopacity, float* dL_dextra, void* stream)
+{
+    int st = check_activate(P, sh_coeffs, active_sh_degree, scaling_cols, extras, f_rest, dL_dextra);
+    if (st) return st;
+    if (P == 0) return SPLATRASTER_OK;
+    if (!xyz || !f_dc || !scaling || !rotation || !opacity || !dL_dscales || !dL_drotations || !dL_dopacities ||
+        !dL_dcolors || !dL_df_dc || !dL_dscaling || !dL_drotation || !dL_dopacity)
+        return SPLATRASTER_ERR_BAD_ARG;
+    if (sh_coeffs > 1 && !dL_df_rest) return SPLATRASTER_ERR_BAD_ARG;
+    if (active_sh_degree > 0 && !campos) return SPLATRASTER_ERR_BAD_ARG;
+    return launch_activate_bwd(P, sh_coeffs, active_sh_degree, scaling_cols, extras, xyz, f_dc, f_rest, scaling,
+                               rotation, opacity, campos, dL_dscales, dL_drotations, dL_dopacities, dL_dcolors,
+                               dL_dxyz, dL_df_dc, dL_df_rest, dL_dscaling, dL_drotation, dL_dopacity, dL_dextra,
+                               reinterpret_cast<hipStream_t>(stream));
+}
+
 int splatknn_dist2(int32_t N, const float* points, float* out, void* workspace, void* stream)
 {
     if (N < 0) return SPLATRASTER_ERR_BAD_ARG;

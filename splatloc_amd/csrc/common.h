@@ -128,6 +128,17 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, co
                                       E dx dy, E dy^2, E, w g_D*/,
                          hipStream_t stream);
 
+int launch_activate_fwd(int32_t P, int32_t K, int32_t deg, int32_t SC, int32_t E, const float* xyz,
+                        const float* f_dc, const float* f_rest, const float* scaling, const float* rotation,
+                        const float* opacity, const float* extra, const float* campos, float* scales,
+                        float* rotations, float* opacities, float* colors, hipStream_t stream);
+int launch_activate_bwd(int32_t P, int32_t K, int32_t deg, int32_t SC, int32_t E, const float* xyz,
+                        const float* f_dc, const float* f_rest, const float* scaling, const float* rotation,
+                        const float* opacity, const float* campos, const float* g_scales,
+                        const float* g_rotations, const float* g_opacities, const float* g_colors, float* d_xyz,
+                        float* d_f_dc, float* d_f_rest, float* d_scaling, float* d_rotation, float* d_opacity,
+                        float* d_extra, hipStream_t stream);
+
 int knn_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream);
 size_t knn_workspace_bytes(int32_t N);
 
