@@ -154,6 +154,85 @@ def bench_activations(args, dev):
     }), flush=True)
 
 
+def bench_loss(args, dev):
+    """--stage loss: the fused per-view mapping loss + gradient (SURVEY.md §8f-2,
+    splatloc_amd.losses) at 1920x1080 next to the reference's chain of torch ops on the same GPU."""
+    import ctypes as C
+    from splatloc_amd import _native
+    from splatloc_amd.losses import mapping_loss_tensors
+    H, W = 1080, 1920
+    g = torch.Generator().manual_seed(3)
+    image = torch.rand(3, H, W, generator=g).to(dev).requires_grad_(True)
+    depth = (0.5 + 3 * torch.rand(1, H, W, generator=g)).to(dev).requires_grad_(True)
+    marker = (2 * torch.randn(H, W, generator=g)).to(dev).requires_grad_(True)
+    gt_image, gt_depth = torch.rand(3, H, W, generator=g).to(dev), (0.5 + 3 * torch.rand(H, W, generator=g)).to(dev)
+    kp = (torch.rand(H, W, generator=g) > 0.9).to(dev)
+    a = torch.tensor([0.05], device=dev, requires_grad=True)
+    b = torch.tensor([0.02], device=dev, requires_grad=True)
+    leaves = [image, depth, marker, a, b]
+
+    def fused():
+        mapping_loss_tensors(image, depth, marker, gt_image, gt_depth, kp, 0.01, a, b).backward()
+
+    def composed():  # utils/utils.py:55-82 + train_gaussians.py:38-42
+        x = torch.exp(a) * image + b
+        m = (gt_image.sum(dim=0) > 0.01).view(*depth.shape)
+        md = (gt_depth[None] > 0.01).view(*depth.shape)
+        loss = torch.abs(x * m - gt_image * m).mean() + torch.abs(depth * md - gt_depth[None] * md).mean() \
+            + torch.nn.functional.binary_cross_entropy(torch.sigmoid(marker.view(-1)), kp.view(-1).float(),
+                                                       reduction="mean")
+        loss.backward()
+
+    lib = _native.load()
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    with torch.no_grad():
+        gi, gd, gm = torch.empty_like(image), torch.empty_like(depth), torch.empty_like(marker)
+        out = torch.empty(4, device=dev)
+        ex = torch.cat((a, b)).detach()
+        k8 = kp.to(torch.uint8)
+        ws = torch.empty(lib.splatraster_mapping_loss_workspace_bytes(H * W), dtype=torch.uint8, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def kernels():
+        _native.check(lib.splatraster_mapping_loss(H * W, p(image), p(depth), p(marker), p(gt_image), p(gt_depth), p(k8),
+                                                   C.c_float(0.01), p(ex), p(gi), p(gd), p(gm), p(out), p(ws), st),
+                      "mapping_loss")
+
+    def time_it(fn):
+        for _ in range(args.warmup):
+            for t in leaves:
+                t.grad = None
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.steps):
+            for t in leaves:
+                t.grad = None
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / args.steps * 1e3, e0.elapsed_time(e1) / args.steps
+
+    wall_f, _ = time_it(fused)
+    wall_c, _ = time_it(composed)
+    _, gpu_k = time_it(kernels)
+    nbytes = H * W * (9 * 4 + 1 + 5 * 4)
+    ach = nbytes / (gpu_k * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "mapping loss + gradient passes/s at 1920x1080 (SURVEY 8f-2 stage; NOT the BASELINE metric)",
+        "value": round(1e3 / wall_f, 1), "unit": "passes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall_f, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "1920x1080 frame: L1 RGB (exposure affine, masks) + L1 depth + BCE marker"},
+        "roofline": {"bound": "hbm", "kernel": "mapping_loss_kernel (+ finish)", "achieved": round(ach, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernels_ms": round(gpu_k, 4), "algorithmic_bytes": nbytes},
+        "through_autograd": {"ms_per_step": round(wall_f, 4)},
+        "torch_ops_same_gpu": {"ms_per_step": round(wall_c, 4), "speedup_wall": round(wall_c / wall_f, 2)},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,7 +241,7 @@ def main():
     ap.add_argument("--workload", default="S2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
-    ap.add_argument("--stage", default="raster", choices=["raster", "activations"],
+    ap.add_argument("--stage", default="raster", choices=["raster", "activations", "loss"],
                     help="raster = the BASELINE metric (default); activations = the fused front-end stage alone")
     args = ap.parse_args()
 
@@ -185,9 +264,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.stage == "activations":
+    if args.stage in ("activations", "loss"):
         if rank == 0:
-            bench_activations(args, dev)
+            (bench_activations if args.stage == "activations" else bench_loss)(args, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -229,6 +229,22 @@ int splatraster_activate_backward(int32_t P, int32_t sh_coeffs, int32_t active_s
                                   float* dL_dxyz, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling,
                                   float* dL_drotation, float* dL_dopacity, float* dL_dextra, void* stream);
 
+/* ---- per-view mapping loss + gradient ---------------------------------- */
+
+/* loss = get_loss_mapping(config, image, depth, viewpoint, opacity) (utils/utils.py:55-82; exposure
+ * affine exp(a) image + b unless exposure == NULL, i.e. initialization=True)
+ *      + get_loss_marker(config, marker, viewpoint.kp_score) (train_gaussians.py:38-42),
+ * the per-view sum of train_gaussians.py:217-218, and its gradient w.r.t. the rendered buffers,
+ * in one pass.  image / g_image are 3 planes of H*W floats with plane stride H*W (they may point
+ * into a [C,H,W] render and its gradient), marker / g_marker one plane.  kp is the uint8 (bool)
+ * key-point mask.  out[4] = { rgbd loss, marker loss, dL/dexposure_a, dL/dexposure_b } (device). */
+size_t splatraster_mapping_loss_workspace_bytes(int32_t pixels);
+int splatraster_mapping_loss(int32_t pixels, const float* image, const float* depth, const float* marker,
+                             const float* gt_image, const float* gt_depth, const uint8_t* kp,
+                             float rgb_boundary_threshold, const float* exposure /* [2] = a, b or NULL */,
+                             float* g_image, float* g_depth, float* g_marker, float* out /* [4] */,
+                             void* workspace, void* stream);
+
 /* ---- simple_knn._C.distCUDA2 (gaussian_model.py:206) ---------------------------------- */
 
 size_t splatknn_workspace_bytes(int32_t N);

@@ -1,0 +1,52 @@
+"""CPU oracle of SplatLoc's per-view mapping loss and its gradients — numpy
+restatement of the reference's in-tree Python.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/ (and nothing on the product path).
+Parity status: PINNED by tests/golden/mapping_loss.npz and tests/golden/loss.npz (values and
+autograd gradients recorded from the reference's own functions;
+tests/golden/make_golden_losses.py, make_golden.py).
+
+  loss = mean |m_rgb x - m_rgb gt| + mean |m_d depth - m_d gt_depth| + mean BCE(sigmoid(marker), kp)
+     x      = exp(exposure_a) image + exposure_b        (image itself at initialization)   utils/utils.py:55-61
+     m_rgb  = sum_c gt[c] > rgb_boundary_threshold,  m_d = gt_depth > 0.01               utils/utils.py:74-75
+     L1 terms: means over 3 H W and H W elements                                          utils/utils.py:77-81
+     BCE: torch.nn.functional.binary_cross_entropy (log clamped at -100), mean            train_gaussians.py:38-42
+  summed per view exactly as SplatLoc.map does (train_gaussians.py:217-218).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def mapping_loss(image, depth, marker, gt_image, gt_depth, kp, rgb_boundary_threshold, exposure_a=None,
+                 exposure_b=None):
+    """Returns dict(loss_rgbd, loss_bce, dL_dimage, dL_ddepth, dL_dmarker, dL_dexposure_a, dL_dexposure_b);
+    the forward sums in float32 like torch, the gradients are exact (float64)."""
+    f32 = np.float32
+    image, depth, marker = np.asarray(image, f32), np.asarray(depth, f32).reshape(1, *np.shape(marker)), np.asarray(marker, f32)
+    gt_image, gt_depth = np.asarray(gt_image, f32), np.asarray(gt_depth, f32).reshape(depth.shape)
+    y = np.asarray(kp).astype(f32)
+    H, W = marker.shape
+    use_exp = exposure_a is not None
+    ea = f32(np.exp(f32(exposure_a))) if use_exp else f32(1.0)
+    eb = f32(exposure_b) if use_exp else f32(0.0)
+    x = ea * image + eb if use_exp else image
+    m_rgb = (gt_image.sum(axis=0) > f32(rgb_boundary_threshold)).reshape(1, H, W).astype(f32)
+    m_d = (gt_depth > f32(0.01)).astype(f32)
+    diff = x * m_rgb - gt_image * m_rgb
+    diffd = depth * m_d - gt_depth * m_d
+    l_rgbd = np.abs(diff).mean(dtype=np.float64) + np.abs(diffd).mean(dtype=np.float64)
+    with np.errstate(over="ignore"):
+        p = (1.0 / (1.0 + np.exp(-marker))).astype(f32)
+    with np.errstate(divide="ignore"):
+        logp = np.maximum(np.log(p), f32(-100.0))
+        log1p = np.maximum(np.log(f32(1.0) - p), f32(-100.0))
+    l_bce = (-(y * logp + (1.0 - y) * log1p)).mean(dtype=np.float64)
+    n_rgb, n = 3.0 * H * W, 1.0 * H * W
+    g_x = np.sign(diff).astype(np.float64) * m_rgb / n_rgb
+    p64 = p.astype(np.float64)
+    g_marker = (p64 - y) / np.maximum((1.0 - p64) * p64, 1e-12) * (p64 * (1.0 - p64)) / n
+    return dict(loss_rgbd=l_rgbd, loss_bce=l_bce, dL_dimage=g_x * float(ea),
+                dL_ddepth=np.sign(diffd).astype(np.float64) * m_d / n, dL_dmarker=g_marker,
+                dL_dexposure_a=float((g_x * image).sum() * float(ea)) if use_exp else 0.0,
+                dL_dexposure_b=float(g_x.sum()) if use_exp else 0.0)

@@ -26,7 +26,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-a
 # (integer outputs derived from them are compared bit-for-bit)
 NO_CONTRACT = {"preprocess.hip", "binning.hip", "knn.hip"}
 SOURCES = ["preprocess.hip", "preprocess_bwd.hip", "scan_sort.hip", "binning.hip", "composite_fwd.hip",
-           "composite_bwd.hip", "knn.hip", "activations.hip", "capi.hip"]
+           "composite_bwd.hip", "knn.hip", "activations.hip", "losses.hip", "capi.hip"]
 
 
 def _hipcc() -> str:

@@ -549,6 +549,21 @@ int splatraster_activate_backward(int32_t P, int32_t sh_coeffs, int32_t active_s
                                reinterpret_cast<hipStream_t>(stream));
 }
 
+size_t splatraster_mapping_loss_workspace_bytes(int32_t pixels) { return mapping_loss_workspace_bytes(pixels); }
+
+int splatraster_mapping_loss(int32_t pixels, const float* image, const float* depth, const float* marker,
+                             const float* gt_image, const float* gt_depth, const uint8_t* kp,
+                             float rgb_boundary_threshold, const float* exposure, float* g_image, float* g_depth,
+                             float* g_marker, float* out, void* workspace, void* stream)
+{
+    if (pixels <= 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (!image || !depth || !marker || !gt_image || !gt_depth || !kp || !g_image || !g_depth || !g_marker || !out ||
+        !workspace)
+        return SPLATRASTER_ERR_BAD_ARG;
+    return launch_mapping_loss(pixels, image, depth, marker, gt_image, gt_depth, kp, rgb_boundary_threshold, exposure,
+                               g_image, g_depth, g_marker, out, workspace, reinterpret_cast<hipStream_t>(stream));
+}
+
 int splatknn_dist2(int32_t N, const float* points, float* out, void* workspace, void* stream)
 {
     if (N < 0) return SPLATRASTER_ERR_BAD_ARG;

@@ -1,0 +1,96 @@
+"""Fused per-view mapping loss on the GPU: against the fixtures recorded from
+the reference's own loss functions + autograd, and against the same arithmetic in torch ops at
+the bench resolution."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_oracle_losses import GOLD, load_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+@pytest.mark.parametrize("name", ["exposure", "initialization"])
+def test_against_reference_fixture(name):
+    from splatloc_amd.losses import mapping_loss
+    c = load_case(name)
+    image, depth, marker = _t(c["image"], True), _t(c["depth"], True), _t(c["marker"], True)
+    a, b = _t(c["exposure"][:1], True), _t(c["exposure"][1:], True)
+    vp = types.SimpleNamespace(original_image=_t(c["gt_image"]), depth=c["gt_depth"], kp_score=_t(c["kp"]),
+                               exposure_a=a, exposure_b=b)
+    cfg = {"Training": {"rgb_boundary_threshold": 0.01}}
+    loss = mapping_loss(cfg, image, depth, marker, vp, initialization=(name == "initialization"))
+    want = float(c["loss"].sum())
+    assert abs(float(loss) - want) <= 3e-6 * want
+    loss.backward()
+    for t, k in ((image, "dL_dimage"), (depth, "dL_ddepth"), (marker, "dL_dmarker")):
+        ref = c[k].astype(np.float64)
+        assert np.abs(t.grad.cpu().numpy() - ref).max() <= 3e-6 * np.abs(ref).max() + 1e-12, k
+    if name == "exposure":
+        assert abs(float(a.grad) - c["dL_dexposure"][0]) <= 2e-5 * abs(c["dL_dexposure"][0])
+        assert abs(float(b.grad) - c["dL_dexposure"][1]) <= 2e-5 * abs(c["dL_dexposure"][1])
+    else:
+        assert a.grad is None and b.grad is None
+
+
+def test_first_generation_fixture_and_views_of_a_render():
+    """image / marker as views of one [4,H,W] render, exactly what render() hands to the loss."""
+    from splatloc_amd.losses import mapping_loss_tensors
+    d = np.load(os.path.join(GOLD, "loss.npz"))
+    H, W = d["marker"].shape
+    render = torch.cat((_t(d["image"]), _t(d["marker"])[None]), dim=0).requires_grad_(True)
+    depth = _t(d["depth"], True)
+    loss = mapping_loss_tensors(render[:3], depth, render[-1], _t(d["gt_image"]), _t(d["gt_depth"]), _t(d["kp"]), 0.01)
+    assert abs(float(loss) - float(d["loss"].sum())) <= 3e-6 * float(d["loss"].sum())
+    (2.0 * loss).backward()                       # upstream gradient != 1
+    ref = np.concatenate((d["dL_dimage"], d["dL_dmarker"][None]), axis=0).astype(np.float64) * 2.0
+    assert np.abs(render.grad.cpu().numpy() - ref).max() <= 3e-6 * np.abs(ref).max()
+    assert np.abs(depth.grad.cpu().numpy() - 2.0 * d["dL_ddepth"]).max() <= 3e-6 * np.abs(d["dL_ddepth"]).max() * 2
+
+
+def test_full_resolution_against_torch_ops():
+    from splatloc_amd.losses import mapping_loss_tensors
+    H, W = 1080, 1920
+    g = torch.Generator().manual_seed(3)
+    image = torch.rand(3, H, W, generator=g).to(DEV).requires_grad_(True)
+    depth = (0.5 + 3 * torch.rand(1, H, W, generator=g)).to(DEV).requires_grad_(True)
+    marker = (2 * torch.randn(H, W, generator=g)).to(DEV).requires_grad_(True)
+    gt_image = torch.rand(3, H, W, generator=g).to(DEV)
+    gt_image[:, :40] = 0
+    gt_depth = (0.5 + 3 * torch.rand(H, W, generator=g)).to(DEV)
+    gt_depth[:, :50] = 0
+    kp = (torch.rand(H, W, generator=g) > 0.9).to(DEV)
+    a = torch.tensor([0.05], device=DEV, requires_grad=True)
+    b = torch.tensor([0.02], device=DEV, requires_grad=True)
+    # utils/utils.py:55-82 + train_gaussians.py:38-42 with torch ops
+    x = torch.exp(a) * image + b
+    m = (gt_image.sum(dim=0) > 0.01).view(*depth.shape)
+    md = (gt_depth[None] > 0.01).view(*depth.shape)
+    ref = torch.abs(x * m - gt_image * m).mean() + torch.abs(depth * md - gt_depth[None] * md).mean() \
+        + torch.nn.functional.binary_cross_entropy(torch.sigmoid(marker.view(-1)), kp.view(-1).float(), reduction="mean")
+    ref.backward()
+    want = [t.grad.clone() for t in (image, depth, marker, a, b)]
+    for t in (image, depth, marker, a, b):
+        t.grad = None
+    loss = mapping_loss_tensors(image, depth, marker, gt_image, gt_depth, kp, 0.01, a, b)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * float(ref)
+    loss.backward()
+    for t, w, k in zip((image, depth, marker, a, b), want, ("image", "depth", "marker", "a", "b")):
+        scale = float(w.abs().max())
+        assert float((t.grad - w).abs().max()) <= 2e-4 * scale + 1e-12, k
+
+
+def test_cpu_tensors_raise():
+    from splatloc_amd.losses import mapping_loss_tensors
+    z = torch.zeros
+    with pytest.raises(RuntimeError):
+        mapping_loss_tensors(z(3, 4, 4), z(1, 4, 4), z(4, 4), z(3, 4, 4), z(4, 4), z(4, 4, dtype=torch.bool), 0.01)

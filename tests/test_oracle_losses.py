@@ -1,0 +1,45 @@
+"""The mapping-loss oracle (oracle/losses.py) against the fixtures recorded from the reference's
+own loss functions + autograd (tests/golden/mapping_loss.npz, loss.npz).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import losses
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_case(name):
+    d = np.load(os.path.join(GOLD, "mapping_loss.npz"))
+    return {k[len(name) + 1:]: d[k] for k in d.files if k.startswith(name + "_")}
+
+
+def check(o, c):
+    assert abs(o["loss_rgbd"] - c["loss"][0]) <= 2e-6 * abs(c["loss"][0])
+    assert abs(o["loss_bce"] - c["loss"][1]) <= 2e-6 * abs(c["loss"][1])
+    for k in ("dL_dimage", "dL_ddepth", "dL_dmarker"):
+        ref = c[k].astype(np.float64)
+        assert np.abs(o[k].reshape(ref.shape) - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-12, k
+
+
+@pytest.mark.parametrize("name", ["exposure", "initialization"])
+def test_mapping_loss_matches_reference(name):
+    c = load_case(name)
+    exp = name == "exposure"
+    o = losses.mapping_loss(c["image"], c["depth"], c["marker"], c["gt_image"], c["gt_depth"], c["kp"], 0.01,
+                            float(c["exposure"][0]) if exp else None, float(c["exposure"][1]) if exp else None)
+    check(o, c)
+    if exp:
+        assert abs(o["dL_dexposure_a"] - c["dL_dexposure"][0]) <= 1e-5 * abs(c["dL_dexposure"][0])
+        assert abs(o["dL_dexposure_b"] - c["dL_dexposure"][1]) <= 1e-5 * abs(c["dL_dexposure"][1])
+    # masked-out pixels and exact zeros of the L1 argument carry no gradient
+    assert np.all(o["dL_dimage"][:, :5, :] == 0) and np.all(o["dL_ddepth"][:, :, :7] == 0)
+    if not exp:
+        assert np.all(o["dL_dimage"][:, 10, :8] == 0) and np.all(c["dL_dimage"][:, 10, :8] == 0)
+
+
+def test_first_generation_fixture():
+    d = np.load(os.path.join(GOLD, "loss.npz"))
+    o = losses.mapping_loss(d["image"], d["depth"], d["marker"], d["gt_image"], d["gt_depth"], d["kp"], 0.01)
+    check(o, {"loss": d["loss"], "dL_dimage": d["dL_dimage"], "dL_ddepth": d["dL_ddepth"], "dL_dmarker": d["dL_dmarker"]})
