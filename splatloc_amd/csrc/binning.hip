@@ -3,7 +3,8 @@
 // The lineage sorts R = sum(tiles_touched) 64-bit (tile | depth) keys with 6 radix passes.
 // Here the same ordering (tile, depth bits, Gaussian index) is produced with far less
 // traffic:
-//   1. stable sort of the P Gaussians by depth bits (32-bit keys, P elements);
+//   1. stable sort of the P Gaussians by depth bits (32-bit keys, P elements; the keys are
+//      written by preprocess_kernel);
 //   2. instances are emitted IN DEPTH ORDER, one thread per instance (coalesced writes);
 //   3. a stable sort of the R instances on the tile id only (<= 16 bits, 2 passes).
 // Because both sorts are stable, ties resolve exactly as in the 64-bit formulation.
@@ -16,27 +17,6 @@ __device__ __forceinline__ int f2i_sat_b(float v)
     if (!(v > -1.0e9f)) v = -1.0e9f;
     if (!(v < 1.0e9f)) v = 1.0e9f;
     return (int)v;
-}
-
-__global__ void __launch_bounds__(256)
-depth_keys_kernel(int P, const float4* __restrict__ rec, uint32_t* __restrict__ keys,
-                  uint32_t* __restrict__ vals)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    // view depth > 0.2 for every visible Gaussian, so its IEEE bits order like the value
-    const float4 r = rec[2 * i];
-    keys[i] = r.w > 0.f ? __float_as_uint(r.z) : 0xFFFFFFFFu;
-    vals[i] = (uint32_t)i;
-}
-
-int launch_depth_keys(int32_t P, const GeomView& g, hipStream_t stream)
-{
-    if (P == 0) return SPLATRASTER_OK;
-    hipLaunchKernelGGL(depth_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.rec, g.sort_keys,
-                       g.depth_order);
-    SR_LAUNCH_CHECK();
-    return SPLATRASTER_OK;
 }
 
 // Instance j belongs to the Gaussian of depth rank r = first r with offsets[r] > j (offsets =

@@ -298,8 +298,6 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
     SR_HIP_CHECK(hipEventRecord(slot->ev, stream));
     {
         StageTimer t(SPLATRASTER_STAGE_DEPTH_SORT, stream);
-        st = launch_depth_keys(P, g, stream);
-        if (st) return st;
         bool in_alt = false;
         uint32_t* keys_alt = reinterpret_cast<uint32_t*>(base + L.keys_alt);
         uint32_t* vals_alt = reinterpret_cast<uint32_t*>(base + L.vals_alt);

@@ -102,7 +102,6 @@ size_t scan_tmp_bytes(int64_t n);
 int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_t* out, uint32_t* total,
                        void* tmp, hipStream_t stream);
 
-int launch_depth_keys(int32_t P, const GeomView& g, hipStream_t stream);
 int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
                 uint32_t* vals, hipStream_t stream);
 int launch_ranges(int64_t R, int32_t tiles, const uint32_t* tile_list, uint32_t* ranges, hipStream_t stream);

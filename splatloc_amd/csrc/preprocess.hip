@@ -95,7 +95,8 @@ preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale
                   const float* __restrict__ campos_p,
                   float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
                   float* __restrict__ rgb, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii,
-                  uint32_t* __restrict__ block_tiles /*[gridDim.x] per-block sums of tiles_touched*/)
+                  uint32_t* __restrict__ block_tiles /*[gridDim.x] per-block sums of tiles_touched*/,
+                  uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals /*depth-sort input*/)
 {
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = gi < P;
@@ -188,6 +189,10 @@ preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale
         tiles_touched[i] = out_tiles;
         rec[2 * i] = r0;
         rec[2 * i + 1] = r1;
+        // input of the depth sort: view depth > 0.2 for every visible Gaussian, so its IEEE bits
+        // order like the value; culled Gaussians sort to the end
+        sort_keys[i] = out_radius > 0 ? __float_as_uint(tz) : 0xFFFFFFFFu;
+        sort_vals[i] = (uint32_t)i;
     }
     // The instance count R = sum of tiles_touched is needed on the HOST (it sizes the binning
     // buffer).  Per-block sums written here (no atomics, nothing to zero) are copied out and
@@ -216,7 +221,7 @@ int launch_preprocess(const splatraster_settings& s, int32_t P, const float* mea
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(PREPROCESS_BLOCK), 0, stream, P, s.image_width,
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs,
                        means3D, shs, opacities, scales, rotations, cov3D_precomp, view, proj, campos, g.rec,
-                       g.tiles_touched, g.rgb, g.clamped, radii, g.block_tiles);
+                       g.tiles_touched, g.rgb, g.clamped, radii, g.block_tiles, g.sort_keys, g.depth_order);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
