@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofli
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -218,6 +219,27 @@ def bench_loss(args, dev):
     wall_f, _ = time_it(fused)
     wall_c, _ = time_it(composed)
     _, gpu_k = time_it(kernels)
+
+    # colour-refinement loss: (1 - 0.2) L1 + 0.2 (1 - SSIM), train_gaussians.py:283-285
+    from splatloc_amd.losses import refinement_loss
+    win = torch.tensor([math.exp(-((x - 5) ** 2) / 4.5) for x in range(11)])
+    win = (win / win.sum()).to(dev)
+    win2d = (win[:, None] @ win[None, :]).expand(3, 1, 11, 11).contiguous()
+
+    def ssim_torch(a_, b_):   # loss_utils.py:72-102
+        conv = lambda t: torch.nn.functional.conv2d(t, win2d, padding=5, groups=3)  # noqa: E731
+        mu1, mu2 = conv(a_), conv(b_)
+        s1, s2, s12 = conv(a_ * a_) - mu1 * mu1, conv(b_ * b_) - mu2 * mu2, conv(a_ * b_) - mu1 * mu2
+        return (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+
+    def refine_fused():
+        refinement_loss(image, gt_image, 0.2).backward()
+
+    def refine_composed():
+        (0.8 * torch.abs(image - gt_image).mean() + 0.2 * (1.0 - ssim_torch(image[None], gt_image[None]))).backward()
+
+    wall_rf, gpu_rf = time_it(refine_fused)
+    wall_rc, gpu_rc = time_it(refine_composed)
     nbytes = H * W * (9 * 4 + 1 + 5 * 4)
     ach = nbytes / (gpu_k * 1e-3) / 1e9
     print(json.dumps({
@@ -230,6 +252,9 @@ def bench_loss(args, dev):
                      "kernels_ms": round(gpu_k, 4), "algorithmic_bytes": nbytes},
         "through_autograd": {"ms_per_step": round(wall_f, 4)},
         "torch_ops_same_gpu": {"ms_per_step": round(wall_c, 4), "speedup_wall": round(wall_c / wall_f, 2)},
+        "refinement_loss_L1_SSIM": {"fused_ms": round(wall_rf, 4), "fused_gpu_ms": round(gpu_rf, 4),
+                                    "torch_conv_chain_ms": round(wall_rc, 4), "torch_gpu_ms": round(gpu_rc, 4),
+                                    "speedup_wall": round(wall_rc / wall_rf, 2)},
     }), flush=True)
 
 

@@ -245,6 +245,16 @@ int splatraster_mapping_loss(int32_t pixels, const float* image, const float* de
                              float* g_image, float* g_depth, float* g_marker, float* out /* [4] */,
                              void* workspace, void* stream);
 
+/* Colour-refinement loss (train_gaussians.py:283-285):
+ *   loss = (1 - lambda_dssim) l1_loss(image, gt) + lambda_dssim (1 - ssim(image, gt))
+ * with l1_loss / ssim of gaussian_splatting/utils/loss_utils.py:21-22, 42-102 (11x11 Gaussian
+ * window, sigma 1.5, zero padding), and its gradient w.r.t. image.  image, gt, g_image: [C,H,W].
+ * out[3] = { l1, ssim, loss } (device). */
+size_t splatraster_refinement_loss_workspace_bytes(int32_t channels, int32_t height, int32_t width);
+int splatraster_refinement_loss(int32_t channels, int32_t height, int32_t width, float lambda_dssim,
+                                const float* image, const float* gt, float* g_image, float* out /* [3] */,
+                                void* workspace, void* stream);
+
 /* ---- simple_knn._C.distCUDA2 (gaussian_model.py:206) ---------------------------------- */
 
 size_t splatknn_workspace_bytes(int32_t N);

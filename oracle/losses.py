@@ -50,3 +50,50 @@ def mapping_loss(image, depth, marker, gt_image, gt_depth, kp, rgb_boundary_thre
                 dL_ddepth=np.sign(diffd).astype(np.float64) * m_d / n, dL_dmarker=g_marker,
                 dL_dexposure_a=float((g_x * image).sum() * float(ea)) if use_exp else 0.0,
                 dL_dexposure_b=float(g_x.sum()) if use_exp else 0.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# colour-refinement loss: (1 - lambda) L1 + lambda (1 - SSIM)
+#   l1_loss   gaussian_splatting/utils/loss_utils.py:21-22
+#   ssim      gaussian_splatting/utils/loss_utils.py:42-102 (11x11 Gaussian window, sigma 1.5, zero
+#             padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements)
+#   combined  train_gaussians.py:283-285 (lambda_dssim)
+# Parity status: PINNED by tests/golden/refinement_loss.npz (tests/golden/make_golden_ssim.py).
+# ---------------------------------------------------------------------------------------------
+def gaussian_window(size: int = 11, sigma: float = 1.5) -> np.ndarray:
+    """loss_utils.py:42-49: float32 1-D window, normalised."""
+    g = np.array([np.exp(-((x - size // 2) ** 2) / float(2 * sigma ** 2)) for x in range(size)], dtype=np.float32)
+    return g / g.sum(dtype=np.float32)
+
+
+def _blur(a: np.ndarray, w: np.ndarray) -> np.ndarray:
+    """Zero-padded separable correlation of every [H,W] plane with w (x) w (float64)."""
+    r = len(w) // 2
+    H, W = a.shape[-2:]
+    pad = np.pad(a.astype(np.float64), [(0, 0)] * (a.ndim - 2) + [(r, r), (r, r)])
+    tmp = sum(w[k] * pad[..., :, k:k + W] for k in range(len(w)))
+    return sum(w[k] * tmp[..., k:k + H, :] for k in range(len(w)))
+
+
+def refinement_loss(image, gt, lambda_dssim: float = 0.2):
+    """Returns dict(l1, ssim, loss, dL_dimage) — float64 restatement (the window itself is the
+    reference's float32 window)."""
+    x, y = np.asarray(image, np.float64), np.asarray(gt, np.float64)
+    w = gaussian_window().astype(np.float64)
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    mu1, mu2 = _blur(x, w), _blur(y, w)
+    s1, s2, s12 = _blur(x * x, w), _blur(y * y, w), _blur(x * y, w)
+    sig1, sig2, sig12 = s1 - mu1 * mu1, s2 - mu2 * mu2, s12 - mu1 * mu2
+    A, B = 2 * mu1 * mu2 + C1, 2 * sig12 + C2
+    Cc, D = mu1 * mu1 + mu2 * mu2 + C1, sig1 + sig2 + C2
+    m = A * B / (Cc * D)
+    n = x.size
+    l1 = np.abs(x - y).mean()
+    ssim = m.mean()
+    # d m / d(mu1, s1, s12) with s1 = blur(x^2), s12 = blur(x y) held as independent inputs
+    dm_dmu1 = (2 * mu2 * (B - A) * Cc * D - A * B * 2 * mu1 * (D - Cc)) / (Cc * D) ** 2
+    dm_ds1 = -A * B / (Cc * D * D)
+    dm_ds12 = 2 * A / (Cc * D)
+    dssim_dx = (_blur(dm_dmu1, w) + 2 * x * _blur(dm_ds1, w) + y * _blur(dm_ds12, w)) / n
+    grad = (1.0 - lambda_dssim) * np.sign(x - y) / n - lambda_dssim * dssim_dx
+    return dict(l1=l1, ssim=ssim, loss=(1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim), dL_dimage=grad)

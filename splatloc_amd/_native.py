@@ -71,6 +71,8 @@ SYMBOLS = {
     "splatraster_activate_backward": (C.c_int, [_i32] * 5 + [_vp] * 19),
     "splatraster_mapping_loss_workspace_bytes": (_sz, [_i32]),
     "splatraster_mapping_loss": (C.c_int, [_i32] + [_vp] * 6 + [C.c_float] + [_vp] * 7),
+    "splatraster_refinement_loss_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "splatraster_refinement_loss": (C.c_int, [_i32, _i32, _i32, C.c_float] + [_vp] * 6),
     "splatraster_error_string": (C.c_char_p, [C.c_int]),
     "splatraster_last_hip_error": (C.c_char_p, []),
     "splatraster_abi_version": (C.c_int, []),

@@ -562,6 +562,22 @@ int splatraster_mapping_loss(int32_t pixels, const float* image, const float* de
                                g_image, g_depth, g_marker, out, workspace, reinterpret_cast<hipStream_t>(stream));
 }
 
+size_t splatraster_refinement_loss_workspace_bytes(int32_t channels, int32_t height, int32_t width)
+{
+    if (channels <= 0 || height <= 0 || width <= 0) return 0;
+    return refinement_loss_workspace_bytes(channels, height, width);
+}
+
+int splatraster_refinement_loss(int32_t channels, int32_t height, int32_t width, float lambda_dssim,
+                                const float* image, const float* gt, float* g_image, float* out, void* workspace,
+                                void* stream)
+{
+    if (channels <= 0 || height <= 0 || width <= 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (!image || !gt || !g_image || !out || !workspace) return SPLATRASTER_ERR_BAD_ARG;
+    return launch_refinement_loss(channels, height, width, lambda_dssim, image, gt, g_image, out, workspace,
+                                  reinterpret_cast<hipStream_t>(stream));
+}
+
 int splatknn_dist2(int32_t N, const float* points, float* out, void* workspace, void* stream)
 {
     if (N < 0) return SPLATRASTER_ERR_BAD_ARG;

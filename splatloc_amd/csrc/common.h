@@ -144,6 +144,10 @@ int launch_mapping_loss(int32_t HW, const float* image, const float* depth, cons
                         const float* exposure, float* g_image, float* g_depth, float* g_marker, float* out,
                         void* workspace, hipStream_t stream);
 
+size_t refinement_loss_workspace_bytes(int32_t C, int32_t H, int32_t W);
+int launch_refinement_loss(int32_t C, int32_t H, int32_t W, float lambda, const float* image, const float* gt,
+                           float* g_image, float* out, void* workspace, hipStream_t stream);
+
 int knn_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream);
 size_t knn_workspace_bytes(int32_t N);
 

@@ -127,4 +127,211 @@ int launch_mapping_loss(int32_t HW, const float* image, const float* depth, cons
     return SPLATRASTER_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Colour-refinement loss (train_gaussians.py:283-285):
+//     loss = (1 - lambda) l1_loss(image, gt) + lambda (1 - ssim(image, gt))
+// l1_loss / ssim: gaussian_splatting/utils/loss_utils.py:21-22, 42-102 (11x11 Gaussian window,
+// sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements).
+// The reference runs 5 dense 11x11 grouped convolutions forward and their autograd backward;
+// here the window is applied separably out of LDS, in two kernels:
+//   refine_fwd: per 16x16 tile (+5 halo) blur(x, y, x^2, y^2, xy) -> SSIM map value and its
+//               partials dm/dmu1, dm/ds1, dm/ds12 (s1 = blur(x^2), s12 = blur(xy)); tile sums of m
+//               and |x - y|
+//   refine_bwd: dL/dx = (1-lambda) sign(x-y)/n - lambda/n (blur(dm/dmu1) + 2 x blur(dm/ds1) + y blur(dm/ds12))
+// (the window is symmetric, so the adjoint of the zero-padded convolution is the same blur).
+// ---------------------------------------------------------------------------------------------
+constexpr int RT = 16;            // tile edge
+constexpr int RH = 5;             // window radius
+constexpr int RW = 2 * RH + 1;    // 11 taps
+constexpr int RE = RT + 2 * RH;   // 26: tile + halo
+
+struct RefineWindow { float w[RW]; };
+
+__global__ void __launch_bounds__(RT * RT)
+refine_fwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, RefineWindow win,
+                  float* __restrict__ dm_dmu1, float* __restrict__ dm_ds1, float* __restrict__ dm_ds12,
+                  double* __restrict__ partial /*[blocks][2]: sum m, sum |x-y|*/)
+{
+    __shared__ float s_x[RE][RE + 1], s_y[RE][RE + 1];
+    __shared__ float s_h[5][RE][RT + 1];
+    __shared__ double s_red[RT * RT / WAVE][2];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * RT, y0 = blockIdx.y * RT;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int e = tid; e < RE * RE; e += RT * RT) {
+        const int r = e / RE, c = e - r * RE;
+        const int gy = y0 + r - RH, gx = x0 + c - RH;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        s_x[r][c] = in ? img[plane + (size_t)gy * W + gx] : 0.0f;
+        s_y[r][c] = in ? gt[plane + (size_t)gy * W + gx] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = tid; e < RE * RT; e += RT * RT) {   // horizontal pass: RE rows x RT columns
+        const int r = e / RT, c = e - r * RT;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+            const float xv = s_x[r][c + k], yv = s_y[r][c + k], wk = win.w[k];
+            a0 += wk * xv;
+            a1 += wk * yv;
+            a2 += wk * (xv * xv);
+            a3 += wk * (yv * yv);
+            a4 += wk * (xv * yv);
+        }
+        s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2; s_h[3][r][c] = a3; s_h[4][r][c] = a4;
+    }
+    __syncthreads();
+    const int ty = tid / RT, tx = tid - ty * RT;
+    const int gy = y0 + ty, gx = x0 + tx;
+    double msum = 0.0, lsum = 0.0;
+    if (gy < H && gx < W) {
+        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+            const float wk = win.w[k];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) v[q] += wk * s_h[q][ty + k][tx];
+        }
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1 = v[0], mu2 = v[1];
+        const float sig1 = v[2] - mu1 * mu1, sig2 = v[3] - mu2 * mu2, sig12 = v[4] - mu1 * mu2;
+        const float A = 2.0f * mu1 * mu2 + C1, B = 2.0f * sig12 + C2;
+        const float Cc = mu1 * mu1 + mu2 * mu2 + C1, D = sig1 + sig2 + C2;
+        const float icd = 1.0f / (Cc * D);
+        const float m = A * B * icd;
+        const size_t o = plane + (size_t)gy * W + gx;
+        dm_dmu1[o] = (2.0f * mu2 * (B - A) * Cc * D - A * B * 2.0f * mu1 * (D - Cc)) * icd * icd;
+        dm_ds1[o] = -m / D;
+        dm_ds12[o] = 2.0f * A * icd;
+        msum = (double)m;
+        lsum = (double)fabsf(s_x[ty + RH][tx + RH] - s_y[ty + RH][tx + RH]);
+    }
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        msum += __shfl_xor(msum, d, WAVE);
+        lsum += __shfl_xor(lsum, d, WAVE);
+    }
+    if ((tid & (WAVE - 1)) == 0) { s_red[tid / WAVE][0] = msum; s_red[tid / WAVE][1] = lsum; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0, b = 0;
+        for (int w = 0; w < RT * RT / WAVE; ++w) { a += s_red[w][0]; b += s_red[w][1]; }
+        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[2 * bid] = a;
+        partial[2 * bid + 1] = b;
+    }
+}
+
+__global__ void __launch_bounds__(RT * RT)
+refine_bwd_kernel(int H, int W, float n_total, float lambda, const float* __restrict__ img,
+                  const float* __restrict__ gt, RefineWindow win, const float* __restrict__ dm_dmu1,
+                  const float* __restrict__ dm_ds1, const float* __restrict__ dm_ds12, float* __restrict__ g_img)
+{
+    __shared__ float s_m[3][RE][RE + 1];
+    __shared__ float s_h[3][RE][RT + 1];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * RT, y0 = blockIdx.y * RT;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int e = tid; e < RE * RE; e += RT * RT) {
+        const int r = e / RE, c = e - r * RE;
+        const int gy = y0 + r - RH, gx = x0 + c - RH;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t o = plane + (size_t)gy * W + gx;
+        s_m[0][r][c] = in ? dm_dmu1[o] : 0.0f;
+        s_m[1][r][c] = in ? dm_ds1[o] : 0.0f;
+        s_m[2][r][c] = in ? dm_ds12[o] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = tid; e < RE * RT; e += RT * RT) {
+        const int r = e / RT, c = e - r * RT;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+            const float wk = win.w[k];
+            a0 += wk * s_m[0][r][c + k];
+            a1 += wk * s_m[1][r][c + k];
+            a2 += wk * s_m[2][r][c + k];
+        }
+        s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2;
+    }
+    __syncthreads();
+    const int ty = tid / RT, tx = tid - ty * RT;
+    const int gy = y0 + ty, gx = x0 + tx;
+    if (gy >= H || gx >= W) return;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+        const float wk = win.w[k];
+        b0 += wk * s_h[0][ty + k][tx];
+        b1 += wk * s_h[1][ty + k][tx];
+        b2 += wk * s_h[2][ty + k][tx];
+    }
+    const size_t o = plane + (size_t)gy * W + gx;
+    const float x = img[o], y = gt[o];
+    const float inv_n = 1.0f / n_total;
+    g_img[o] = (1.0f - lambda) * sgn(x - y) * inv_n - lambda * inv_n * (b0 + 2.0f * x * b1 + y * b2);
+}
+
+__global__ void __launch_bounds__(LOSS_BLOCK)
+refine_finish_kernel(int blocks, double n_total, float lambda, const double* __restrict__ partial,
+                     float* __restrict__ out /*[3] = l1, ssim, loss*/)
+{
+    __shared__ double s_red[LOSS_BLOCK / WAVE][2];
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < blocks; i += blockDim.x) { a += partial[2 * (size_t)i]; b += partial[2 * (size_t)i + 1]; }
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { a += __shfl_xor(a, d, WAVE); b += __shfl_xor(b, d, WAVE); }
+    if ((threadIdx.x & (WAVE - 1)) == 0) { s_red[threadIdx.x / WAVE][0] = a; s_red[threadIdx.x / WAVE][1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = 0, l = 0;
+        for (int w = 0; w < LOSS_BLOCK / WAVE; ++w) { m += s_red[w][0]; l += s_red[w][1]; }
+        const double ssim = m / n_total, l1 = l / n_total;
+        out[0] = (float)l1;
+        out[1] = (float)ssim;
+        out[2] = (float)((1.0 - (double)lambda) * l1 + (double)lambda * (1.0 - ssim));
+    }
+}
+
+static RefineWindow refine_window()
+{
+    // loss_utils.py:42-49: exp in double -> float32 tensor -> divided by its float32 sum
+    RefineWindow win;
+    float sum = 0.f;
+    for (int k = 0; k < RW; ++k) {
+        win.w[k] = (float)exp(-(double)((k - RH) * (k - RH)) / (2.0 * 1.5 * 1.5));
+        sum += win.w[k];
+    }
+    for (int k = 0; k < RW; ++k) win.w[k] /= sum;
+    return win;
+}
+
+size_t refinement_loss_workspace_bytes(int32_t C, int32_t H, int32_t W)
+{
+    const size_t blocks = (size_t)((W + RT - 1) / RT) * ((H + RT - 1) / RT) * (size_t)C;
+    return align_up(3 * sizeof(float) * (size_t)C * H * W, 256) + blocks * 2 * sizeof(double);
+}
+
+int launch_refinement_loss(int32_t C, int32_t H, int32_t W, float lambda, const float* image, const float* gt,
+                           float* g_image, float* out, void* workspace, hipStream_t stream)
+{
+    const size_t n = (size_t)C * H * W;
+    float* maps = reinterpret_cast<float*>(workspace);
+    double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + align_up(3 * sizeof(float) * n, 256));
+    const dim3 grid((W + RT - 1) / RT, (H + RT - 1) / RT, C);
+    const int blocks = (int)(grid.x * grid.y * grid.z);
+    const RefineWindow win = refine_window();
+    hipLaunchKernelGGL(refine_fwd_kernel, grid, dim3(RT * RT), 0, stream, H, W, image, gt, win, maps, maps + n,
+                       maps + 2 * n, partial);
+    SR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(refine_bwd_kernel, grid, dim3(RT * RT), 0, stream, H, W, (float)n, lambda, image, gt, win, maps,
+                       maps + n, maps + 2 * n, g_image);
+    SR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(refine_finish_kernel, dim3(1), dim3(LOSS_BLOCK), 0, stream, blocks, (double)n, lambda, partial,
+                       out);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
 }  // namespace sr

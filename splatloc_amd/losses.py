@@ -79,3 +79,51 @@ def mapping_loss(config, image, depth, marker, viewpoint, initialization: bool =
     b = None if initialization else viewpoint.exposure_b
     return mapping_loss_tensors(image, depth, marker, viewpoint.original_image.to(dev), gt_depth,
                                 viewpoint.kp_score.to(dev), thr, a, b)
+
+
+class _RefinementLoss(torch.autograd.Function):
+    """mode 0: (1 - lambda) L1 + lambda (1 - SSIM);  mode 1: SSIM;  mode 2: L1."""
+
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim: float, mode: int):
+        lib = _native.load()
+        _require_gpu(image, "image")
+        dev = image.device
+        if image.dim() != 3 or tuple(image.shape) != tuple(gt.shape):
+            raise RuntimeError("refinement_loss: expected image and gt of the same [C,H,W] shape")
+        Cn, H, W = (int(v) for v in image.shape)
+        lam = {0: float(lambda_dssim), 1: 1.0, 2: 0.0}[mode]
+        im, g = _prep(image, dev), _prep(gt, dev)
+        g_image = torch.empty((Cn, H, W), dtype=torch.float32, device=dev)
+        out = torch.empty((3,), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.splatraster_refinement_loss_workspace_bytes(Cn, H, W),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(lib.splatraster_refinement_loss(Cn, H, W, C.c_float(lam), _ptr(im), _ptr(g), _ptr(g_image),
+                                                          _ptr(out), _ptr(ws), _stream(dev)), "refinement_loss")
+        ctx.save_for_backward(g_image)
+        ctx.sign = -1.0 if mode == 1 else 1.0     # the kernel's gradient is that of lambda (1 - ssim)
+        return out[{0: 2, 1: 1, 2: 0}[mode]]
+
+    @staticmethod
+    def backward(ctx, g):
+        (g_image,) = ctx.saved_tensors
+        return (ctx.sign * g) * g_image, None, None, None
+
+
+def refinement_loss(image, gt, lambda_dssim: float = 0.2):
+    """(1 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1 - ssim(image, gt)) — the
+    colour-refinement loss of train_gaussians.py:283-285 — value and image gradient in two HIP
+    kernels instead of five 11x11 grouped convolutions and their autograd backward."""
+    return _RefinementLoss.apply(image, gt, float(lambda_dssim), 0)
+
+
+def ssim(img1, img2, window_size: int = 11, size_average: bool = True):
+    """gaussian_splatting/utils/loss_utils.py:61-70 (the configuration SplatLoc uses)."""
+    if window_size != 11 or not size_average:
+        raise RuntimeError("ssim: only window_size=11, size_average=True is implemented on the HIP path")
+    return _RefinementLoss.apply(img1, img2, 1.0, 1)
+
+
+def l1_loss(network_output, gt):
+    """gaussian_splatting/utils/loss_utils.py:21-22."""
+    return _RefinementLoss.apply(network_output, gt, 0.0, 2)

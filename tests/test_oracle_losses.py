@@ -43,3 +43,21 @@ def test_first_generation_fixture():
     d = np.load(os.path.join(GOLD, "loss.npz"))
     o = losses.mapping_loss(d["image"], d["depth"], d["marker"], d["gt_image"], d["gt_depth"], d["kp"], 0.01)
     check(o, {"loss": d["loss"], "dL_dimage": d["dL_dimage"], "dL_ddepth": d["dL_ddepth"], "dL_dmarker": d["dL_dmarker"]})
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_refinement_loss_matches_reference(name):
+    """(1 - lambda) L1 + lambda (1 - SSIM): value, both terms and the image gradient of the
+    reference's l1_loss / ssim + autograd (loss_utils.py:21-102, train_gaussians.py:283-285)."""
+    d = np.load(os.path.join(GOLD, "refinement_loss.npz"))
+    o = losses.refinement_loss(d[name + "_image"], d[name + "_gt"], float(d["lambda_dssim"]))
+    l1, ssim, loss = d[name + "_terms"]
+    assert abs(o["l1"] - l1) <= 2e-6 * l1 and abs(o["ssim"] - ssim) <= 5e-6 * ssim and abs(o["loss"] - loss) <= 5e-6 * loss
+    ref = d[name + "_dL_dimage"].astype(np.float64)
+    assert np.abs(o["dL_dimage"] - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert np.all(o["dL_dimage"][:, -1, :3] * 0 == 0)
+
+
+def test_gaussian_window_is_the_reference_window():
+    w = losses.gaussian_window()
+    assert w.dtype == np.float32 and abs(float(w.sum()) - 1.0) < 1e-6 and w.argmax() == 5 and len(w) == 11
