@@ -108,3 +108,36 @@ def test_everything_behind_or_beside_the_camera():
     assert run.num_rendered == 0 and int(run.radii.abs().sum()) == 0
     for t in (run.means3D, run.colors, run.opacities, run.scales, run.rotations):
         assert float(t.grad.abs().sum()) == 0.0
+
+
+def test_sizes_change_between_calls_in_one_process():
+    """Densification changes P every few iterations and key-frames differ in size: every call
+    sizes its own buffers (the host landing slot of the instance count grows on demand)."""
+    for P, W, H, C, sm in ((500, 64, 48, 4, 0.05), (70_000, 320, 240, 4, 0.01), (3, 17, 9, 3, 0.2),
+                           (1_200_000, 96, 64, 3, 0.002), (9_000, 200, 120, 35, 0.03)):
+        sc = make_scene(P, W, H, C, seed=P % 97, scale_median=sm)
+        _run_and_check(sc, backward=(P < 100_000))
+
+
+def test_two_streams_interleaved():
+    """Frames enqueued on two different HIP streams from one host thread: results equal the
+    single-stream ones (the C ABI only ever touches the stream it is given)."""
+    sc_a = make_scene(4000, 160, 96, 4, seed=61, scale_median=0.04)
+    sc_b = make_scene(6000, 128, 128, 35, seed=62, scale_median=0.03)
+    ref_a, ref_b = HipRun(sc_a), HipRun(sc_b)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    runs = {}
+    for rep in range(3):
+        with torch.cuda.stream(s1):
+            runs["a"] = HipRun(sc_a)
+        with torch.cuda.stream(s2):
+            runs["b"] = HipRun(sc_b)
+    torch.cuda.synchronize()
+    for k, ref in (("a", ref_a), ("b", ref_b)):
+        r = runs[k]
+        assert torch.equal(r.radii, ref.radii) and r.num_rendered == ref.num_rendered
+        assert float((r.color - ref.color).abs().max()) == 0.0
+        assert float((r.depth - ref.depth).abs().max()) == 0.0
+        scale = float(ref.means3D.grad.abs().max())
+        assert float((r.means3D.grad - ref.means3D.grad).abs().max()) <= 2e-3 * scale
