@@ -145,3 +145,18 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["frames_per_step"] == 2 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["steps"] == 3 and "roofline" in out and "cpu_baseline" not in out
+
+
+@pytest.mark.parametrize("stage,extra", [("activations", []), ("loss", []), ("map_step", ["--workload", "S0"])])
+def test_bench_secondary_stages_run(stage, extra):
+    """bench.py --stage ...: the §8f stage figures and the map()-shaped step stay runnable and
+    print ONE JSON line with the contract's keys."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--stage", stage, "--steps", "3", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["unit"].endswith("/s") and "NOT the BASELINE metric" in out["metric"]
+    if stage != "map_step":
+        assert 0 < out["roofline"]["frac"] < 1
