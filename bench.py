@@ -262,12 +262,13 @@ def bench_map_step(args, dev):
     """--stage map_step: one optimisation step of SplatLoc.map (train_gaussians.py:187-267) on the
     S2 shapes — 5 views x (render -> per-view mapping loss), ONE backward, densification
     statistics, Adam over the parameter groups — with the fused front-end / loss
-    (splatloc_amd.fused.render, splatloc_amd.losses.mapping_loss) and, for comparison, with the
+    (splatloc_amd.fused.render, splatloc_amd.losses.mapping_loss, splatloc_amd.densify) and, for comparison, with the
     reference's chains of torch ops around the same rasterizer.  Secondary figure, not the
     BASELINE metric (which is the rasterizer fwd+bwd alone)."""
     import types
     from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer
     from splatloc_amd.camera import PinholeCamera
+    from splatloc_amd.densify import add_densification_stats
     from splatloc_amd.fused import render as fused_render
     from splatloc_amd.losses import mapping_loss
     from splatloc_amd.synthetic import WORKLOADS, make_workload
@@ -339,6 +340,9 @@ def bench_map_step(args, dev):
         loss.backward()
         with torch.no_grad():   # train_gaussians.py:238-246, gaussian_model.py:677-679
             for pkg in pkgs:
+                if fused:
+                    add_densification_stats(pkg["viewspace_points"].grad, pkg["radii"], accum, denom, max_radii)
+                    continue
                 vis = pkg["visibility_filter"]
                 max_radii[vis] = torch.max(max_radii[vis], pkg["radii"][vis].float())
                 accum[vis] += torch.norm(pkg["viewspace_points"].grad[vis, :2], dim=-1, keepdim=True)

@@ -229,6 +229,13 @@ int splatraster_activate_backward(int32_t P, int32_t sh_coeffs, int32_t active_s
                                   float* dL_dxyz, float* dL_df_dc, float* dL_df_rest, float* dL_dscaling,
                                   float* dL_drotation, float* dL_dopacity, float* dL_dextra, void* stream);
 
+/* Per-view densification statistics, in place: for every Gaussian with
+ * radii > 0:  max_radii2D = max(max_radii2D, radii) (train_gaussians.py:240-244),
+ * xyz_gradient_accum += ||viewspace_grad[:2]||, denom += 1 (gaussian_model.py:677-679). */
+int splatraster_densification_stats(int32_t P, const float* viewspace_grad /* [P,3] */, const int32_t* radii,
+                                    float* xyz_gradient_accum /* [P,1] */, float* denom /* [P,1] */,
+                                    float* max_radii2D /* [P] */, void* stream);
+
 /* ---- per-view mapping loss + gradient ---------------------------------- */
 
 /* loss = get_loss_mapping(config, image, depth, viewpoint, opacity) (utils/utils.py:55-82; exposure

@@ -69,6 +69,7 @@ SYMBOLS = {
     "splatknn_dist2": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "splatraster_activate_forward": (C.c_int, [_i32] * 5 + [_vp] * 13),
     "splatraster_activate_backward": (C.c_int, [_i32] * 5 + [_vp] * 19),
+    "splatraster_densification_stats": (C.c_int, [_i32] + [_vp] * 6),
     "splatraster_mapping_loss_workspace_bytes": (_sz, [_i32]),
     "splatraster_mapping_loss": (C.c_int, [_i32] + [_vp] * 6 + [C.c_float] + [_vp] * 7),
     "splatraster_refinement_loss_workspace_bytes": (_sz, [_i32, _i32, _i32]),

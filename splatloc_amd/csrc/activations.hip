@@ -267,6 +267,35 @@ activate_bwd_kernel(int P, int K, int deg, int SC, int E, const float* __restric
     }
 }
 
+// Per-view densification statistics, in place, one launch and no host round trip (the reference
+// indexes with boolean masks, i.e. a nonzero + device->host sync per statement):
+//   vis = radii > 0
+//   max_radii2D[vis] = max(max_radii2D[vis], radii[vis])                 train_gaussians.py:240-244
+//   xyz_gradient_accum[vis] += ||viewspace_grad[vis, :2]||;  denom[vis] += 1   gaussian_model.py:677-679
+__global__ void __launch_bounds__(256)
+densification_stats_kernel(int P, const float* __restrict__ vs_grad /*[P,3]*/, const int32_t* __restrict__ radii,
+                           float* __restrict__ accum, float* __restrict__ denom, float* __restrict__ max_radii)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float gx = vs_grad[3 * (size_t)i], gy = vs_grad[3 * (size_t)i + 1];
+    accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+    max_radii[i] = fmaxf(max_radii[i], (float)r);
+}
+
+int launch_densification_stats(int32_t P, const float* vs_grad, const int32_t* radii, float* accum, float* denom,
+                               float* max_radii, hipStream_t stream)
+{
+    if (P == 0) return SPLATRASTER_OK;
+    hipLaunchKernelGGL(densification_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, vs_grad, radii,
+                       accum, denom, max_radii);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
 int launch_activate_fwd(int32_t P, int32_t K, int32_t deg, int32_t SC, int32_t E, const float* xyz,
                         const float* f_dc, const float* f_rest, const float* scaling, const float* rotation,
                         const float* opacity, const float* extra, const float* campos, float* scales,

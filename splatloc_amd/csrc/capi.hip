@@ -547,6 +547,16 @@ int splatraster_activate_backward(int32_t P, int32_t sh_coeffs, int32_t active_s
                                reinterpret_cast<hipStream_t>(stream));
 }
 
+int splatraster_densification_stats(int32_t P, const float* viewspace_grad, const int32_t* radii,
+                                    float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream)
+{
+    if (P < 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (P == 0) return SPLATRASTER_OK;
+    if (!viewspace_grad || !radii || !xyz_gradient_accum || !denom || !max_radii2D) return SPLATRASTER_ERR_BAD_ARG;
+    return launch_densification_stats(P, viewspace_grad, radii, xyz_gradient_accum, denom, max_radii2D,
+                                      reinterpret_cast<hipStream_t>(stream));
+}
+
 size_t splatraster_mapping_loss_workspace_bytes(int32_t pixels) { return mapping_loss_workspace_bytes(pixels); }
 
 int splatraster_mapping_loss(int32_t pixels, const float* image, const float* depth, const float* marker,

@@ -138,6 +138,8 @@ int launch_activate_bwd(int32_t P, int32_t K, int32_t deg, int32_t SC, int32_t E
                         float* d_f_dc, float* d_f_rest, float* d_scaling, float* d_rotation, float* d_opacity,
                         float* d_extra, hipStream_t stream);
 
+int launch_densification_stats(int32_t P, const float* vs_grad, const int32_t* radii, float* accum, float* denom,
+                               float* max_radii, hipStream_t stream);
 size_t mapping_loss_workspace_bytes(int32_t HW);
 int launch_mapping_loss(int32_t HW, const float* image, const float* depth, const float* marker,
                         const float* gt_image, const float* gt_depth, const uint8_t* kp, float threshold,
