@@ -1,0 +1,38 @@
+"""Wave start/end timeline of the compositing kernels (debug build -DSR_TRACE_WAVES, 100 MHz
+s_memrealtime): resident waves over time, life-time distribution, tail."""
+import ctypes as C, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+os.environ["SPLATRASTER_LIB"] = os.path.abspath("splatloc_amd/_lib/variants/libsplatraster_trace.so")
+from splatloc_amd import _native
+from splatloc_amd.synthetic import make_workload
+from tests.helpers import HipRun
+_native.load()
+sc = make_workload("S2")
+HipRun(sc, backward=True)
+HipRun(sc, backward=True)
+torch.cuda.synchronize()
+raw = C.CDLL(os.environ["SPLATRASTER_LIB"])
+n = 32640
+for k in ("fwd", "bwd"):
+    buf = (C.c_ulonglong * (2 * n))()
+    assert getattr(raw, "splatraster_debug_trace_" + k)(buf, n) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 2).astype(np.int64)
+    t0, t1 = a[:, 0], a[:, 1]
+    ok = t1 > 0
+    t0, t1 = t0[ok], t1[ok]
+    base = t0.min()
+    s, e = (t0 - base) / 100.0, (t1 - base) / 100.0      # us
+    life = e - s
+    T = e.max()
+    print(f"== {k}: {ok.sum()} waves, kernel span {T:.0f} us; life us: mean {life.mean():.1f} p10 {np.percentile(life,10):.1f} "
+          f"p50 {np.percentile(life,50):.1f} p90 {np.percentile(life,90):.1f} max {life.max():.1f}")
+    # resident waves over time in 20 buckets
+    edges = np.linspace(0, T, 21)
+    res = [((s < edges[i + 1]) & (e > edges[i])).sum() for i in range(20)]
+    started = [((s >= edges[i]) & (s < edges[i + 1])).sum() for i in range(20)]
+    print("   resident (of 6144 / 4096 slots) per 5% of the span:", res)
+    print("   waves started per 5% of the span:", started)
+    print(f"   last wave starts at {s.max():.0f} us; time with < 50% of peak residency: "
+          f"{sum(1 for r in res if r < 0.5 * max(res)) * 5}% of the span")
