@@ -47,6 +47,10 @@
 
 namespace sr {
 
+#ifdef SR_TRACE_WAVES  // debug build for tools/wave_trace.py: per-workgroup start/end (100 MHz clock)
+__device__ unsigned long long g_trace_bwd[2 * 40960];
+#endif
+
 #ifdef SR_BWD_PROFILE
 __device__ unsigned long long g_bwd_prof[12];
 #define BP_T(v) const unsigned long long v = __builtin_readcyclecounter()
@@ -98,6 +102,19 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     __shared__ float s_w[MFMA ? WAVE * WS : 1];   // matrix-pipe weight panel w[64 pix][GROUP]
     __shared__ uint32_t s_gid[MFMA ? GROUP : 1];  // Gaussian id of every parked panel column
 
+#ifdef SR_TRACE_WAVES
+    struct TraceEnd {
+        unsigned long long t0;
+        unsigned long long* buf;
+        __device__ ~TraceEnd()
+        {
+            if (threadIdx.x == 0 && blockIdx.x < 40960) {
+                buf[2 * blockIdx.x] = t0;
+                buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+    } trace_end{__builtin_amdgcn_s_memrealtime(), g_trace_bwd};
+#endif
     int tile, quad;
     quadrant_of_block(blockIdx.x, tile, quad);
     if (tile >= tiles) return;
@@ -496,3 +513,10 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, co
 }
 
 }  // namespace sr
+
+#ifdef SR_TRACE_WAVES
+extern "C" int splatraster_debug_trace_bwd(unsigned long long* out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sr::g_trace_bwd), sizeof(unsigned long long) * 2 * (size_t)n) == hipSuccess ? 0 : 2;
+}
+#endif

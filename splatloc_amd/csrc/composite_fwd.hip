@@ -34,6 +34,10 @@
 
 namespace sr {
 
+#ifdef SR_TRACE_WAVES  // debug build for tools/wave_trace.py: per-workgroup start/end (100 MHz clock)
+__device__ unsigned long long g_trace_fwd[2 * 40960];
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // In-place half swap: afterwards x = [x.lanes0-31 | y.lanes0-31], y = [x.lanes32-63 | y.lanes32-63].
@@ -91,6 +95,19 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
     __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
     __shared__ uint32_t s_cgid[FS];
 
+#ifdef SR_TRACE_WAVES
+    struct TraceEnd {
+        unsigned long long t0;
+        unsigned long long* buf;
+        __device__ ~TraceEnd()
+        {
+            if (threadIdx.x == 0 && blockIdx.x < 40960) {
+                buf[2 * blockIdx.x] = t0;
+                buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+    } trace_end{__builtin_amdgcn_s_memrealtime(), g_trace_fwd};
+#endif
     int tile, quad;
     quadrant_of_block(blockIdx.x, tile, quad);
     if (tile >= tiles) return;
@@ -294,3 +311,10 @@ int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomVie
 }
 
 }  // namespace sr
+
+#ifdef SR_TRACE_WAVES
+extern "C" int splatraster_debug_trace_fwd(unsigned long long* out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sr::g_trace_fwd), sizeof(unsigned long long) * 2 * (size_t)n) == hipSuccess ? 0 : 2;
+}
+#endif
