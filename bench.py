@@ -28,7 +28,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BREAKDOWN_STEPS = 5    # untimed steps that collect the per-stage table
+BREAKDOWN_STEPS = 20   # untimed steps that collect the per-stage table (and bring the clocks up)
 
 
 def algorithmic_bytes(P, R, W, H, C, tiles):
