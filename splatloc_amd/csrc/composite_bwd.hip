@@ -27,6 +27,9 @@
 //     runs on the matrix pipe with v_mfma_f32_16x16x4_f32 — exact fp32 (k-ordered fmaf chain).
 #include "composite_common.h"
 
+#ifndef SR_BWD_FS
+#define SR_BWD_FS 32  // feature rows staged per round (<= 64)
+#endif
 #ifndef SR_STAGE_UNROLL
 #define SR_STAGE_UNROLL 2  // gather iterations in flight together while staging feature rows
 #endif
@@ -69,7 +72,7 @@ struct BwdCfg {
     static constexpr int NV = NC - NM;         // channels reduced with the packed butterfly
     static constexpr int KV = NV + 7;          // butterfly values per Gaussian
     static constexpr int NCP = (NC + 3) & ~3;
-    static constexpr int FS = 32;              // feature rows staged per round
+    static constexpr int FS = SR_BWD_FS;             // feature rows staged per round
     static constexpr int GROUP = 16;           // Gaussians per MFMA flush (M of v_mfma_f32_16x16x4_f32)
     static constexpr int WS = 17;              // LDS row stride of the weight panel [64 pix][GROUP]
 };

@@ -24,6 +24,9 @@
 // the two weight registers of the pair after ONE v_permlane32_swap.
 #include "composite_common.h"
 
+#ifndef SR_FWD_FS
+#define SR_FWD_FS 32  // feature rows staged per round (<= 64)
+#endif
 #ifndef SR_STAGE_UNROLL
 #define SR_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2: 1: 0.429, 2: 0.456, 3: 0.416, 5: 0.478 ms)
 #endif
@@ -73,7 +76,7 @@ struct FwdCfg {
     static constexpr int NM = MFMA ? 32 : 0;   // channels accumulated on the matrix pipe
     static constexpr int NV = NC - NM;         // channels accumulated with VALU FMAs
     static constexpr int NCP = (NC + 3) & ~3;  // LDS row stride (floats), 16-B aligned rows
-    static constexpr int FS = 32;              // feature rows staged per round
+    static constexpr int FS = SR_FWD_FS;             // feature rows staged per round
 };
 
 template <int NC>
