@@ -41,11 +41,11 @@ def algorithmic_bytes(P, R, W, H, C, tiles):
         "scan": P * 8,
         "emit": R * 12,
         "tile_sort": R * 24 * n_pass,
-        "ranges": R * 8,
+        "ranges": tiles * 8,  # clearing the table; the R * 8 boundary scan rides in the payload kernel
         "composite_fwd": R * (32 + 4 * C) + W * H * (4 * C + 16),
         "composite_bwd": R * (32 + 4 * C) + W * H * (4 * C + 16) + P * (28 + 4 * C),
         "preprocess_bwd": P * (100 + 4 * C + 56 + 4 * C),
-        "payload": R * (8 + 32 + 33),  # not in the lineage: ids + gathered records in, records + mask out
+        "payload": R * (8 + 32 + 33),  # not in the lineage: ids + gathered records in, records + mask out (+ tile ranges)
     }
     frame = P * (296 + 16 * C) + R * (20 + 24 * n_pass + 2 * (32 + 4 * C)) + W * H * (8 * C + 32)
     return stage, frame, n_pass

@@ -280,11 +280,11 @@ int splatknn_dist2(int32_t N, const float* points /* [N,3] */, float* out /* [N]
 #define SPLATRASTER_STAGE_SCAN 2           /* inclusive scan of tiles_touched */
 #define SPLATRASTER_STAGE_EMIT 3           /* emit_kernel */
 #define SPLATRASTER_STAGE_TILE_SORT 4      /* R-sized radix sort on tile id */
-#define SPLATRASTER_STAGE_RANGES 5         /* ranges_kernel */
+#define SPLATRASTER_STAGE_RANGES 5         /* clearing the per-tile range table (boundaries: payload_kernel) */
 #define SPLATRASTER_STAGE_COMPOSITE_FWD 6  /* composite_fwd_kernel */
 #define SPLATRASTER_STAGE_COMPOSITE_BWD 7  /* composite_bwd_kernel (the accumulator memset before it is not bracketed) */
 #define SPLATRASTER_STAGE_PREPROCESS_BWD 8 /* preprocess_bwd_kernel */
-#define SPLATRASTER_STAGE_PAYLOAD 9        /* payload_kernel: per-instance records + quadrant reach masks */
+#define SPLATRASTER_STAGE_PAYLOAD 9        /* payload_kernel: per-instance records, reach masks, tile ranges */
 #define SPLATRASTER_STAGE_COUNT 10
 
 int splatraster_timing_enable(int on);            /* all stages on / off */

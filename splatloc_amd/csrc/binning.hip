@@ -118,23 +118,11 @@ int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomV
     return SPLATRASTER_OK;
 }
 
-__global__ void __launch_bounds__(256)
-ranges_kernel(int64_t R, const uint32_t* __restrict__ tile_list, uint32_t* __restrict__ ranges)
-{
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= R) return;
-    const uint32_t t = tile_list[j];
-    if (j == 0 || tile_list[j - 1] != t) ranges[2 * t] = (uint32_t)j;
-    if (j == R - 1 || tile_list[j + 1] != t) ranges[2 * t + 1] = (uint32_t)(j + 1);
-}
-
-int launch_ranges(int64_t R, int32_t tiles, const uint32_t* tile_list, uint32_t* ranges, hipStream_t stream)
+// Zeroes the per-tile range table (empty tiles keep [0, 0)); the boundaries themselves are written
+// by payload_kernel, which walks the sorted list anyway.
+int launch_ranges_clear(int32_t tiles, uint32_t* ranges, hipStream_t stream)
 {
     SR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)tiles, stream));
-    if (R == 0) return SPLATRASTER_OK;
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, tile_list,
-                       ranges);
-    SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
 
@@ -145,7 +133,7 @@ int launch_ranges(int64_t R, int32_t tiles, const uint32_t* tile_list, uint32_t*
 __global__ void __launch_bounds__(256)
 payload_kernel(int64_t R, int gx, const uint32_t* __restrict__ point_list,
                const uint32_t* __restrict__ tile_list, const float4* __restrict__ rec,
-               float4* __restrict__ irec, uint8_t* __restrict__ imask)
+               float4* __restrict__ irec, uint8_t* __restrict__ imask, uint32_t* __restrict__ ranges)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= R) return;
@@ -155,6 +143,9 @@ payload_kernel(int64_t R, int gx, const uint32_t* __restrict__ point_list,
     irec[2 * j] = a0;
     irec[2 * j + 1] = a1;
     imask[j] = (uint8_t)quadrant_reach_mask(a0, a1, (float)(tx * TILE), (float)(ty * TILE));
+    // per-tile [start, end) of the sorted list (the table was zeroed for the empty tiles)
+    if (j == 0 || tile_list[j - 1] != t) ranges[2 * t] = (uint32_t)j;
+    if (j == R - 1 || tile_list[j + 1] != t) ranges[2 * t + 1] = (uint32_t)(j + 1);
 }
 
 int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b, hipStream_t stream)
@@ -162,7 +153,7 @@ int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, 
     if (R == 0) return SPLATRASTER_OK;
     const int gx = (s.image_width + TILE - 1) / TILE;
     hipLaunchKernelGGL(payload_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, b.point_list,
-                       b.tile_list, g.rec, b.irec, b.imask);
+                       b.tile_list, g.rec, b.irec, b.imask, b.ranges);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

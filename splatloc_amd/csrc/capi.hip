@@ -360,7 +360,7 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
     }
     {
         StageTimer t(SPLATRASTER_STAGE_RANGES, stream);
-        st = launch_ranges(R, tiles, b.tile_list, b.ranges, stream);
+        st = launch_ranges_clear(tiles, b.ranges, stream);
     }
     if (st) return st;
     const float* featp = feat;  // 16-byte aligned rows for the compositing kernels

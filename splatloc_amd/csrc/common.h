@@ -104,7 +104,7 @@ int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint
 
 int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
                 uint32_t* vals, hipStream_t stream);
-int launch_ranges(int64_t R, int32_t tiles, const uint32_t* tile_list, uint32_t* ranges, hipStream_t stream);
+int launch_ranges_clear(int32_t tiles, uint32_t* ranges, hipStream_t stream);
 int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b, hipStream_t stream);
 // 16-byte aligned copy of the [P, C] feature rows (returns feat itself when C % 4 == 0)
 int launch_pad_features(int32_t P, int C, const float* feat, float* featp, hipStream_t stream);
