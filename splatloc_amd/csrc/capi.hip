@@ -286,8 +286,11 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
     char* base = reinterpret_cast<char*>(geometry);
     {
         StageTimer t(SPLATRASTER_STAGE_PREPROCESS, stream);
+        // the look-back state of the depth sort and of the scan is cleared by preprocess_kernel
         st = launch_preprocess(*s, P, means3D, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix,
-                               projmatrix, campos, g, radii, stream);
+                               projmatrix, campos, g, radii, g.sort_tmp, (uint32_t)(sort_zero_bytes(P, 32) / 4),
+                               reinterpret_cast<uint32_t*>(base + L.scan_tmp), (uint32_t)(scan_state_bytes(P) / 4),
+                               stream);
     }
     if (st) return st;
     HostSlot* slot = nullptr;
@@ -301,13 +304,13 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
         bool in_alt = false;
         uint32_t* keys_alt = reinterpret_cast<uint32_t*>(base + L.keys_alt);
         uint32_t* vals_alt = reinterpret_cast<uint32_t*>(base + L.vals_alt);
-        st = sort_pairs_u32(P, g.sort_keys, g.depth_order, keys_alt, vals_alt, 32, g.sort_tmp, stream, &in_alt);
+        st = sort_pairs_u32(P, g.sort_keys, g.depth_order, keys_alt, vals_alt, 32, g.sort_tmp, stream, &in_alt, true);
         if (st) return st;
         if (in_alt) return SPLATRASTER_ERR_UNSUPPORTED;  // 4 passes: never
     }
     {
         StageTimer t(SPLATRASTER_STAGE_SCAN, stream);
-        st = inclusive_scan_u32(P, g.tiles_touched, g.depth_order, g.offsets, g.total, base + L.scan_tmp, stream);
+        st = inclusive_scan_u32(P, g.tiles_touched, g.depth_order, g.offsets, g.total, base + L.scan_tmp, stream, true);
     }
     if (st) return st;
     SR_HIP_CHECK(hipEventSynchronize(slot->ev));  // the copy only: sort and scan may still be running

@@ -81,7 +81,8 @@ ImgView img_view(void* base, int32_t W, int32_t H);
 int launch_preprocess(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, const float* view, const float* proj,
-                      const float* campos, GeomView g, int32_t* radii, hipStream_t stream);
+                      const float* campos, GeomView g, int32_t* radii, uint32_t* zero0, uint32_t nzero0, uint32_t* zero1, uint32_t nzero1,
+                      hipStream_t stream);
 int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           const float* view, const float* proj, const float* campos, const int32_t* radii,
@@ -95,12 +96,14 @@ int launch_mark_visible(int32_t P, const float* means3D, const float* view, uint
                         hipStream_t stream);
 
 size_t sort_tmp_bytes(int64_t n);
+size_t sort_zero_bytes(int64_t n, int key_bits);
 int sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
-                   int key_bits, void* tmp, hipStream_t stream, bool* result_in_alt);
+                   int key_bits, void* tmp, hipStream_t stream, bool* result_in_alt, bool tmp_zeroed = false);
 // inclusive scan of in[perm[i]] (perm may be null) into out[i]; total (u64 as 2 words) optional
 size_t scan_tmp_bytes(int64_t n);
+size_t scan_state_bytes(int64_t n);
 int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_t* out, uint32_t* total,
-                       void* tmp, hipStream_t stream);
+                       void* tmp, hipStream_t stream, bool state_zeroed = false);
 
 int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
                 uint32_t* vals, hipStream_t stream);

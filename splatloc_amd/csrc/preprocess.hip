@@ -96,9 +96,14 @@ preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale
                   float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
                   float* __restrict__ rgb, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii,
                   uint32_t* __restrict__ block_tiles /*[gridDim.x] per-block sums of tiles_touched*/,
-                  uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals /*depth-sort input*/)
+                  uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals /*depth-sort input*/,
+                  uint32_t* __restrict__ zero0, uint32_t nzero0, uint32_t* __restrict__ zero1, uint32_t nzero1)
 {
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    // state words of the depth sort's look-back and of the one-pass scan must be zero when those
+    // kernels start: cleared here instead of by two extra memset launches
+    for (uint32_t w = (uint32_t)gi; w < nzero0; w += gridDim.x * blockDim.x) zero0[w] = 0u;
+    for (uint32_t w = (uint32_t)gi; w < nzero1; w += gridDim.x * blockDim.x) zero1[w] = 0u;
     const bool live = gi < P;
     const int i = live ? gi : P - 1;  // padding lanes recompute the last Gaussian and store nothing
     // camera tensors: wave-uniform addresses -> scalar loads, SGPR-resident
@@ -214,14 +219,15 @@ preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale
 int launch_preprocess(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
                       const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, const float* view, const float* proj,
-                      const float* campos, GeomView g, int32_t* radii, hipStream_t stream)
+                      const float* campos, GeomView g, int32_t* radii, uint32_t* zero0, uint32_t nzero0,
+                      uint32_t* zero1, uint32_t nzero1, hipStream_t stream)
 {
     if (P == 0) return SPLATRASTER_OK;
     const int blocks = preprocess_blocks(P);
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(PREPROCESS_BLOCK), 0, stream, P, s.image_width,
                        s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs,
                        means3D, shs, opacities, scales, rotations, cov3D_precomp, view, proj, campos, g.rec,
-                       g.tiles_touched, g.rgb, g.clamped, radii, g.block_tiles, g.sort_keys, g.depth_order);
+                       g.tiles_touched, g.rgb, g.clamped, radii, g.block_tiles, g.sort_keys, g.depth_order, zero0, nzero0, zero1, nzero1);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

@@ -130,10 +130,111 @@ scan_apply_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ pe
     }
 }
 
+// One-pass inclusive scan (n <= SCAN_ONEPASS_MAX_BLOCKS tiles): each block scans its tile, publishes
+// its total in a 64-bit status word (value | flag << 62: 1 = tile total, 2 = inclusive prefix) and
+// wave 0 resolves the exclusive prefix with a wave-wide decoupled look-back — 64 predecessors per
+// L2 round trip.  Relaxed agent-scope atomics (the word IS the flag), ticketed block ids (a block
+// only waits for blocks that already started), bounded spins.  State (ticket + status words) must
+// be zero on entry.
+constexpr int SCAN_ONEPASS_MAX_BLOCKS = 2048;
+constexpr uint64_t SC_LOCAL = 1ull << 62, SC_INCL = 2ull << 62, SC_VAL = (1ull << 62) - 1ull;
+
+struct ScanState {
+    uint32_t ticket;
+    uint32_t error;
+    uint64_t status[1];  // [nb]
+};
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_onepass_kernel(int64_t n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ perm,
+                    uint32_t* __restrict__ out, uint64_t* __restrict__ total, ScanState* __restrict__ st)
+{
+    __shared__ uint32_t wsum[SCAN_THREADS / WAVE];
+    __shared__ uint32_t s_bid;
+    __shared__ uint64_t s_excl;
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    if (threadIdx.x == 0) s_bid = atomicAdd(&st->ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const int64_t base = (int64_t)bid * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + k;
+        v[k] = i < n ? (perm ? in[perm[i]] : in[i]) : 0u;
+        s += v[k];
+    }
+    const uint32_t incl = wave_inclusive_scan(s, lane);
+    if (lane == WAVE - 1) wsum[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0, btotal = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_THREADS / WAVE; ++k) {
+        if (k < w) woff += wsum[k];
+        btotal += wsum[k];
+    }
+    if (w == 0) {
+        uint64_t* mine = st->status + bid;
+        uint64_t excl = 0;
+        if (bid == 0) {
+            if (lane == 0) __hip_atomic_store(mine, (uint64_t)btotal | SC_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(mine, (uint64_t)btotal | SC_LOCAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t pb = (int64_t)bid - 1;
+            uint32_t spins = 0;
+            while (true) {
+                const int64_t idx = pb - lane;
+                const uint64_t word = idx >= 0 ? __hip_atomic_load(st->status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : SC_INCL;  // before tile 0: inclusive prefix 0
+                const uint64_t flag = word & ~SC_VAL;
+                const uint64_t ready = __builtin_amdgcn_ballot_w64(flag != 0);
+                const uint64_t has_incl = __builtin_amdgcn_ballot_w64(flag == SC_INCL);
+                const int first = has_incl ? __builtin_ctzll(has_incl) : WAVE - 1;   // nearest inclusive prefix
+                const uint64_t need = first == WAVE - 1 ? ~0ull : ((1ull << (first + 1)) - 1ull);
+                if ((ready & need) != need) {
+                    if (++spins > (1u << 22)) { if (lane == 0) st->error = 1u; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                uint64_t part = lane <= first ? (word & SC_VAL) : 0ull;
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) part += __shfl_xor(part, d, WAVE);
+                excl += part;
+                if (has_incl) break;
+                pb -= WAVE;
+            }
+            if (lane == 0)
+                __hip_atomic_store(mine, ((excl + btotal) & SC_VAL) | SC_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_excl = excl;
+            if (total && (int64_t)(bid + 1) * SCAN_TILE >= n) *total = excl + btotal;
+        }
+    }
+    __syncthreads();
+    uint32_t run = (uint32_t)s_excl + woff + incl - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + k;
+        run += v[k];
+        if (i < n) out[i] = run;
+    }
+}
+
+size_t scan_state_bytes(int64_t n)
+{
+    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb > SCAN_ONEPASS_MAX_BLOCKS) return 0;
+    return align_up(sizeof(ScanState) + (size_t)(nb > 0 ? nb : 1) * sizeof(uint64_t), 256);
+}
+
 size_t scan_tmp_bytes(int64_t n)
 {
     const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    return align_up((size_t)(nb + 2) * sizeof(uint64_t), 256);
+    const size_t three_kernel = align_up((size_t)(nb + 2) * sizeof(uint64_t), 256);
+    const size_t one_pass = scan_state_bytes(n);
+    return three_kernel > one_pass ? three_kernel : one_pass;
 }
 
 template <bool EXCLUSIVE>
@@ -158,8 +259,17 @@ static int scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_
 }
 
 int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_t* out, uint32_t* total,
-                       void* tmp, hipStream_t stream)
+                       void* tmp, hipStream_t stream, bool state_zeroed)
 {
+    const size_t state = scan_state_bytes(n);
+    if (n > 0 && state) {
+        if (!state_zeroed) SR_HIP_CHECK(hipMemsetAsync(tmp, 0, state, stream));
+        const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(scan_onepass_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, n, in, perm, out,
+                           reinterpret_cast<uint64_t*>(total), reinterpret_cast<ScanState*>(tmp));
+        SR_LAUNCH_CHECK();
+        return SPLATRASTER_OK;
+    }
     return scan_u32<false>(n, in, perm, out, total, tmp, stream);
 }
 
@@ -461,8 +571,18 @@ size_t sort_tmp_bytes(int64_t n)
     return legacy > sweep ? legacy : sweep;
 }
 
+// bytes at the start of tmp that must be zero before sort_pairs_u32 (0: none); a caller that
+// zeroes them itself passes tmp_zeroed = true
+size_t sort_zero_bytes(int64_t n, int key_bits)
+{
+    const int64_t nb = (n + SORT_TILE - 1) / SORT_TILE;
+    if (n <= 0 || key_bits <= 0 || !(SR_SORT_ONESWEEP && nb <= 256)) return 0;
+    const int passes = (key_bits + 7) / 8;
+    return align_up(sizeof(SweepState), 256) + (size_t)passes * align_up((size_t)nb * RADIX * sizeof(uint32_t), 256);
+}
+
 int sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
-                   int key_bits, void* tmp, hipStream_t stream, bool* result_in_alt)
+                   int key_bits, void* tmp, hipStream_t stream, bool* result_in_alt, bool tmp_zeroed)
 {
     *result_in_alt = false;
     if (n <= 0 || key_bits <= 0) return SPLATRASTER_OK;
@@ -478,7 +598,7 @@ int sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt
         const size_t head = align_up(sizeof(SweepState), 256);
         SweepState* st = reinterpret_cast<SweepState*>(tmp);
         char* status0 = reinterpret_cast<char*>(tmp) + head;
-        SR_HIP_CHECK(hipMemsetAsync(tmp, 0, head + (size_t)passes * table, stream));
+        if (!tmp_zeroed) SR_HIP_CHECK(hipMemsetAsync(tmp, 0, head + (size_t)passes * table, stream));
         hipLaunchKernelGGL(sort_hist_all_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, n, kin, passes, st);
         SR_LAUNCH_CHECK();
         for (int p = 0; p < passes; ++p) {
