@@ -145,9 +145,10 @@ struct ScanState {
     uint64_t status[1];  // [nb]
 };
 
+template <bool EXCLUSIVE>
 __global__ void __launch_bounds__(SCAN_THREADS)
-scan_onepass_kernel(int64_t n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ perm,
-                    uint32_t* __restrict__ out, uint64_t* __restrict__ total, ScanState* __restrict__ st)
+scan_onepass_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ perm,
+                    uint32_t* out /* may alias in */, uint64_t* __restrict__ total, ScanState* __restrict__ st)
 {
     __shared__ uint32_t wsum[SCAN_THREADS / WAVE];
     __shared__ uint32_t s_bid;
@@ -217,8 +218,13 @@ scan_onepass_kernel(int64_t n, const uint32_t* __restrict__ in, const uint32_t* 
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const int64_t i = base + k;
-        run += v[k];
-        if (i < n) out[i] = run;
+        if (EXCLUSIVE) {
+            if (i < n) out[i] = run;
+            run += v[k];
+        } else {
+            run += v[k];
+            if (i < n) out[i] = run;
+        }
     }
 }
 
@@ -265,7 +271,7 @@ int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint
     if (n > 0 && state) {
         if (!state_zeroed) SR_HIP_CHECK(hipMemsetAsync(tmp, 0, state, stream));
         const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-        hipLaunchKernelGGL(scan_onepass_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, n, in, perm, out,
+        hipLaunchKernelGGL(scan_onepass_kernel<false>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, n, in, perm, out,
                            reinterpret_cast<uint64_t*>(total), reinterpret_cast<ScanState*>(tmp));
         SR_LAUNCH_CHECK();
         return SPLATRASTER_OK;
@@ -278,9 +284,11 @@ int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SORT_THREADS)
 sort_hist_kernel(int64_t n, const uint32_t* __restrict__ keys, int shift, uint32_t nblocks,
-                 uint32_t* __restrict__ table)
+                 uint32_t* __restrict__ table, uint32_t* __restrict__ zero, uint32_t nzero)
 {
     __shared__ uint32_t hist[RADIX];
+    // look-back state of the one-pass scan that follows: cleared here, not by a memset launch
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nzero; w += gridDim.x * blockDim.x) zero[w] = 0u;
     hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
@@ -615,11 +623,20 @@ int sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt
     void* scan_tmp = reinterpret_cast<char*>(tmp) + align_up((size_t)nb * RADIX * sizeof(uint32_t), 256);
     for (int p = 0; p < passes; ++p) {
         const int shift = p * 8;
+        const int64_t cnt = nb * RADIX;
+        const size_t sstate = scan_state_bytes(cnt);
         hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, n, kin, shift,
-                           (uint32_t)nb, table);
+                           (uint32_t)nb, table, reinterpret_cast<uint32_t*>(scan_tmp), (uint32_t)(sstate / 4));
         SR_LAUNCH_CHECK();
-        int st = scan_u32<true>(nb * RADIX, table, nullptr, table, nullptr, scan_tmp, stream);
-        if (st != SPLATRASTER_OK) return st;
+        if (sstate) {
+            const int64_t snb = (cnt + SCAN_TILE - 1) / SCAN_TILE;
+            hipLaunchKernelGGL(scan_onepass_kernel<true>, dim3((unsigned)snb), dim3(SCAN_THREADS), 0, stream, cnt, table,
+                               nullptr, table, nullptr, reinterpret_cast<ScanState*>(scan_tmp));
+            SR_LAUNCH_CHECK();
+        } else {
+            int st = scan_u32<true>(cnt, table, nullptr, table, nullptr, scan_tmp, stream);
+            if (st != SPLATRASTER_OK) return st;
+        }
         hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, n, kin, vin,
                            kout, vout, shift, (uint32_t)nb, table);
         SR_LAUNCH_CHECK();
