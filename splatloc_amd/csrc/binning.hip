@@ -28,12 +28,13 @@ __device__ __forceinline__ int f2i_sat_b(float v)
 // thread finishes with a binary search in LDS.
 constexpr int EMIT_BLOCK = 256;
 constexpr int EMIT_IPT = 4;
-constexpr int EMIT_SPAN = EMIT_BLOCK * EMIT_IPT;
+static_assert(EMIT_SPAN == EMIT_BLOCK * EMIT_IPT, "common.h: EMIT_SPAN");
 
 __global__ void __launch_bounds__(EMIT_BLOCK)
 emit_kernel(int64_t R, int P, int W, int H, const uint32_t* __restrict__ offsets,
             const uint32_t* __restrict__ depth_order, const float4* __restrict__ rec,
-            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+            const uint32_t* __restrict__ span_owner /* first rank of span k, or NULL */)
 {
     __shared__ uint32_t s_off[EMIT_SPAN + 1];  // s_off[q] = offsets[r_lo - 1 + q] (0 before the first)
     __shared__ uint32_t s_gid[EMIT_SPAN], s_org[EMIT_SPAN], s_w[EMIT_SPAN];
@@ -41,8 +42,12 @@ emit_kernel(int64_t R, int P, int W, int H, const uint32_t* __restrict__ offsets
     const int t = threadIdx.x;
     const int64_t j0 = (int64_t)blockIdx.x * EMIT_SPAN;
     const uint32_t j0u = (uint32_t)j0;
-    // ---- first rank with offsets[r] > j0 ----
+    // ---- first rank with offsets[r] > j0: handed over by the scan, else searched for ----
     int lo = 0, hi = P;
+    if (span_owner && blockIdx.x < SPAN_OWNER_CAP) {
+        lo = (int)span_owner[blockIdx.x];
+        hi = lo + 1;
+    }
     while (hi - lo > 1) {
         const int n = hi - lo;
         const int step = (n + EMIT_BLOCK - 1) / EMIT_BLOCK;
@@ -113,7 +118,8 @@ int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomV
     if (R == 0) return SPLATRASTER_OK;
     const int64_t blocks = (R + EMIT_SPAN - 1) / EMIT_SPAN;
     hipLaunchKernelGGL(emit_kernel, dim3((unsigned)blocks), dim3(EMIT_BLOCK), 0, stream, R, P, s.image_width,
-                       s.image_height, g.offsets, g.depth_order, g.rec, keys, vals);
+                       s.image_height, g.offsets, g.depth_order, g.rec, keys, vals,
+                       scan_state_bytes(P) ? g.span_owner : nullptr);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

@@ -98,7 +98,7 @@ static inline int tile_bits(int tiles)
 
 struct GeomLayout {
     size_t rec0, rec1, tiles_touched, depth_order, offsets, rgb, clamped, sort_keys, keys_alt, vals_alt,
-        sort_tmp, scan_tmp, total, block_tiles, bytes;
+        sort_tmp, scan_tmp, total, block_tiles, span_owner, bytes;
 };
 static GeomLayout geom_layout(int32_t P)
 {
@@ -120,6 +120,7 @@ static GeomLayout geom_layout(int32_t P)
     L.scan_tmp = take(scan_tmp_bytes((int64_t)n));
     L.total = take(16);
     L.block_tiles = take(4 * (size_t)preprocess_blocks((int32_t)n));
+    L.span_owner = take(4 * (size_t)SPAN_OWNER_CAP);
     L.bytes = o;
     return L;
 }
@@ -139,6 +140,7 @@ GeomView geom_view(void* base, int32_t P)
     g.sort_tmp = reinterpret_cast<uint32_t*>(b + L.sort_tmp);
     g.total = reinterpret_cast<uint32_t*>(b + L.total);
     g.block_tiles = reinterpret_cast<uint32_t*>(b + L.block_tiles);
+    g.span_owner = reinterpret_cast<uint32_t*>(b + L.span_owner);
     return g;
 }
 
@@ -310,7 +312,8 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
     }
     {
         StageTimer t(SPLATRASTER_STAGE_SCAN, stream);
-        st = inclusive_scan_u32(P, g.tiles_touched, g.depth_order, g.offsets, g.total, base + L.scan_tmp, stream, true);
+        st = inclusive_scan_u32(P, g.tiles_touched, g.depth_order, g.offsets, g.total, base + L.scan_tmp, stream, true,
+                                g.span_owner, (uint32_t)EMIT_SPAN, SPAN_OWNER_CAP);
     }
     if (st) return st;
     SR_HIP_CHECK(hipEventSynchronize(slot->ev));  // the copy only: sort and scan may still be running

@@ -55,6 +55,7 @@ struct GeomView {
     uint32_t* sort_tmp;      // scratch for the P-sized sort + scan partials
     uint32_t* total;         // [2] device-side R (uint64 as two words), written by the scan
     uint32_t* block_tiles;   // [preprocess_blocks(P)] per-block sums of tiles_touched, written by preprocess
+    uint32_t* span_owner;    // [SPAN_OWNER_CAP] depth rank owning instance k * EMIT_SPAN, written by the one-pass scan
 };
 struct BinView {
     uint32_t* point_list; // [R] sorted gaussian ids
@@ -103,7 +104,10 @@ int sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt
 size_t scan_tmp_bytes(int64_t n);
 size_t scan_state_bytes(int64_t n);
 int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_t* out, uint32_t* total,
-                       void* tmp, hipStream_t stream, bool state_zeroed = false);
+                       void* tmp, hipStream_t stream, bool state_zeroed = false, uint32_t* span_owner = nullptr,
+                       uint32_t span = 0, uint32_t span_cap = 0);
+constexpr int EMIT_SPAN = 1024;  // instances emitted per workgroup (binning.hip)
+constexpr uint32_t SPAN_OWNER_CAP = 1u << 16;  // emit workgroups that get their first rank from the scan (R <= 64 M)
 
 int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
                 uint32_t* vals, hipStream_t stream);

@@ -148,7 +148,8 @@ struct ScanState {
 template <bool EXCLUSIVE>
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_onepass_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ perm,
-                    uint32_t* out /* may alias in */, uint64_t* __restrict__ total, ScanState* __restrict__ st)
+                    uint32_t* out /* may alias in */, uint64_t* __restrict__ total, ScanState* __restrict__ st,
+                    uint32_t* __restrict__ span_owner /* or NULL */, uint32_t span, uint32_t span_cap)
 {
     __shared__ uint32_t wsum[SCAN_THREADS / WAVE];
     __shared__ uint32_t s_bid;
@@ -222,8 +223,16 @@ scan_onepass_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ 
             if (i < n) out[i] = run;
             run += v[k];
         } else {
+            const uint32_t prev = run;
             run += v[k];
-            if (i < n) out[i] = run;
+            if (i < n) {
+                out[i] = run;
+                // element i owns the output range [prev, run): record it as the owner of every
+                // multiple of `span` inside (the emit kernel starts its rank search there)
+                if (span_owner && run > prev)
+                    for (uint32_t b = (prev + span - 1) / span; (uint64_t)b * span < run && b < span_cap; ++b)
+                        span_owner[b] = (uint32_t)i;
+            }
         }
     }
 }
@@ -265,14 +274,15 @@ static int scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_
 }
 
 int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_t* out, uint32_t* total,
-                       void* tmp, hipStream_t stream, bool state_zeroed)
+                       void* tmp, hipStream_t stream, bool state_zeroed, uint32_t* span_owner, uint32_t span,
+                       uint32_t span_cap)
 {
     const size_t state = scan_state_bytes(n);
     if (n > 0 && state) {
         if (!state_zeroed) SR_HIP_CHECK(hipMemsetAsync(tmp, 0, state, stream));
         const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
         hipLaunchKernelGGL(scan_onepass_kernel<false>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, n, in, perm, out,
-                           reinterpret_cast<uint64_t*>(total), reinterpret_cast<ScanState*>(tmp));
+                           reinterpret_cast<uint64_t*>(total), reinterpret_cast<ScanState*>(tmp), span_owner, span, span_cap);
         SR_LAUNCH_CHECK();
         return SPLATRASTER_OK;
     }
@@ -631,7 +641,7 @@ int sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt
         if (sstate) {
             const int64_t snb = (cnt + SCAN_TILE - 1) / SCAN_TILE;
             hipLaunchKernelGGL(scan_onepass_kernel<true>, dim3((unsigned)snb), dim3(SCAN_THREADS), 0, stream, cnt, table,
-                               nullptr, table, nullptr, reinterpret_cast<ScanState*>(scan_tmp));
+                               nullptr, table, nullptr, reinterpret_cast<ScanState*>(scan_tmp), nullptr, 0u, 0u);
             SR_LAUNCH_CHECK();
         } else {
             int st = scan_u32<true>(cnt, table, nullptr, table, nullptr, scan_tmp, stream);
