@@ -34,8 +34,10 @@ __global__ void __launch_bounds__(EMIT_BLOCK)
 emit_kernel(int64_t R, int P, int W, int H, const uint32_t* __restrict__ offsets,
             const uint32_t* __restrict__ depth_order, const float4* __restrict__ rec,
             uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-            const uint32_t* __restrict__ span_owner /* first rank of span k, or NULL */)
+            const uint32_t* __restrict__ span_owner /* first rank of span k, or NULL */,
+            uint32_t* __restrict__ ranges, uint32_t nranges /* words to clear for payload_kernel */)
 {
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nranges; w += gridDim.x * blockDim.x) ranges[w] = 0u;
     __shared__ uint32_t s_off[EMIT_SPAN + 1];  // s_off[q] = offsets[r_lo - 1 + q] (0 before the first)
     __shared__ uint32_t s_gid[EMIT_SPAN], s_org[EMIT_SPAN], s_w[EMIT_SPAN];
     __shared__ int s_min;
@@ -113,13 +115,13 @@ emit_kernel(int64_t R, int P, int W, int H, const uint32_t* __restrict__ offsets
 }
 
 int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
-                uint32_t* vals, hipStream_t stream)
+                uint32_t* vals, uint32_t* ranges, uint32_t nranges, hipStream_t stream)
 {
     if (R == 0) return SPLATRASTER_OK;
     const int64_t blocks = (R + EMIT_SPAN - 1) / EMIT_SPAN;
     hipLaunchKernelGGL(emit_kernel, dim3((unsigned)blocks), dim3(EMIT_BLOCK), 0, stream, R, P, s.image_width,
                        s.image_height, g.offsets, g.depth_order, g.rec, keys, vals,
-                       scan_state_bytes(P) ? g.span_owner : nullptr);
+                       scan_state_bytes(P) ? g.span_owner : nullptr, ranges, nranges);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

@@ -354,7 +354,7 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
     if (R > 0) {
         {
             StageTimer t(SPLATRASTER_STAGE_EMIT, stream);
-            st = launch_emit(*s, P, R, g, k0, v0, stream);
+            st = launch_emit(*s, P, R, g, k0, v0, b.ranges, 2u * (uint32_t)tiles, stream);  // also clears the range table
         }
         if (st) return st;
         bool in_alt = false;
@@ -364,7 +364,7 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
         }
         if (st) return st;
     }
-    {
+    if (R == 0) {   // nothing was emitted: the table is cleared here instead
         StageTimer t(SPLATRASTER_STAGE_RANGES, stream);
         st = launch_ranges_clear(tiles, b.ranges, stream);
     }

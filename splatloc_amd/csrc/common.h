@@ -110,7 +110,7 @@ constexpr int EMIT_SPAN = 1024;  // instances emitted per workgroup (binning.hip
 constexpr uint32_t SPAN_OWNER_CAP = 1u << 16;  // emit workgroups that get their first rank from the scan (R <= 64 M)
 
 int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
-                uint32_t* vals, hipStream_t stream);
+                uint32_t* vals, uint32_t* ranges, uint32_t nranges, hipStream_t stream);
 int launch_ranges_clear(int32_t tiles, uint32_t* ranges, hipStream_t stream);
 int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b, hipStream_t stream);
 // 16-byte aligned copy of the [P, C] feature rows (returns feat itself when C % 4 == 0)
