@@ -109,7 +109,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         color = torch.empty((Cn, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)   # preprocess_kernel writes every element
         geom = torch.empty((lib.splatraster_geometry_bytes(P),), dtype=torch.uint8, device=dev)
         img = torch.empty((lib.splatraster_image_bytes(W, H),), dtype=torch.uint8, device=dev)
         stream = _stream(dev)
@@ -133,6 +133,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                 (m3, shs, col, opa, sca, rot, cov, bg, view, proj, campos)],
                               radii, geom, binning, img, color, depth, alpha)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # no zero tensors for unused output gradients (radii, depth, alpha)
         return color, depth, alpha, radii
 
     @staticmethod
