@@ -30,6 +30,11 @@
 #ifndef SR_BWD_FS
 #define SR_BWD_FS 32  // feature rows staged per round (<= 64)
 #endif
+#ifdef SR_ABLATE_HOT_ROWS  // timing experiment only: every gather hits the same few rows
+#define SR_ABLATE_HOT(x) ((x) & 1023u)
+#else
+#define SR_ABLATE_HOT(x) (x)
+#endif
 #ifndef SR_STAGE_UNROLL
 #define SR_STAGE_UNROLL 2  // gather iterations in flight together while staging feature rows
 #endif
@@ -283,7 +288,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #pragma unroll SR_STAGE_UNROLL
             for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
-                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)s_cgid[row] * CP4 + (c0 >> 2) + pc];
+                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)SR_ABLATE_HOT(s_cgid[row]) * CP4 + (c0 >> 2) + pc];
             }
             __builtin_amdgcn_wave_barrier();
 #ifdef SR_BWD_PROFILE

@@ -27,6 +27,11 @@
 #ifndef SR_FWD_FS
 #define SR_FWD_FS 32  // feature rows staged per round (<= 64)
 #endif
+#ifdef SR_ABLATE_HOT_ROWS  // timing experiment only: every gather hits the same few rows
+#define SR_ABLATE_HOT(x) ((x) & 1023u)
+#else
+#define SR_ABLATE_HOT(x) (x)
+#endif
 #ifndef SR_STAGE_UNROLL
 #define SR_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2: 1: 0.429, 2: 0.456, 3: 0.416, 5: 0.478 ms)
 #endif
@@ -175,7 +180,7 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
 #pragma unroll SR_STAGE_UNROLL
             for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
-                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)s_cgid[row] * CP4 + (c0 >> 2) + pc];
+                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)SR_ABLATE_HOT(s_cgid[row]) * CP4 + (c0 >> 2) + pc];
             }
             __builtin_amdgcn_wave_barrier();
             // ---- composite them front to back, two at a time ----
