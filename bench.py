@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """bench.py — fwd+bwd frames/s of the MI355X-native Gaussian rasterizer (BASELINE.json metric).
 
-One "step" = one forward + one backward pass of the rasterizer hot path
-(diff_gauss.GaussianRasterizer forward/backward through the C ABI) over one frame of the
-synthetic workload S2 (500k Gaussians, 1920x1080, 35 channels: RGB + 32 feature channels,
-+ depth + alpha), inputs resident in HBM, on every rank.  With N > 1 ranks (one process
-per GPU, RCCL) every rank renders its own frame of a full scene replica and the parameter
-gradients are SUM-all-reduced inside the timed region (the frame-parallel map() step of
-SURVEY.md §8e): weak scaling, value = N frames per step / max-over-ranks step time.
+One "step" = one optimisation step of SplatLoc.map as far as the rasterizer is concerned
+(train_gaussians.py:187-229): `--views` = 5 frames (the reference's window_size, configs/*/
+base_config.yaml: window_size: 5), each one forward + one backward pass of the rasterizer hot
+path (diff_gauss.GaussianRasterizer through the C ABI) over the synthetic workload S2 (500k
+Gaussians, 1920x1080, 35 channels: RGB + 32 feature channels, + depth + alpha), inputs resident
+in HBM, gradients accumulated over the window.  With N > 1 ranks (one process per GPU, RCCL)
+every rank renders its own window of a full scene replica and the accumulated parameter
+gradients are SUM-all-reduced ONCE per step inside the timed region (the frame-parallel map()
+step of SURVEY.md §8e): weak scaling, value = 5 N frames per step / max-over-ranks step time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline`
 (dominant kernel, HIP events measured live on the launch stream) and `cpu_baseline`
@@ -381,6 +383,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="S2")
+    ap.add_argument("--views", type=int, default=5,
+                    help="frames per optimisation step (SplatLoc.map's window_size = 5); gradients accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
     ap.add_argument("--stage", default="raster", choices=["raster", "activations", "loss", "map_step"],
@@ -436,11 +440,13 @@ def main():
     def step():
         for p in params:
             p.grad = None
-        color, depth, alpha, radii = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors,
-                                          opacities=opac, scales=scales, rotations=rots, cov3D_precomp=None)
-        info["R"] = color.grad_fn.num_rendered
+        for _ in range(args.views):   # the window: every frame one forward + one backward, grads accumulate
+            color, depth, alpha, radii = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors,
+                                              opacities=opac, scales=scales, rotations=rots, cov3D_precomp=None)
+            info["R"] = color.grad_fn.num_rendered
+            if not args.fwd_only:
+                torch.autograd.backward((color, depth, alpha), g_out)
         if not args.fwd_only:
-            torch.autograd.backward((color, depth, alpha), g_out)
             if world > 1:
                 # parameter gradients only: the viewspace (means2D) gradient feeds per-view
                 # densification statistics, which replicas sync through their own accumulators
@@ -486,7 +492,7 @@ def main():
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         st_bytes, frame_bytes, n_pass = algorithmic_bytes(P, R, W, H, C, tiles)
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.steps / elapsed
+        value = world * args.views * args.steps / elapsed
         per_stage = {}
         for s, (ms, cnt) in stages.items():
             if cnt:
@@ -509,15 +515,16 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: P={P} Gaussians, {W}x{H}, C={C} channels "
                                    f"(3 RGB + {C - 3} feature) + depth + alpha, seed {wl['seed']}",
-                       "tile_instances_R": R, "frames_per_step": world,
+                       "tile_instances_R": R, "frames_per_step": world * args.views, "views_per_rank_per_step": args.views,
                        "parallelism": f"frame-parallel dp{world}, scene replica per GPU"
-                                      + (", RCCL SUM all-reduce of parameter grads" if world > 1 else "")},
+                                      + (", one RCCL SUM all-reduce of the accumulated parameter grads per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "note": "composite kernels are VALU/LDS-bound, not HBM-bound (DESIGN.md)"},
             "frame_hbm": {"algorithmic_bytes_per_frame": frame_bytes, "lineage_radix_passes": n_pass,
                           "achieved_GBps": round(frame_bytes * value / world / 1e9, 1),
-                          "frac_of_peak": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5)},
+                          "frac_of_peak": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5),
+                          "ms_per_frame": round(ms_per_step / args.views, 4)},
             "stages": per_stage,
             "stages_note": f"per-stage table from {BREAKDOWN_STEPS} untimed steps with every stage bracketed by HIP "
                            f"events; only '{dom}' is bracketed inside the timed region",

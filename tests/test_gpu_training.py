@@ -137,13 +137,14 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     env = dict(os.environ, SPLATLOC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--workload", "S0", "--no-cpu-baseline"]
+           "--warmup", "1", "--workload", "S0", "--no-cpu-baseline", "--views", "2"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]     # rank 0 prints ONE line
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["frames_per_step"] == 2 and out["scaling"] == "weak"
+    assert out["n_gpus"] == 2 and out["config"]["frames_per_step"] == 4 and out["scaling"] == "weak"
+    assert out["config"]["views_per_rank_per_step"] == 2
     assert out["value"] > 0 and out["steps"] == 3 and "roofline" in out and "cpu_baseline" not in out
 
 
