@@ -20,8 +20,11 @@ LIB_PATH = os.path.join(LIB_DIR, "libsplatraster.so")
 
 
 ARCH = "gfx950"
-COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall",
-          "-Wno-unused-function"]
+# -fno-slp-vectorize: the SLP vectoriser turns pairs of fp32 operations into v_pk_{mul,add,fma}_f32,
+# which measured SLOWER than the scalar pairs in both compositing kernels on MI355X (A/B in one
+# run: forward 0.423 -> 0.411 ms, backward 0.989 -> 0.966 ms with it off)
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-fno-slp-vectorize",
+          "-Wall", "-Wno-unused-function"]
 # translation units whose fp32 results must round exactly like the CPU oracle
 # (integer outputs derived from them are compared bit-for-bit)
 NO_CONTRACT = {"preprocess.hip", "binning.hip", "knn.hip"}
