@@ -137,7 +137,8 @@ int launch_ranges_clear(int32_t tiles, uint32_t* ranges, hipStream_t stream)
 // Per-instance payload, written once per frame in sorted order so that every later reader
 // (forward and backward compositing, four quadrant-waves per tile) streams it with coalesced
 // loads instead of chasing id -> record through 16-byte gathers scattered over HBM:
-//   irec[2j], irec[2j+1] = the 32-byte projected record of point_list[j];  imask[j] = reach bits.
+//   irec[2j] = (pixel x, y, depth, radius) of point_list[j], irec[2j+1] = its conic pre-scaled for
+//   the compositing kernels (payload_conic) and opacity;  imask[j] = reach bits.
 __global__ void __launch_bounds__(256)
 payload_kernel(int64_t R, int gx, const uint32_t* __restrict__ point_list,
                const uint32_t* __restrict__ tile_list, const float4* __restrict__ rec,
@@ -149,7 +150,7 @@ payload_kernel(int64_t R, int gx, const uint32_t* __restrict__ point_list,
     const float4 a0 = rec[2 * (size_t)g], a1 = rec[2 * (size_t)g + 1];  // one 32-byte gather
     const uint32_t ty = t / (uint32_t)gx, tx = t - ty * (uint32_t)gx;
     irec[2 * j] = a0;
-    irec[2 * j + 1] = a1;
+    irec[2 * j + 1] = payload_conic(a1);   // pre-scaled for gauss_log2 (composite_common.h)
     imask[j] = (uint8_t)quadrant_reach_mask(a0, a1, (float)(tx * TILE), (float)(ty * TILE));
     // per-tile [start, end) of the sorted list (the table was zeroed for the empty tiles)
     if (j == 0 || tile_list[j - 1] != t) ranges[2 * t] = (uint32_t)j;

@@ -75,6 +75,23 @@ __device__ __forceinline__ bool quadrant_reach(const float4 r0, const float4 r1,
     return (lim > 0.0f) && (qmin <= lim);
 }
 
+// The per-instance payload stores the conic pre-scaled for the compositing kernels:
+//   q = (-0.5 log2(e) A, -log2(e) B, -0.5 log2(e) C, opacity)
+// so that log2 of the Gaussian weight is a 5-operation polynomial and the weight itself one
+// v_exp_f32 (no separate -0.5 and log2(e) multiplies per (pixel, Gaussian)).  Forward and backward
+// call the SAME function with explicit fmaf: their alpha values are bit-identical.
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float4 payload_conic(const float4& conic_opacity)
+{
+    return make_float4(-0.5f * LOG2E * conic_opacity.x, -LOG2E * conic_opacity.y, -0.5f * LOG2E * conic_opacity.z,
+                       conic_opacity.w);
+}
+__device__ __forceinline__ float gauss_log2(const float4& q, float dx, float dy)
+{
+    return fmaf(dx, fmaf(q.y, dy, q.x * dx), (q.z * dy) * dy);
+}
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // Block id -> (tile, quadrant) for the wave-per-quadrant kernels: the four quadrants of a tile
 // get ids with the same (id % 8), i.e. they run on the same XCD (observed dispatch: block b ->
 // XCD b % 8) and share that XCD's L2 for the tile's list; speed only, never correctness.

@@ -194,10 +194,9 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 const float4 p0 = s_rec0[j0], q0 = s_rec1[j0];
                 const float4 p1 = s_rec0[j1], q1 = s_rec1[j1];
                 const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
-                const float pw0 = -0.5f * (q0.x * dx0 * dx0 + q0.z * dy0 * dy0) - q0.y * dx0 * dy0;
-                const float pw1 = -0.5f * (q1.x * dx1 * dx1 + q1.z * dy1 * dy1) - q1.y * dx1 * dy1;
-                const float al0 = fminf(ALPHA_MAX, q0.w * __expf(pw0));
-                const float al1 = fminf(ALPHA_MAX, q1.w * __expf(pw1));
+                const float pw0 = gauss_log2(q0, dx0, dy0), pw1 = gauss_log2(q1, dx1, dy1);  // log2 of the weight
+                const float al0 = fminf(ALPHA_MAX, q0.w * exp2_fast(pw0));
+                const float al1 = fminf(ALPHA_MAX, q1.w * exp2_fast(pw1));
                 // Gaussian 0
                 const bool live0 = active && pw0 <= 0.0f && al0 >= ALPHA_MIN;
                 const float tT0 = T * (1.0f - al0);
