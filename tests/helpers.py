@@ -80,13 +80,21 @@ class HipRun:
         return None if t is None else t.detach().cpu().numpy()
 
 
-def assert_grad_close(name, got, ref, rtol=2e-3, atol_scale=1e-4):
-    """|got - ref| <= rtol*|ref| + atol_scale*max|ref| elementwise (atomics reorder sums)."""
+def assert_grad_close(name, got, ref, rtol=2e-3, atol_scale=1e-4, allow_frac=0.0, outlier_factor=30.0):
+    """|got - ref| <= rtol*|ref| + atol_scale*max|ref| elementwise (atomics reorder sums).
+    allow_frac > 0 (full-size frames only): that fraction of the elements may miss the bar — the
+    Gaussians behind an alpha >= 1/255 test that flipped within an ulp — but by no more than
+    outlier_factor times the tolerance."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
     scale = np.abs(ref).max() if ref.size else 0.0
     tol = rtol * np.abs(ref) + atol_scale * scale + 1e-30
     bad = np.abs(got - ref) > tol
+    if allow_frac > 0.0 and bad.any():
+        assert bad.mean() <= allow_frac and not (np.abs(got - ref) > outlier_factor * tol).any(), (
+            f"{name}: {bad.sum()} / {bad.size} elements off (allowed fraction {allow_frac}); worst abs err "
+            f"{np.abs(got - ref).max():.3e} (scale {scale:.3e})")
+        return
     assert not bad.any(), (f"{name}: {bad.sum()} / {bad.size} elements off; worst abs err "
                            f"{np.abs(got - ref).max():.3e} (scale {scale:.3e})")

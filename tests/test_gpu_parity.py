@@ -48,19 +48,20 @@ def _check_forward(run: HipRun, f: dict, sc):
     assert P == rec0.shape[0] and (H, W) == nc.shape
 
 
-def _check_backward(run: HipRun, b: dict):
-    assert_grad_close("dL_dmeans3D", run.np(run.means3D.grad), b["dL_dmeans3D"])
-    assert_grad_close("dL_dmeans2D", run.np(run.means2D.grad), b["dL_dmeans2D"])
-    assert_grad_close("dL_dopacities", run.np(run.opacities.grad), b["dL_dopacities"])
+def _check_backward(run: HipRun, b: dict, allow_frac=0.0):
+    kw = dict(allow_frac=allow_frac)
+    assert_grad_close("dL_dmeans3D", run.np(run.means3D.grad), b["dL_dmeans3D"], **kw)
+    assert_grad_close("dL_dmeans2D", run.np(run.means2D.grad), b["dL_dmeans2D"], **kw)
+    assert_grad_close("dL_dopacities", run.np(run.opacities.grad), b["dL_dopacities"], **kw)
     if run.colors is not None:
-        assert_grad_close("dL_dcolors", run.np(run.colors.grad), b["dL_dcolors"])
+        assert_grad_close("dL_dcolors", run.np(run.colors.grad), b["dL_dcolors"], **kw)
     if run.shs is not None:
-        assert_grad_close("dL_dshs", run.np(run.shs.grad), b["dL_dshs"])
+        assert_grad_close("dL_dshs", run.np(run.shs.grad), b["dL_dshs"], **kw)
     if run.scales is not None:
-        assert_grad_close("dL_dscales", run.np(run.scales.grad), b["dL_dscales"])
-        assert_grad_close("dL_drotations", run.np(run.rotations.grad), b["dL_drotations"])
+        assert_grad_close("dL_dscales", run.np(run.scales.grad), b["dL_dscales"], **kw)
+        assert_grad_close("dL_drotations", run.np(run.rotations.grad), b["dL_drotations"], **kw)
     if run.cov3D is not None:
-        assert_grad_close("dL_dcov3D", run.np(run.cov3D.grad), b["dL_dcov3D"])
+        assert_grad_close("dL_dcov3D", run.np(run.cov3D.grad), b["dL_dcov3D"], **kw)
 
 
 @pytest.mark.parametrize("cfg", [
@@ -273,6 +274,16 @@ def test_full_size_properties():
     assert np.array_equal(run.np(st["point_list"]).astype(np.uint32), f["point_list"])
     assert np.array_equal(run.np(st["ranges"]).astype(np.uint32), f["ranges"])
     assert np.abs(run.np(run.alpha) - f["alpha"]).max() <= IMG_TOL
+    # gradients of the full-size frame against the oracle's backward (OpenMP build: seconds on the box)
+    # At ~1e9 (pixel, Gaussian) evaluations a handful land within an ulp of the alpha >= 1/255 test
+    # and go the other way than in the oracle (v_exp_f32 vs libm expf): such a flip moves the pixel
+    # by <= 1/255 * T * colour.  So: <= 1e-4 everywhere except on <= 1e-5 of the pixels, and
+    # <= 1/255 there.
+    fb = oracle_forward(sc, omp=True)
+    dcol = np.abs(run.np(run.color) - fb["color"])
+    flipped = (dcol > IMG_TOL).any(axis=0)
+    assert flipped.mean() <= 1e-5 and dcol.max() <= 1.0 / 255.0, (int(flipped.sum()), float(dcol.max()))
+    _check_backward(run, oracle_backward(fb, sc, omp=True), allow_frac=2e-5)
     # linearity: backward(2 g) == 2 backward(g)
     g1 = run.means3D.grad.clone()
     c1 = run.colors.grad.clone()
