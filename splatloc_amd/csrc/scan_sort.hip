@@ -18,6 +18,9 @@ constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
 constexpr int SORT_THREADS = 256;
+#ifndef SR_SORT_LOOKBACK
+#define SR_SORT_LOOKBACK 8  // predecessors whose status words are loaded together in the look-back
+#endif
 #ifndef SR_SORT_ITEMS
 #define SR_SORT_ITEMS 16
 #endif
@@ -516,7 +519,7 @@ sort_sweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_
             __hip_atomic_store(mine, cnt | ST_LOCAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // LOOKBACK independent loads in flight per step: the walk over predecessors that have
             // only published their local count costs one L2 round trip per LOOKBACK blocks
-            constexpr int LOOKBACK = 8;
+            constexpr int LOOKBACK = SR_SORT_LOOKBACK;
             int64_t pb = (int64_t)bid - 1;
             uint32_t spins = 0;
             bool done = false;
