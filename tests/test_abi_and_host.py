@@ -67,6 +67,22 @@ def test_bad_arguments_return_status_not_crash():
     assert lib.splatknn_dist2(-1, None, None, None, None) == 1
     assert lib.splatknn_dist2(0, None, None, None, None) == 0
     assert lib.splatraster_sort_pairs_u32(5, None, None, 8, None, None) == 1
+    # the §8f stages validate before any HIP call too
+    N13, N19 = [None] * 13, [None] * 19
+    assert lib.splatraster_activate_forward(0, 1, 0, 3, 0, *N13) == 0                   # P = 0: nothing to do
+    assert lib.splatraster_activate_forward(10, 1, 0, 3, 0, *N13) == 1                  # null inputs
+    assert lib.splatraster_activate_forward(10, 1, 4, 3, 0, *N13) == 3                  # SH degree 4: unsupported
+    assert lib.splatraster_activate_forward(10, 1, 1, 3, 0, *N13) == 1                  # degree 1 needs 4 coefficients
+    assert lib.splatraster_activate_forward(10, 1, 0, 2, 0, *N13) == 1                  # scaling columns must be 1 or 3
+    assert lib.splatraster_activate_backward(10, 4, 1, 3, 1, *N19) == 1
+    assert lib.splatraster_mapping_loss(0, *([None] * 6), C.c_float(0.01), *([None] * 7)) == 1
+    assert lib.splatraster_mapping_loss(100, *([None] * 6), C.c_float(0.01), *([None] * 7)) == 1
+    assert lib.splatraster_refinement_loss(3, 0, 8, C.c_float(0.2), *([None] * 6)) == 1
+    assert lib.splatraster_densification_stats(-1, *([None] * 6)) == 1
+    assert lib.splatraster_densification_stats(0, *([None] * 6)) == 0
+    assert lib.splatraster_mapping_loss_workspace_bytes(640 * 480) > 0
+    assert lib.splatraster_refinement_loss_workspace_bytes(3, 480, 640) >= 3 * 4 * 3 * 480 * 640
+    assert lib.splatraster_timing_select(0) == 0 and lib.splatraster_timing_enable(0) == 0
 
 
 def test_drop_in_module_names():
