@@ -49,10 +49,6 @@
 #ifndef SR_BWD_SKIP_BRANCH
 #define SR_BWD_SKIP_BRANCH 0  // 1 = skip a candidate pair that no pixel of the quadrant hits (A/B: slower, more VGPRs)
 #endif
-#ifndef SR_BWD_WX
-#define SR_BWD_WX 0  // 1 = third flush block for the channels beyond 32 + depth, butterfly keeps 6 values per
-                    // Gaussian (A/B: 160 VGPRs -> 3 waves/SIMD, 16 more f32 MFMAs per flush: 1.02 vs 0.96 ms)
-#endif
 #ifndef SR_BWD_PACKED_MOMENTS
 #define SR_BWD_PACKED_MOMENTS 0  // 1 = moment / channel products of a pair as v_pk_mul_f32 (A/B: 10 instructions fewer per pair but 1.04 vs 0.99 ms)
 #endif
@@ -80,15 +76,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NC>
 struct BwdCfg {
     static constexpr bool MFMA = NC >= 32;
-    static constexpr int NM = MFMA ? 32 : 0;   // channels reduced on the matrix pipe (two 16-column blocks)
-    // SR_BWD_WX: a third 16-column block of the flush contraction takes the channels beyond 32 and the
-    // depth column (w g_D), so only the 6 E-moments are left to the butterfly
-    static constexpr bool WX = MFMA && SR_BWD_WX;
-    static constexpr int NX = WX ? NC - NM : 0;          // leftover channels in the third block (+1 depth column)
-    static constexpr int NV = NC - NM - NX;              // channels reduced with the packed butterfly
-    static constexpr int KV = NV + (WX ? 6 : 7);         // butterfly values per Gaussian
-    static_assert(NX + 1 <= 16, "third block: leftover channels + depth fit 16 columns");
-    static_assert(!(WX && SR_BWD_PACKED_MOMENTS), "the packed-moment variant assumes the 7-value record");
+    static constexpr int NM = MFMA ? 32 : 0;   // channels reduced on the matrix pipe
+    static constexpr int NV = NC - NM;         // channels reduced with the packed butterfly
+    static constexpr int KV = NV + 7;          // butterfly values per Gaussian
     static constexpr int NCP = (NC + 3) & ~3;
     static constexpr int FS = SR_BWD_FS;             // feature rows staged per round
     static constexpr int GROUP = 16;           // Gaussians per MFMA flush (M of v_mfma_f32_16x16x4_f32)
@@ -108,8 +98,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      int MO)
 {
     using Cfg = BwdCfg<NC>;
-    constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS, NX = Cfg::NX;
-    constexpr bool WX = Cfg::WX;
+    constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
     constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
     constexpr bool MFMA = Cfg::MFMA;
     constexpr bool DOTM = NC >= SR_BWD_DOTM_MIN;  // dot products q = f . g on the matrix pipe
@@ -174,16 +163,13 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     // B operand of the contraction, kept in registers for the whole tile: for k-step kk and
     // channel half t, lane l holds dL/dcolor[pix = 4 kk + (l >> 4)][ch = 16 t + (l & 15)].
     // Built once by transposing through the (still unused) weight panel.
-    float gt[MFMA ? 16 : 1][WX ? 3 : 2];
+    float gt[MFMA ? 16 : 1][2];
     if (MFMA) {
 #pragma unroll
-        for (int t = 0; t < (WX ? 3 : 2); ++t) {
+        for (int t = 0; t < 2; ++t) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int ch = 0; ch < 16; ++ch) {
-                const int col = 16 * t + ch;   // third block: leftover channels, then the depth column, then zeros
-                s_w[lane * WS + ch] = col < NC ? g[col < NC ? col : 0] : (col == NC ? gD : 0.0f);
-            }
+            for (int ch = 0; ch < 16; ++ch) s_w[lane * WS + ch] = g[16 * t + ch];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) gt[kk][t] = s_w[(4 * kk + (lane >> 4)) * WS + (lane & 15)];
@@ -218,14 +204,13 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     auto flush_panel = [&](int count) {
         BP_T(tf0);
         __builtin_amdgcn_wave_barrier();
-        f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
         const int row = (lane >> 4) * WS + (lane & 15);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const float a = s_w[4 * kk * WS + row];
             D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][0], D0, 0, 0, 0);
             D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][1], D1, 0, 0, 0);
-            if constexpr (WX) D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][2], D2, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -237,10 +222,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #else
                 atomicAdd(dst, D0[r]);
                 atomicAdd(dst + 16, D1[r]);
-                if constexpr (WX) {
-                    const int c = lane & 15;   // leftover channel c, or the depth moment (slot 6 of the record)
-                    if (c <= NX) atomicAdd(gacc + (size_t)s_gid[gs] * GROW + (c < NX ? c0 + NM + c : MO + 6), D2[r]);
-                }
 #endif
             }
         }
@@ -392,8 +373,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #else
 #pragma unroll
                 for (int ch = 0; ch < NV; ++ch) {
-                    red[ch] = w0 * g[NM + NX + ch];
-                    red[KV + ch] = w1 * g[NM + NX + ch];
+                    red[ch] = w0 * g[NM + ch];
+                    red[KV + ch] = w1 * g[NM + ch];
                 }
                 // geometric partials as raw moments of E = G dL/dalpha over the pixel offset d;
                 // the per-Gaussian factors (conic, opacity, 0.5 W / 0.5 H) are applied once per
@@ -406,7 +387,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     red[NV + 3] = Ex * dy0;
                     red[NV + 4] = Ey * dy0;
                     red[NV + 5] = E;
-                    if constexpr (!WX) red[NV + 6] = w0 * gD;
+                    red[NV + 6] = w0 * gD;
                 }
                 {
                     const float E = G1 * dA1, Ex = E * dx1, Ey = E * dy1;
@@ -416,7 +397,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     red[KV + NV + 3] = Ex * dy1;
                     red[KV + NV + 4] = Ey * dy1;
                     red[KV + NV + 5] = E;
-                    if constexpr (!WX) red[KV + NV + 6] = w1 * gD;
+                    red[KV + NV + 6] = w1 * gD;
                 }
 #endif
                 BP_T(tp2);
