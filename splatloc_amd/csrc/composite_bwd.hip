@@ -49,9 +49,6 @@
 #ifndef SR_BWD_SKIP_BRANCH
 #define SR_BWD_SKIP_BRANCH 0  // 1 = skip a candidate pair that no pixel of the quadrant hits (A/B: slower, more VGPRs)
 #endif
-#ifndef SR_BWD_PACKED_MOMENTS
-#define SR_BWD_PACKED_MOMENTS 0  // 1 = moment / channel products of a pair as v_pk_mul_f32 (A/B: 10 instructions fewer per pair but 1.04 vs 0.99 ms)
-#endif
 #ifndef SR_BWD_DOTM_MIN
 #define SR_BWD_DOTM_MIN 8  // channels from which the 4x4x1 MFMA dot product is used
 #endif
@@ -346,31 +343,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     T *= 1.0f - al1;
                 }
                 float red[2 * KV];
-#if SR_BWD_PACKED_MOMENTS
-                // both Gaussians of the pair as 2-vectors: the products below are v_pk_mul_f32
-                // (two fp32 multiplies per instruction)
-                {
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const f32x2 w = {w0, w1}, gd = {gD, gD};
-#pragma unroll
-                    for (int ch = 0; ch < NV; ++ch) {
-                        const f32x2 gg = {g[NM + ch], g[NM + ch]};
-                        const f32x2 r = w * gg;
-                        red[ch] = r.x;
-                        red[KV + ch] = r.y;
-                    }
-                    const f32x2 G = {G0, G1}, dA = {dA0, dA1}, dx = {dx0, dx1}, dy = {dy0, dy1};
-                    const f32x2 E = G * dA, Ex = E * dx, Ey = E * dy;
-                    const f32x2 Exx = Ex * dx, Exy = Ex * dy, Eyy = Ey * dy, wd = w * gd;
-                    red[NV + 0] = Ex.x;  red[KV + NV + 0] = Ex.y;
-                    red[NV + 1] = Ey.x;  red[KV + NV + 1] = Ey.y;
-                    red[NV + 2] = Exx.x; red[KV + NV + 2] = Exx.y;
-                    red[NV + 3] = Exy.x; red[KV + NV + 3] = Exy.y;
-                    red[NV + 4] = Eyy.x; red[KV + NV + 4] = Eyy.y;
-                    red[NV + 5] = E.x;   red[KV + NV + 5] = E.y;
-                    red[NV + 6] = wd.x;  red[KV + NV + 6] = wd.y;
-                }
-#else
 #pragma unroll
                 for (int ch = 0; ch < NV; ++ch) {
                     red[ch] = w0 * g[NM + ch];
@@ -399,7 +371,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     red[KV + NV + 5] = E;
                     red[KV + NV + 6] = w1 * gD;
                 }
-#endif
                 BP_T(tp2);
                 BP_ADD(3, tp2 - tp1);
                 const float outv = wave_reduce_pack<2 * KV>(red, lane);
