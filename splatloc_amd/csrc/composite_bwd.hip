@@ -50,7 +50,7 @@
 #define SR_BWD_SKIP_BRANCH 0  // 1 = skip a candidate pair that no pixel of the quadrant hits (A/B: slower, more VGPRs)
 #endif
 #ifndef SR_BWD_DOT_CHAINS
-#define SR_BWD_DOT_CHAINS 2  // independent accumulators of the 4x4x1 MFMA dot product (A/B: 1: 0.950, 2: 0.928, 3: 0.944 (other box), 6 spills)
+#define SR_BWD_DOT_CHAINS 2  // (>= 1) independent accumulators of the 4x4x1 MFMA dot product (A/B: 1: 0.950, 2: 0.928, 3: 0.944 (other box), 6 spills)
 #endif
 #ifndef SR_BWD_DOTM_MIN
 #define SR_BWD_DOTM_MIN 8  // channels from which the 4x4x1 MFMA dot product is used
@@ -407,6 +407,28 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     }
                 }
             };
+            // q[pix][g] = sum_ch F[g][ch] G[pix][ch] + z_g g_D for four staged rows on the matrix pipe:
+            // v_mfma_f32_4x4x1_16b_f32 computes D[lane 4b+j][r] += A[lane 4b+r] * B[lane 4b+j]; with A =
+            // feature of Gaussian (lane & 3) and B = this pixel's gradient, register r of every lane ends
+            // up holding q[own pixel][Gaussian r].
+            auto dot4 = [&](int slot4) -> f32x4 {
+                const int k = lane & 3;
+                const int srow = min(slot4 + k, ncand - 1);
+                const float* fr = &s_feat[srow * NCP];
+                const float zsel = reinterpret_cast<const float*>(&s_rec0[srow])[2];
+                constexpr int CH = SR_BWD_DOT_CHAINS;   // independent accumulation chains
+                f32x4 Qc[CH];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) Qc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ch = 0; ch < NC; ++ch)
+                    Qc[ch % CH] = __builtin_amdgcn_mfma_f32_4x4x1f32(fr[ch], g[ch], Qc[ch % CH], 0, 0, 0);
+                Qc[NC % CH] = __builtin_amdgcn_mfma_f32_4x4x1f32(zsel, gD, Qc[NC % CH], 0, 0, 0);
+                f32x4 Q = Qc[0];
+#pragma unroll
+                for (int c = 1; c < CH; ++c) Q += Qc[c];
+                return Q;
+            };
 #pragma unroll 1
             for (int slot = 0; slot < ncand; slot += (DOTM ? 4 : 2)) {
                 // pop the next two (four) candidates; hasK are wave-uniform
@@ -422,36 +444,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 float qm[4] = {0.f, 0.f, 0.f, 0.f};
                 BP_T(td0);
                 if (DOTM) {
-                    // q[pix][g] = sum_ch F[g][ch] G[pix][ch] + z_g g_D for the four Gaussians on the
-                    // matrix pipe: v_mfma_f32_4x4x1_16b_f32 computes D[lane 4b+j][r] += A[lane 4b+r] *
-                    // B[lane 4b+j]; with A = feature of Gaussian (lane & 3) and B = this pixel's
-                    // gradient, register r of every lane ends up holding q[own pixel][Gaussian r].
-                    const int k = lane & 3;
-                    const int srow = min(slot + k, ncand - 1);
-                    const float* fr = &s_feat[srow * NCP];
-                    const float zsel = reinterpret_cast<const float*>(&s_rec0[srow])[2];
-#if SR_BWD_DOT_CHAINS > 1
-                    // SR_BWD_DOT_CHAINS independent accumulation chains (channel ch goes to chain
-                    // ch % CH): the dependent-MFMA latency per group shrinks accordingly
-                    constexpr int CH = SR_BWD_DOT_CHAINS;
-                    f32x4 Qc[CH];
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) Qc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ch = 0; ch < NC; ++ch)
-                        Qc[ch % CH] = __builtin_amdgcn_mfma_f32_4x4x1f32(fr[ch], g[ch], Qc[ch % CH], 0, 0, 0);
-                    Qc[NC % CH] = __builtin_amdgcn_mfma_f32_4x4x1f32(zsel, gD, Qc[NC % CH], 0, 0, 0);
-                    f32x4 Q = Qc[0];
-#pragma unroll
-                    for (int c = 1; c < CH; ++c) Q += Qc[c];
+                    const f32x4 Q = dot4(slot);
                     qm[0] = Q[0]; qm[1] = Q[1]; qm[2] = Q[2]; qm[3] = Q[3];
-#else
-                    f32x4 Q = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ch = 0; ch < NC; ++ch) Q = __builtin_amdgcn_mfma_f32_4x4x1f32(fr[ch], g[ch], Q, 0, 0, 0);
-                    Q = __builtin_amdgcn_mfma_f32_4x4x1f32(zsel, gD, Q, 0, 0, 0);
-                    qm[0] = Q[0]; qm[1] = Q[1]; qm[2] = Q[2]; qm[3] = Q[3];
-#endif
 #ifdef SR_BWD_PROFILE
                     asm volatile("" ::"v"(qm[0]), "v"(qm[3]));
 #endif
