@@ -444,6 +444,7 @@ def main():
             color, depth, alpha, radii = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors,
                                               opacities=opac, scales=scales, rotations=rots, cov3D_precomp=None)
             info["R"] = color.grad_fn.num_rendered
+            info["radii"] = radii
             if not args.fwd_only:
                 torch.autograd.backward((color, depth, alpha), g_out)
         if not args.fwd_only:
@@ -489,6 +490,7 @@ def main():
 
     if rank == 0:
         R = int(info["R"])
+        V = int((info["radii"] > 0).sum().item())
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         st_bytes, frame_bytes, n_pass = algorithmic_bytes(P, R, W, H, C, tiles)
         ms_per_step = 1e3 * elapsed / args.steps
@@ -515,7 +517,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: P={P} Gaussians, {W}x{H}, C={C} channels "
                                    f"(3 RGB + {C - 3} feature) + depth + alpha, seed {wl['seed']}",
-                       "tile_instances_R": R, "frames_per_step": world * args.views, "views_per_rank_per_step": args.views,
+                       "tile_instances_R": R, "visible_gaussians_V": V, "frames_per_step": world * args.views, "views_per_rank_per_step": args.views,
                        "parallelism": f"frame-parallel dp{world}, scene replica per GPU"
                                       + (", one RCCL SUM all-reduce of the accumulated parameter grads per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
