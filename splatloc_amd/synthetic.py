@@ -69,6 +69,8 @@ WORKLOADS = {
     "S1": dict(P=300_000, W=1200, H=680, C=3, seed=1, scale_median=0.010),
     "S2": dict(P=500_000, W=1920, H=1080, C=35, seed=2, scale_median=0.00627),   # R = 4.0 M (R/P = 8)
     "S2-ref-layout": dict(P=500_000, W=640, H=480, C=4, seed=2, scale_median=0.00627),
+    "S1-640": dict(P=300_000, W=640, H=480, C=3, seed=1, scale_median=0.010),                 # S1 at the reference resolution
+    "S2-640": dict(P=500_000, W=640, H=480, C=35, seed=2, scale_median=0.00627),              # S2 channels at the reference resolution
 }
 
 
