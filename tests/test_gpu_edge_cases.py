@@ -141,3 +141,20 @@ def test_two_streams_interleaved():
         assert float((r.depth - ref.depth).abs().max()) == 0.0
         scale = float(ref.means3D.grad.abs().max())
         assert float((r.means3D.grad - ref.means3D.grad).abs().max()) <= 2e-3 * scale
+
+
+def test_forward_under_no_grad_like_eval_rendering():
+    """utils/eval_utils.py:46 renders inside torch.no_grad(): same image, no autograd state."""
+    from splatloc_amd import GaussianRasterizer
+    from tests.helpers import hip_settings
+    sc = make_scene(5000, 320, 240, 4, seed=71, scale_median=0.03)
+    ref = HipRun(sc, backward=False)
+    dev = torch.device("cuda:0")
+    s = sc.to(dev)
+    with torch.no_grad():
+        color, depth, alpha, radii = GaussianRasterizer(raster_settings=hip_settings(s, dev))(
+            means3D=s.means3D, means2D=torch.zeros_like(s.means3D), shs=None, colors_precomp=s.features,
+            opacities=s.opacities, scales=s.scales, rotations=s.rotations, cov3D_precomp=None)
+    assert color.grad_fn is None and not color.requires_grad
+    assert torch.equal(color, ref.color.detach()) and torch.equal(depth, ref.depth.detach())
+    assert torch.equal(alpha, ref.alpha.detach()) and torch.equal(radii, ref.radii)
