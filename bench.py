@@ -169,7 +169,7 @@ def bench_loss(args, dev):
     depth = (0.5 + 3 * torch.rand(1, H, W, generator=g)).to(dev).requires_grad_(True)
     marker = (2 * torch.randn(H, W, generator=g)).to(dev).requires_grad_(True)
     gt_image, gt_depth = torch.rand(3, H, W, generator=g).to(dev), (0.5 + 3 * torch.rand(H, W, generator=g)).to(dev)
-    kp = (torch.rand(H, W, generator=g) > 0.9).to(dev)
+    kp = (torch.rand(H, W, generator=g) ** 4).to(dev)   # float score map: soft BCE targets (train_gaussians.py:40)
     a = torch.tensor([0.05], device=dev, requires_grad=True)
     b = torch.tensor([0.02], device=dev, requires_grad=True)
     leaves = [image, depth, marker, a, b]
@@ -192,7 +192,7 @@ def bench_loss(args, dev):
         gi, gd, gm = torch.empty_like(image), torch.empty_like(depth), torch.empty_like(marker)
         out = torch.empty(4, device=dev)
         ex = torch.cat((a, b)).detach()
-        k8 = kp.to(torch.uint8)
+        k8 = kp.to(torch.float32).contiguous()
         ws = torch.empty(lib.splatraster_mapping_loss_workspace_bytes(H * W), dtype=torch.uint8, device=dev)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -242,7 +242,7 @@ def bench_loss(args, dev):
 
     wall_rf, gpu_rf = time_it(refine_fused)
     wall_rc, gpu_rc = time_it(refine_composed)
-    nbytes = H * W * (9 * 4 + 1 + 5 * 4)
+    nbytes = H * W * (9 * 4 + 4 + 5 * 4)
     ach = nbytes / (gpu_k * 1e-3) / 1e9
     print(json.dumps({
         "metric": "mapping loss + gradient passes/s at 1920x1080 (SURVEY 8f-2 stage; NOT the BASELINE metric)",
@@ -296,7 +296,7 @@ def bench_map_step(args, dev):
         cam = PinholeCamera(W, H, W / 2.0, W / 2.0, (W - 1) / 2.0, (H - 1) / 2.0, R, torch.tensor([0.01 * k, 0.0, 0.0])).to(dev)
         cam.original_image = torch.rand(3, H, W, generator=g).to(dev)
         cam.depth = (0.5 + 3 * torch.rand(H, W, generator=g)).to(dev)
-        cam.kp_score = (torch.rand(H, W, generator=g) > 0.9).to(dev)
+        cam.kp_score = (torch.rand(H, W, generator=g) ** 4).to(dev)   # float score map (utils/dataset.py:94)
         cam.exposure_a = torch.zeros(1, device=dev, requires_grad=True)
         cam.exposure_b = torch.zeros(1, device=dev, requires_grad=True)
         views.append(cam)

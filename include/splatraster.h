@@ -33,12 +33,17 @@
 extern "C" {
 #endif
 
+/* bumped on every change of a signature or buffer layout; the Python binding refuses a library
+ * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
+ * ctypes with mismatched arguments) */
+#define SPLATRASTER_ABI_VERSION 2
+
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
 /* status codes */
 #define SPLATRASTER_OK 0
 #define SPLATRASTER_ERR_BAD_ARG 1      /* null pointer / inconsistent sizes / both-or-neither inputs */
-#define SPLATRASTER_ERR_HIP 2          /* a HIP runtime call or kernel launch failed */
+#define SPLATRASTER_ERR_HIP 2          /* a HIP runtime call or kernel launch failed, or a look-back watchdog fired */
 #define SPLATRASTER_ERR_UNSUPPORTED 3  /* e.g. sh_degree > 3 */
 #define SPLATRASTER_ERR_OVERFLOW 4     /* tile instance count does not fit the binning buffer */
 
@@ -243,11 +248,12 @@ int splatraster_densification_stats(int32_t P, const float* viewspace_grad /* [P
  *      + get_loss_marker(config, marker, viewpoint.kp_score) (train_gaussians.py:38-42),
  * the per-view sum of train_gaussians.py:217-218, and its gradient w.r.t. the rendered buffers,
  * in one pass.  image / g_image are 3 planes of H*W floats with plane stride H*W (they may point
- * into a [C,H,W] render and its gradient), marker / g_marker one plane.  kp is the uint8 (bool)
- * key-point mask.  out[4] = { rgbd loss, marker loss, dL/dexposure_a, dL/dexposure_b } (device). */
+ * into a [C,H,W] render and its gradient), marker / g_marker one plane.  kp is the float32
+ * key-point score map used as the (soft) BCE target, `gt.view(-1).float()` at train_gaussians.py:40
+ * (a bool mask is passed as 0.0 / 1.0).  out[4] = { rgbd loss, marker loss, dL/dexposure_a, dL/dexposure_b } (device). */
 size_t splatraster_mapping_loss_workspace_bytes(int32_t pixels);
 int splatraster_mapping_loss(int32_t pixels, const float* image, const float* depth, const float* marker,
-                             const float* gt_image, const float* gt_depth, const uint8_t* kp,
+                             const float* gt_image, const float* gt_depth, const float* kp,
                              float rgb_boundary_threshold, const float* exposure /* [2] = a, b or NULL */,
                              float* g_image, float* g_depth, float* g_marker, float* out /* [4] */,
                              void* workspace, void* stream);
@@ -294,6 +300,18 @@ int splatraster_timing_select(uint32_t stage_mask); /* bit s set: time stage s o
 int splatraster_timing_collect(double* ms, int64_t* counts);
 
 /* ---- misc ---------------------------------------------------------------------------- */
+
+/* The decoupled look-backs of the one-pass scan and of the one-sweep radix sort spin with a bound.
+ * A timeout raises a flag in host-mapped memory; forward_geometry / forward_render / backward /
+ * sort_pairs poll it on entry (and forward_geometry again after its host wait) and return
+ * SPLATRASTER_ERR_HIP, so a timed-out scan or sort is never a silently wrong image.  The work is
+ * asynchronous: the failing call may be a later one on the same device.  splatraster_poll_errors()
+ * polls explicitly (after a stream synchronize it is exact). */
+int splatraster_poll_errors(void);
+/* test hooks: spin bound of the look-backs (default 1 << 24; 0 forces a timeout wherever a block
+ * has to wait), and y[i] = the device's 2^x (the alpha arithmetic shared with the CPU oracle). */
+int splatraster_debug_set_spin_limit(uint32_t limit);
+int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
 
 const char* splatraster_error_string(int status);
 /* last HIP error text recorded by this thread (empty string when none). */

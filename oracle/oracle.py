@@ -212,3 +212,19 @@ def dist2(points, omp: bool = True) -> np.ndarray:
     out = np.zeros(points.shape[0], np.float32)
     _lib(omp).orc_dist2(C.c_int32(points.shape[0]), _p(points), _p(out))
     return out
+
+
+def exp2(x) -> np.ndarray:
+    """The oracle's 2^x (orc_exp2: the alpha arithmetic shared bit-for-bit with the HIP path)."""
+    lib = _lib(False)
+    lib.orc_exp2_array.restype = None
+    x = _f32(x).ravel()
+    out = np.zeros_like(x)
+    lib.orc_exp2_array(C.c_int64(x.size), _p(x), _p(out))
+    return out
+
+
+def set_alpha_mode(mode: int) -> None:
+    """0 = shared arithmetic contract (default), 1 = the lineage's literal expf form (both builds)."""
+    for omp in (False, True):
+        _lib(omp).orc_set_alpha_mode(C.c_int(mode))

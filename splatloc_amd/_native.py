@@ -11,6 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
+ABI_VERSION = 2   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 _ERR_NAMES = {1: "bad argument", 2: "HIP runtime error", 3: "unsupported configuration",
@@ -77,6 +78,9 @@ SYMBOLS = {
     "splatraster_error_string": (C.c_char_p, [C.c_int]),
     "splatraster_last_hip_error": (C.c_char_p, []),
     "splatraster_abi_version": (C.c_int, []),
+    "splatraster_poll_errors": (C.c_int, []),
+    "splatraster_debug_set_spin_limit": (C.c_int, [C.c_uint32]),
+    "splatraster_debug_exp2": (C.c_int, [_i64, _vp, _vp, _vp]),
 }
 
 
@@ -90,16 +94,24 @@ def load(build_if_missing: bool = True):
     if _LIB is not None:
         return _LIB
     path = os.environ.get("SPLATRASTER_LIB", _build.LIB_PATH)  # override: perf experiments only
-    if not os.path.exists(path):
-        if not build_if_missing:
-            raise RuntimeError(f"{path} is missing: run `python -m splatloc_amd.build`")
+    if path == _build.LIB_PATH and build_if_missing and _build.have_hipcc():
+        # mtime-cached: a no-op when nothing changed, a rebuild when a source / header is newer than
+        # the in-tree .so (which is git-ignored and survives checkouts)
         try:
             _build.build()
         except Exception as e:  # noqa: BLE001
             raise RuntimeError(
-                "splatloc_amd: the HIP extension libsplatraster.so is missing and could not be built "
+                "splatloc_amd: the HIP extension libsplatraster.so could not be built "
                 f"({e}). There is no CPU fallback.") from e
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing and hipcc is not available: run `python -m splatloc_amd.build` "
+                           "on a machine with ROCm. There is no CPU fallback.")
     lib = C.CDLL(path)
+    lib.splatraster_abi_version.restype = C.c_int
+    got = int(lib.splatraster_abi_version())
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{path} has ABI version {got}, this binding needs {ABI_VERSION}: stale library, "
+                           "rebuild with `python -m splatloc_amd.build --force`")
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res

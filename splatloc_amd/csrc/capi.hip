@@ -17,6 +17,8 @@ void set_hip_error(hipError_t e, const char* what)
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
 }
 
+void set_error_text(const char* text) { g_last_error = text; }
+
 // ---- stage timing ---------------------------------------------------------------------
 struct StageRec { int stage; hipEvent_t a, b; };
 static uint32_t g_timing_mask = 0;  // bit s: stage s is bracketed by an event pair
@@ -210,7 +212,7 @@ using namespace sr;
 
 extern "C" {
 
-int splatraster_abi_version(void) { return 1; }
+int splatraster_abi_version(void) { return SPLATRASTER_ABI_VERSION; }
 
 const char* splatraster_error_string(int status)
 {
@@ -282,6 +284,10 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
         if (s->sh_degree < 0 || s->sh_degree > 3) return SPLATRASTER_ERR_UNSUPPORTED;
         if (s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1)) return SPLATRASTER_ERR_BAD_ARG;
     }
+    st = lookback_error_init();
+    if (st) return st;
+    st = lookback_error_poll();   // a timed-out scan / sort of an earlier call on this device
+    if (st) return st;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const GeomLayout L = geom_layout(P);
     GeomView g = geom_view(geometry, P);
@@ -321,7 +327,7 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
     for (size_t k = 0; k < nblk; ++k) total += slot->p[k];
     if (total >= ((uint64_t)1 << 31)) return SPLATRASTER_ERR_OVERFLOW;
     *num_rendered = (int64_t)total;
-    return SPLATRASTER_OK;
+    return lookback_error_poll();
 }
 
 int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t R, const float* bg,
@@ -333,6 +339,8 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
     if (P < 0 || R < 0 || !image || !out_color || !out_depth || !out_alpha) return SPLATRASTER_ERR_BAD_ARG;
     if (s->bg_channels > 0 && !bg) return SPLATRASTER_ERR_BAD_ARG;
     if (P > 0 && (!geometry || !binning)) return SPLATRASTER_ERR_BAD_ARG;
+    st = lookback_error_poll();
+    if (st) return st;
     if (R > 0 && !binning) return SPLATRASTER_ERR_BAD_ARG;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int W = s->image_width, H = s->image_height;
@@ -400,7 +408,13 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     int st = check_settings(s);
     if (st) return st;
     if (P < 0 || R < 0) return SPLATRASTER_ERR_BAD_ARG;
-    if (P == 0) return SPLATRASTER_OK;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (P == 0) {   // nothing to differentiate: the camera gradients are still defined (zero)
+        if (dL_dviewmatrix) SR_HIP_CHECK(hipMemsetAsync(dL_dviewmatrix, 0, 16 * sizeof(float), stream));
+        if (dL_dprojmatrix) SR_HIP_CHECK(hipMemsetAsync(dL_dprojmatrix, 0, 16 * sizeof(float), stream));
+        if (dL_dcampos) SR_HIP_CHECK(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), stream));
+        return SPLATRASTER_OK;
+    }
     if (!means3D || !viewmatrix || !projmatrix || !radii || !geometry || !binning || !image || !out_color ||
         !out_depth || !dL_dout_color || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacities)
         return SPLATRASTER_ERR_BAD_ARG;
@@ -408,7 +422,8 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     if (!shs && (!colors_precomp || !dL_dcolors)) return SPLATRASTER_ERR_BAD_ARG;
     if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
         return SPLATRASTER_ERR_BAD_ARG;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    st = lookback_error_poll();   // this frame's tile sort (when the GPU got that far) or an earlier call
+    if (st) return st;
     const int W = s->image_width, H = s->image_height;
     GeomView g = geom_view(geometry, P);
     BinView b = bin_view(const_cast<void*>(binning), P, R, W, H, s->channels);
@@ -443,6 +458,23 @@ int splatraster_mark_visible(int32_t P, const float* means3D, const float* viewm
     return launch_mark_visible(P, means3D, viewmatrix, present, reinterpret_cast<hipStream_t>(stream));
 }
 
+int splatraster_poll_errors(void) { return lookback_error_poll(); }
+
+int splatraster_debug_set_spin_limit(uint32_t limit)
+{
+    int st = lookback_error_init();
+    if (st) return st;
+    return lookback_set_spin_limit(limit);
+}
+
+int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream)
+{
+    if (n < 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (n == 0) return SPLATRASTER_OK;
+    if (!x || !y) return SPLATRASTER_ERR_BAD_ARG;
+    return launch_debug_exp2(n, x, y, reinterpret_cast<hipStream_t>(stream));
+}
+
 size_t splatraster_sort_tmp_bytes(int64_t n)
 {
     const size_t m = (size_t)(n > 0 ? n : 1);
@@ -455,6 +487,12 @@ int splatraster_sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, int32_
     if (n < 0 || key_bits < 0 || key_bits > 32) return SPLATRASTER_ERR_BAD_ARG;
     if (n == 0 || key_bits == 0) return SPLATRASTER_OK;
     if (!keys || !vals || !tmp) return SPLATRASTER_ERR_BAD_ARG;
+    {
+        int st0 = lookback_error_init();
+        if (st0) return st0;
+        st0 = lookback_error_poll();
+        if (st0) return st0;
+    }
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     char* t = reinterpret_cast<char*>(tmp);
     const size_t stride = align_up(4 * (size_t)n, 256);
@@ -566,7 +604,7 @@ int splatraster_densification_stats(int32_t P, const float* viewspace_grad, cons
 size_t splatraster_mapping_loss_workspace_bytes(int32_t pixels) { return mapping_loss_workspace_bytes(pixels); }
 
 int splatraster_mapping_loss(int32_t pixels, const float* image, const float* depth, const float* marker,
-                             const float* gt_image, const float* gt_depth, const uint8_t* kp,
+                             const float* gt_image, const float* gt_depth, const float* kp,
                              float rgb_boundary_threshold, const float* exposure, float* g_image, float* g_depth,
                              float* g_marker, float* out, void* workspace, void* stream)
 {

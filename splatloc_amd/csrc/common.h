@@ -21,6 +21,14 @@ static inline int preprocess_blocks(int32_t P) { return (P + PREPROCESS_BLOCK - 
 
 // thread-local last-error text, filled by SR_HIP_CHECK
 void set_hip_error(hipError_t e, const char* what);
+void set_error_text(const char* text);
+
+// look-back watchdog (scan_sort.hip): flag word in host-mapped memory, polled by every entry point
+int lookback_error_init();
+int lookback_error_poll();
+int lookback_set_spin_limit(uint32_t limit);
+// test hook: y[i] = exp2_shared(x[i]) (composite_fwd.hip)
+int launch_debug_exp2(int64_t n, const float* x, float* y, hipStream_t stream);
 
 #define SR_HIP_CHECK(expr)                                 \
     do {                                                   \
@@ -149,7 +157,7 @@ int launch_densification_stats(int32_t P, const float* vs_grad, const int32_t* r
                                float* max_radii, hipStream_t stream);
 size_t mapping_loss_workspace_bytes(int32_t HW);
 int launch_mapping_loss(int32_t HW, const float* image, const float* depth, const float* marker,
-                        const float* gt_image, const float* gt_depth, const uint8_t* kp, float threshold,
+                        const float* gt_image, const float* gt_depth, const float* kp, float threshold,
                         const float* exposure, float* g_image, float* g_depth, float* g_marker, float* out,
                         void* workspace, hipStream_t stream);
 

@@ -308,7 +308,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 const float4 p1 = s_rec0[r1], q1 = s_rec1[r1];
                 const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
                 const float pw0 = gauss_log2(q0, dx0, dy0), pw1 = gauss_log2(q1, dx1, dy1);  // log2 of the weight
-                const float G0 = exp2_fast(pw0), G1 = exp2_fast(pw1);
+                const float G0 = exp2_shared(pw0), G1 = exp2_shared(pw1);
                 const float al0 = fminf(ALPHA_MAX, q0.w * G0), al1 = fminf(ALPHA_MAX, q1.w * G1);
                 const bool hit0 = (idx0 + (uint32_t)j0 < last) && pw0 <= 0.0f && al0 >= ALPHA_MIN;
                 const bool hit1 = has1 && (idx0 + (uint32_t)j1 < last) && pw1 <= 0.0f && al1 >= ALPHA_MIN;
@@ -337,13 +337,13 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 if (hit0) {
                     S -= w0 * qd0;
                     dA0 = T * qd0 - S * __frcp_rn(1.0f - al0);
-                    T *= 1.0f - al0;
+                    T = transmit(T, al0);
                 }
                 const float w1 = hit1 ? al1 * T : 0.0f;
                 if (hit1) {
                     S -= w1 * qd1;
                     dA1 = T * qd1 - S * __frcp_rn(1.0f - al1);
-                    T *= 1.0f - al1;
+                    T = transmit(T, al1);
                 }
                 float red[2 * KV];
 #pragma unroll

@@ -90,7 +90,39 @@ __device__ __forceinline__ float gauss_log2(const float4& q, float dx, float dy)
 {
     return fmaf(dx, fmaf(q.y, dy, q.x * dx), (q.z * dy) * dy);
 }
-__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+// 2^x as ONE explicit operation sequence that the CPU oracle restates instruction for instruction
+// (its orc_exp2; the product never links it), so that alpha, the transmittance chain and therefore every
+// alpha >= 1/255 / T < 1e-4 decision, n_contrib and final_T are BIT-IDENTICAL on both sides:
+//   n = rint(x) (ties to even: v_rndne_f32), f = x - n in [-0.5, 0.5] (exact),
+//   p = degree-5 minimax polynomial of 2^f (Horner, fmaf), result = ldexp(p, n) (v_ldexp_f32).
+// c0 = 1 exactly (2^n is exact at the integers); max relative error 1.7e-7 (1.4 ulp) — the accuracy
+// class of a libm expf.
+// v_exp_f32 (the hardware approximation, 1 quarter-rate instruction instead of 9 full-rate ones) is
+// not reproducible off the GPU; -DSR_EXP2_HW selects it for A/B timing only (cost: DESIGN.md §5).
+constexpr float EXP2_C0 = 1.0f, EXP2_C1 = 0.6931470036506653f, EXP2_C2 = 0.24022242426872253f,
+                EXP2_C3 = 0.05550733581185341f, EXP2_C4 = 0.009671512991189957f, EXP2_C5 = 0.001326472731307149f;
+__device__ __forceinline__ float exp2_shared(float x)
+{
+#ifdef SR_EXP2_HW
+    return __builtin_amdgcn_exp2f(x);
+#else
+    const float n = __builtin_rintf(x);
+    const float f = x - n;
+    float p = fmaf(EXP2_C5, f, EXP2_C4);
+    p = fmaf(p, f, EXP2_C3);
+    p = fmaf(p, f, EXP2_C2);
+    p = fmaf(p, f, EXP2_C1);
+    p = fmaf(p, f, EXP2_C0);
+    return __builtin_amdgcn_ldexpf(p, (int)n);   // v_cvt_i32_f32 saturates; underflow -> 0
+#endif
+}
+// T (1 - alpha) with two roundings, never a contracted fma: the oracle's transmittance chain
+__device__ __forceinline__ float transmit(float T, float alpha)
+{
+#pragma clang fp contract(off)
+    const float om = 1.0f - alpha;
+    return T * om;
+}
 
 // Block id -> (tile, quadrant) for the wave-per-quadrant kernels: the four quadrants of a tile
 // get ids with the same (id % 8), i.e. they run on the same XCD (observed dispatch: block b ->

@@ -195,18 +195,18 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 const float4 p1 = s_rec0[j1], q1 = s_rec1[j1];
                 const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
                 const float pw0 = gauss_log2(q0, dx0, dy0), pw1 = gauss_log2(q1, dx1, dy1);  // log2 of the weight
-                const float al0 = fminf(ALPHA_MAX, q0.w * exp2_fast(pw0));
-                const float al1 = fminf(ALPHA_MAX, q1.w * exp2_fast(pw1));
+                const float al0 = fminf(ALPHA_MAX, q0.w * exp2_shared(pw0));
+                const float al1 = fminf(ALPHA_MAX, q1.w * exp2_shared(pw1));
                 // Gaussian 0
                 const bool live0 = active && pw0 <= 0.0f && al0 >= ALPHA_MIN;
-                const float tT0 = T * (1.0f - al0);
+                const float tT0 = transmit(T, al0);
                 const bool hit0 = live0 && tT0 >= T_EPS;
                 const bool act1 = active && !(live0 && !hit0);  // transmittance exhausted: pixel finished
                 const float w0 = hit0 ? al0 * T : 0.0f;
                 const float T1 = hit0 ? tT0 : T;
                 // Gaussian 1 (absent when !has1)
                 const bool live1 = has1 && act1 && pw1 <= 0.0f && al1 >= ALPHA_MIN;
-                const float tT1 = T1 * (1.0f - al1);
+                const float tT1 = transmit(T1, al1);
                 const bool hit1 = live1 && tT1 >= T_EPS;
                 active = act1 && !(live1 && !hit1);
                 const float w1 = hit1 ? al1 * T1 : 0.0f;
@@ -266,6 +266,19 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
             n_contrib[pix] = last;
         }
     }
+}
+
+__global__ void debug_exp2_kernel(int64_t n, const float* __restrict__ x, float* __restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = exp2_shared(x[i]);
+}
+
+int launch_debug_exp2(int64_t n, const float* x, float* y, hipStream_t stream)
+{
+    hipLaunchKernelGGL(debug_exp2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, x, y);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
 }
 
 template <int NC>

@@ -6,7 +6,8 @@
 // as summed per view at train_gaussians.py:217-218:
 //   loss = mean |m_rgb x - m_rgb gt| + mean |m_d depth - m_d gt_depth| + mean BCE(sigmoid(marker), kp)
 //   x = exp(a) image + b,  m_rgb = sum_c gt[c] > threshold,  m_d = gt_depth > 0.01
-// HBM-bound: reads 8 planes + a byte mask, writes 5 planes per pixel.  The five sums (three loss
+// kp is the float score map used as a SOFT BCE target (gt.view(-1).float(), train_gaussians.py:40).
+// HBM-bound: reads 9 planes, writes 5 planes per pixel.  The five sums (three loss
 // terms, dL/da, dL/db) are reduced per block in double and finished by a one-block kernel:
 // deterministic, no atomics.
 #include "common.h"
@@ -21,7 +22,7 @@ __device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 
 __global__ void __launch_bounds__(LOSS_BLOCK)
 mapping_loss_kernel(int HW, const float* __restrict__ image /*3 planes*/, const float* __restrict__ depth,
                     const float* __restrict__ marker, const float* __restrict__ gt_image,
-                    const float* __restrict__ gt_depth, const uint8_t* __restrict__ kp, float threshold,
+                    const float* __restrict__ gt_depth, const float* __restrict__ kp, float threshold,
                     const float* __restrict__ exposure /*[2] = a, b or NULL*/, float* __restrict__ g_image,
                     float* __restrict__ g_depth, float* __restrict__ g_marker, double* __restrict__ partial)
 {
@@ -50,7 +51,7 @@ mapping_loss_kernel(int HW, const float* __restrict__ image /*3 planes*/, const 
         acc[1] += fabsf(dd);
         g_depth[p] = sgn(dd) * md * inv_n;
         const float s = 1.0f / (1.0f + expf(-marker[p]));
-        const float y = kp[p] ? 1.0f : 0.0f;
+        const float y = kp[p];   // soft target: the raw key-point score map (utils/dataset.py:94, camera_utils.py:75)
         const float lp = fmaxf(logf(s), -100.0f), lq = fmaxf(logf(1.0f - s), -100.0f);
         acc[2] += (double)(-(y * lp + (1.0f - y) * lq));
         const float sq = s * (1.0f - s);
@@ -111,7 +112,7 @@ size_t mapping_loss_workspace_bytes(int32_t HW)
 }
 
 int launch_mapping_loss(int32_t HW, const float* image, const float* depth, const float* marker,
-                        const float* gt_image, const float* gt_depth, const uint8_t* kp, float threshold,
+                        const float* gt_image, const float* gt_depth, const float* kp, float threshold,
                         const float* exposure, float* g_image, float* g_depth, float* g_marker, float* out,
                         void* workspace, hipStream_t stream)
 {

@@ -133,6 +133,60 @@ scan_apply_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ pe
     }
 }
 
+// ---- look-back watchdog ------------------------------------------------------------------
+// The decoupled look-backs below spin on predecessors that already hold a ticket, so they always
+// make progress; the spin bound is a watchdog against a wedged GPU (better a status code than a
+// hung queue).  A timeout must never yield a silently wrong prefix: the kernel raises a flag in
+// HOST-mapped pinned memory (system-scope store), and every C-ABI entry point polls that word
+// (lookback_error_poll) and returns SPLATRASTER_ERR_HIP.  The bound is a device global so that
+// tests/test_gpu_edge_cases.py can force a timeout (splatraster_debug_set_spin_limit).
+__device__ uint32_t* g_err_sink = nullptr;          // device address of the host flag word
+__device__ uint32_t g_spin_limit = 1u << 24;
+
+__device__ __forceinline__ void lookback_timeout(uint32_t* state_error)
+{
+    *state_error = 1u;
+    uint32_t* sink = g_err_sink;
+    if (sink) __hip_atomic_store(sink, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+constexpr int MAX_DEVICES = 64;
+static uint32_t* g_err_host[MAX_DEVICES] = {};       // pinned, mapped; one word per device
+
+int lookback_error_init()
+{
+    int dev = 0;
+    SR_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return SPLATRASTER_ERR_UNSUPPORTED;
+    if (g_err_host[dev]) return SPLATRASTER_OK;
+    uint32_t* h = nullptr;
+    SR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped | hipHostMallocPortable));
+    *h = 0u;
+    uint32_t* d = nullptr;
+    SR_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0));
+    SR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_err_sink), &d, sizeof(d)));
+    g_err_host[dev] = h;
+    return SPLATRASTER_OK;
+}
+
+// SPLATRASTER_ERR_HIP once for every raised flag (the flag is cleared), else OK
+int lookback_error_poll()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES || !g_err_host[dev]) return SPLATRASTER_OK;
+    volatile uint32_t* h = g_err_host[dev];
+    if (*h == 0u) return SPLATRASTER_OK;
+    *h = 0u;
+    set_error_text("a decoupled look-back (scan / radix sort) timed out: the results of a previous call on this device are invalid");
+    return SPLATRASTER_ERR_HIP;
+}
+
+int lookback_set_spin_limit(uint32_t limit)
+{
+    SR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_spin_limit), &limit, sizeof(limit)));
+    return SPLATRASTER_OK;
+}
+
 // One-pass inclusive scan (n <= SCAN_ONEPASS_MAX_BLOCKS tiles): each block scans its tile, publishes
 // its total in a 64-bit status word (value | flag << 62: 1 = tile total, 2 = inclusive prefix) and
 // wave 0 resolves the exclusive prefix with a wave-wide decoupled look-back — 64 predecessors per
@@ -198,7 +252,7 @@ scan_onepass_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ 
                 const int first = has_incl ? __builtin_ctzll(has_incl) : WAVE - 1;   // nearest inclusive prefix
                 const uint64_t need = first == WAVE - 1 ? ~0ull : ((1ull << (first + 1)) - 1ull);
                 if ((ready & need) != need) {
-                    if (++spins > (1u << 22)) { if (lane == 0) st->error = 1u; break; }
+                    if (++spins > g_spin_limit) { if (lane == 0) lookback_timeout(&st->error); break; }
                     __builtin_amdgcn_s_sleep(1);
                     continue;
                 }
@@ -424,8 +478,8 @@ sort_scatter_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint3
 // written once per state with a relaxed AGENT-scope atomic store and polled with relaxed
 // agent-scope atomic loads — the data IS the flag, so no fence is needed.  Blocks take their
 // logical index from an atomic ticket, so a block only ever waits for blocks that have
-// already started: no residency assumption, no deadlock.  Spins are bounded; a timeout sets
-// an error word (checked by nobody on the fast path, read back by the tests).
+// already started: no residency assumption, no deadlock.  Spins are bounded; a timeout raises
+// the host-visible watchdog flag (lookback_timeout above) and the next C-ABI call fails.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t ST_LOCAL = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
 constexpr int MAX_PASSES = 4;
@@ -544,7 +598,7 @@ sort_sweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_
                 }
                 pb -= used;
                 if (used == 0) {
-                    if (++spins > (1u << 24)) { st->error = 1u; break; }
+                    if (++spins > g_spin_limit) { lookback_timeout(&st->error); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }

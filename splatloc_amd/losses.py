@@ -33,7 +33,9 @@ class _MappingLoss(torch.autograd.Function):
         if tuple(image.shape) != (3, H, W) or depth.numel() != HW or marker.numel() != HW:
             raise RuntimeError("mapping_loss: expected image [3,H,W], depth [1,H,W], marker [H,W]")
         im, de, ma, gi, gd = (_prep(t, dev) for t in (image, depth, marker, gt_image, gt_depth))
-        k8 = kp.to(device=dev).ne(0).to(torch.uint8).contiguous() if kp.dtype != torch.uint8 else kp.to(dev).contiguous()
+        # the BCE target is the score map itself (`gt.view(-1).float()`, train_gaussians.py:40): a soft
+        # target in [0, 1] on real data (utils/dataset.py:94), 0/1 when a bool mask is passed
+        k8 = _prep(kp.to(torch.float32), dev)
         ex = _prep(exposure, dev) if exposure is not None else None
         f32 = dict(dtype=torch.float32, device=dev)
         g_image = torch.empty((3, H, W), **f32)
@@ -59,7 +61,7 @@ class _MappingLoss(torch.autograd.Function):
 def mapping_loss_tensors(image, depth, marker, gt_image, gt_depth, kp, rgb_boundary_threshold, exposure_a=None,
                          exposure_b=None):
     """Tensor-level entry: image [3,H,W], depth [1,H,W], marker [H,W] (logits), gt_image [3,H,W],
-    gt_depth [H,W], kp [H,W] bool; exposure_a / exposure_b one-element tensors or None (no affine)."""
+    gt_depth [H,W], kp [H,W] float score map in [0,1] (or bool); exposure_a / exposure_b one-element tensors or None (no affine)."""
     exposure = None
     if exposure_a is not None:
         exposure = torch.cat((exposure_a.reshape(1), exposure_b.reshape(1))).to(torch.float32)

@@ -2,7 +2,9 @@
 container: get_loss_mapping with the exposure affine (utils/utils.py:55-82) +
 get_loss_marker (train_gaussians.py:38-42), exactly as SplatLoc.map sums them per view
 (train_gaussians.py:217-218), on a seeded 60x80 frame; records the loss value and the autograd
-gradients w.r.t. image, depth, marker, exposure_a, exposure_b.  Only the fixture is committed.
+gradients w.r.t. image, depth, marker, exposure_a, exposure_b.  The `exposure_` case uses a float
+key-point score map (soft BCE targets, as on real data), the `initialization_` case a bool mask.
+Only the fixture is committed.
 """
 import os
 import sys
@@ -37,7 +39,13 @@ def main():
             gt_depth[:, :7] = 0.0                                # invalid depth
             with torch.no_grad():
                 image[:, 10, :8] = gt_img[:, 10, :8]             # exact zeros of the L1 argument (sign(0) = 0)
-            kp = torch.rand(H, W, generator=g) > 0.8
+            if init:
+                kp = torch.rand(H, W, generator=g) > 0.8             # a bool mask: hard 0 / 1 targets
+            else:
+                # what the dataset really hands over (utils/dataset.py:94 `*_score.npy`, camera_utils.py:75):
+                # a continuous score map in [0, 1] -> SOFT BCE targets (train_gaussians.py:40 `.float()`)
+                kp = torch.rand(H, W, generator=g) ** 4
+                kp[1, :6] = torch.tensor([0.0, 1.0, 0.005, 0.5, 1e-6, 0.999])
             a = torch.tensor([0.13], requires_grad=True)
             b = torch.tensor([-0.04], requires_grad=True)
             vp = types.SimpleNamespace(original_image=gt_img, depth=gt_depth, exposure_a=a, exposure_b=b)

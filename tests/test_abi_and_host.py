@@ -31,7 +31,11 @@ def test_host_only_entry_points():
     """Sizing / layout / error-string functions never touch the GPU."""
     from splatloc_amd import _native
     lib = _native.load()
-    assert lib.splatraster_abi_version() == 1
+    import re
+    hdr = open(os.path.join(ROOT, "include", "splatraster.h")).read()
+    declared_version = int(re.search(r"#define SPLATRASTER_ABI_VERSION (\d+)", hdr).group(1))
+    assert lib.splatraster_abi_version() == declared_version == _native.ABI_VERSION
+    assert lib.splatraster_poll_errors() == 0          # no device touched yet: nothing to report
     assert lib.splatraster_error_string(0) == b"ok" and lib.splatraster_error_string(1) == b"bad argument"
     g1, g2 = lib.splatraster_geometry_bytes(1000), lib.splatraster_geometry_bytes(500_000)
     assert 0 < g1 < g2 and g2 % 256 == 0

@@ -158,3 +158,56 @@ def test_forward_under_no_grad_like_eval_rendering():
     assert color.grad_fn is None and not color.requires_grad
     assert torch.equal(color, ref.color.detach()) and torch.equal(depth, ref.depth.detach())
     assert torch.equal(alpha, ref.alpha.detach()) and torch.equal(radii, ref.radii)
+
+
+def test_lookback_timeout_is_reported_not_silent():
+    """A timed-out decoupled look-back (one-pass scan / one-sweep radix sort) must surface as a status
+    code, never as a silently mis-sorted frame: with the spin bound forced to 0 every block that has to
+    wait for a predecessor times out, raises the host-mapped watchdog flag, and a C-ABI call fails with
+    SPLATRASTER_ERR_HIP; with the bound restored the same frame is bit-exact again."""
+    from splatloc_amd import _native
+    lib = _native.load()
+    sc = make_scene(300_000, 640, 480, 3, seed=71, scale_median=0.006)   # 74 sort blocks, 147 scan tiles
+    _native.check(lib.splatraster_poll_errors(), "poll (clean start)")
+    _native.check(lib.splatraster_debug_set_spin_limit(0), "set_spin_limit")
+    try:
+        raised = False
+        for _ in range(4):                       # waiting is timing dependent: a few frames make it certain
+            try:
+                HipRun(sc, backward=True)
+                torch.cuda.synchronize()
+                _native.check(lib.splatraster_poll_errors(), "poll")
+            except RuntimeError as e:
+                assert "HIP" in str(e) and "look-back" in str(e), str(e)
+                raised = True
+                break
+        assert raised, "no look-back had to wait in 4 frames of 300k Gaussians?"
+    finally:
+        _native.check(lib.splatraster_debug_set_spin_limit(1 << 24), "restore spin limit")
+        torch.cuda.synchronize()
+        lib.splatraster_poll_errors()            # drain flags raised by frames still in flight
+    _run_and_check(sc, backward=False)           # healthy again, bit-exact
+
+
+def test_empty_scene_backward_zeroes_pose_gradients():
+    """P = 0 with camera tensors that require grad: dL/dviewmatrix / projmatrix / campos are defined zeros
+    (the backward returns early; the buffers must not be left uninitialised)."""
+    from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer
+    sc = make_scene(10, 64, 48, 3, seed=5)
+    dev = torch.device("cuda:0")
+    cam = sc.camera
+    V = cam.world_view_transform.to(dev).clone().requires_grad_(True)
+    PM = cam.full_proj_transform.to(dev).clone().requires_grad_(True)
+    cp = cam.camera_center.to(dev).clone().requires_grad_(True)
+    # poison the allocator's free blocks so that an un-zeroed buffer would show
+    junk = [torch.full((64,), float("nan"), device=dev) for _ in range(64)]
+    del junk
+    rs = GaussianRasterizationSettings(48, 64, cam.tanfovx, cam.tanfovy, torch.ones(3, device=dev), 1.0, V, PM, 0, cp,
+                                       False, False)
+    e = lambda *s: torch.zeros(*s, device=dev, requires_grad=True)  # noqa: E731
+    color, depth, alpha, radii = GaussianRasterizer(raster_settings=rs)(
+        means3D=e(0, 3), means2D=e(0, 3), shs=None, colors_precomp=e(0, 3), opacities=e(0, 1), scales=e(0, 3),
+        rotations=e(0, 4), cov3D_precomp=None)
+    (color.sum() + depth.sum()).backward()
+    for t in (V, PM, cp):
+        assert t.grad is not None and bool((t.grad == 0).all())

@@ -1,0 +1,44 @@
+"""The alpha arithmetic contract shared by the oracle and the HIP path (orc_exp2 /
+exp2_shared): accuracy of the restated 2^x, and that adopting it changes nothing beyond rounding
+relative to the lineage's literal `exp(power)` form."""
+import numpy as np
+
+from oracle import oracle
+from splatloc_amd.synthetic import make_scene
+from tests.helpers import oracle_forward
+
+
+def test_exp2_accuracy_and_edges():
+    x = np.concatenate([np.linspace(-24.0, 0.0, 2_000_001), np.linspace(-0.5, 0.5, 200_001),
+                        -np.logspace(-30, 2, 4001)]).astype(np.float32)
+    y = oracle.exp2(x).astype(np.float64)
+    ref = np.exp2(x.astype(np.float64))
+    rel = np.abs(y / ref - 1.0)
+    assert rel[x > -120].max() <= 1.8e-7, rel[x > -120].max()      # 1.4 ulp: the class of a libm expf
+    # exact at the integers, monotone where the compositing thresholds live
+    n = np.arange(-126, 1, dtype=np.float32)
+    assert np.array_equal(oracle.exp2(n), np.exp2(n.astype(np.float64)).astype(np.float32))
+    xs = np.linspace(-9.0, 0.0, 1_000_001).astype(np.float32)
+    ys = oracle.exp2(xs)
+    assert (np.diff(ys) >= -np.spacing(ys[1:])).all()               # non-decreasing up to one ulp
+    # underflow / specials behave like the device sequence (v_cvt_i32 saturation + v_ldexp)
+    sp = oracle.exp2(np.array([-1e30, -300.0, -160.0, -149.5, 0.0, -0.0], np.float32))
+    assert sp[0] == 0 and sp[1] == 0 and sp[2] == 0 and sp[3] <= 2e-45 and sp[4] == 1 and sp[5] == 1
+
+
+def test_contract_vs_lineage_literal_form():
+    """mode 0 (pre-scaled conic, fmaf chain, orc_exp2) vs mode 1 (-0.5 (A dx^2 + C dy^2) - B dx dy,
+    expf): same image to 1e-4; the integer outputs differ only where a threshold flips within an ulp."""
+    sc = make_scene(P=6000, W=320, H=240, C=4, seed=11, scale_median=0.03)
+    try:
+        oracle.set_alpha_mode(1)
+        f1 = oracle_forward(sc)
+    finally:
+        oracle.set_alpha_mode(0)
+    f0 = oracle_forward(sc)
+    assert np.array_equal(f0["point_list"], f1["point_list"]) and np.array_equal(f0["radii"], f1["radii"])
+    flipped = f0["n_contrib"] != f1["n_contrib"]
+    assert flipped.mean() <= 1e-3, flipped.mean()
+    d = np.abs(f0["color"] - f1["color"]).max(axis=0)
+    assert d[~flipped].max() <= 2e-6 and d.max() <= 1.0 / 255.0 + 1e-6
+    assert np.abs(f0["final_T"] - f1["final_T"])[~flipped].max() <= 2e-6
