@@ -301,15 +301,16 @@ int splatraster_timing_collect(double* ms, int64_t* counts);
 
 /* ---- misc ---------------------------------------------------------------------------- */
 
-/* The decoupled look-backs of the one-pass scan and of the one-sweep radix sort spin with a bound.
- * A timeout raises a flag in host-mapped memory; forward_geometry / forward_render / backward /
- * sort_pairs poll it on entry (and forward_geometry again after its host wait) and return
- * SPLATRASTER_ERR_HIP, so a timed-out scan or sort is never a silently wrong image.  The work is
- * asynchronous: the failing call may be a later one on the same device.  splatraster_poll_errors()
- * polls explicitly (after a stream synchronize it is exact). */
+/* The decoupled look-backs of the one-pass scan and of the one-sweep radix sort never give up with a
+ * partial prefix (that would be a silently mis-sorted frame).  A block that has waited longer than the
+ * spin bound raises a flag in host-mapped memory and keeps waiting; forward_geometry / forward_render /
+ * backward / sort_pairs poll that flag (and forward_geometry again after its host wait) and return
+ * SPLATRASTER_ERR_HIP: a stalling or wedged device is reported, results are never wrong.  The work is
+ * asynchronous, so the reporting call may be a later one on the same device.
+ * splatraster_poll_errors() polls explicitly (exact after a stream synchronize). */
 int splatraster_poll_errors(void);
-/* test hooks: spin bound of the look-backs (default 1 << 24; 0 forces a timeout wherever a block
- * has to wait), and y[i] = the device's 2^x (the alpha arithmetic shared with the CPU oracle). */
+/* test hooks: spin bound of the look-backs (default 1 << 24; 0 makes every block that has to wait at
+ * all report), and y[i] = the device's 2^x (the alpha arithmetic shared with the CPU oracle). */
 int splatraster_debug_set_spin_limit(uint32_t limit);
 int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
 

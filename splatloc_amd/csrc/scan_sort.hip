@@ -135,11 +135,14 @@ scan_apply_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ pe
 
 // ---- look-back watchdog ------------------------------------------------------------------
 // The decoupled look-backs below spin on predecessors that already hold a ticket, so they always
-// make progress; the spin bound is a watchdog against a wedged GPU (better a status code than a
-// hung queue).  A timeout must never yield a silently wrong prefix: the kernel raises a flag in
-// HOST-mapped pinned memory (system-scope store), and every C-ABI entry point polls that word
-// (lookback_error_poll) and returns SPLATRASTER_ERR_HIP.  The bound is a device global so that
-// tests/test_gpu_edge_cases.py can force a timeout (splatraster_debug_set_spin_limit).
+// make progress on a healthy GPU.  They never give up with a partial prefix — a wrong prefix would be
+// a silently mis-sorted frame, and garbage offsets send the downstream kernels out of bounds.  Instead
+// a block that has waited longer than the spin bound raises a flag in HOST-mapped pinned memory
+// (system-scope store) and KEEPS WAITING: the result of the call is either correct or (wedged GPU)
+// never arrives, and every C-ABI entry point polls that word (lookback_error_poll) and returns
+// SPLATRASTER_ERR_HIP, so a stalling device is reported instead of hanging unexplained.  The bound is
+// a device global so that tests/test_gpu_edge_cases.py can force the report
+// (splatraster_debug_set_spin_limit).
 __device__ uint32_t* g_err_sink = nullptr;          // device address of the host flag word
 __device__ uint32_t g_spin_limit = 1u << 24;
 
@@ -177,7 +180,7 @@ int lookback_error_poll()
     volatile uint32_t* h = g_err_host[dev];
     if (*h == 0u) return SPLATRASTER_OK;
     *h = 0u;
-    set_error_text("a decoupled look-back (scan / radix sort) timed out: the results of a previous call on this device are invalid");
+    set_error_text("look-back watchdog: a scan / radix-sort block waited longer than the spin bound for a predecessor (stalling device); results are late, never wrong");
     return SPLATRASTER_ERR_HIP;
 }
 
@@ -242,6 +245,7 @@ scan_onepass_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ 
             if (lane == 0) __hip_atomic_store(mine, (uint64_t)btotal | SC_LOCAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int64_t pb = (int64_t)bid - 1;
             uint32_t spins = 0;
+            bool reported = false;
             while (true) {
                 const int64_t idx = pb - lane;
                 const uint64_t word = idx >= 0 ? __hip_atomic_load(st->status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -252,7 +256,7 @@ scan_onepass_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ 
                 const int first = has_incl ? __builtin_ctzll(has_incl) : WAVE - 1;   // nearest inclusive prefix
                 const uint64_t need = first == WAVE - 1 ? ~0ull : ((1ull << (first + 1)) - 1ull);
                 if ((ready & need) != need) {
-                    if (++spins > g_spin_limit) { if (lane == 0) lookback_timeout(&st->error); break; }
+                    if (++spins > g_spin_limit && !reported) { reported = true; if (lane == 0) lookback_timeout(&st->error); }
                     __builtin_amdgcn_s_sleep(1);
                     continue;
                 }
@@ -478,8 +482,8 @@ sort_scatter_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint3
 // written once per state with a relaxed AGENT-scope atomic store and polled with relaxed
 // agent-scope atomic loads — the data IS the flag, so no fence is needed.  Blocks take their
 // logical index from an atomic ticket, so a block only ever waits for blocks that have
-// already started: no residency assumption, no deadlock.  Spins are bounded; a timeout raises
-// the host-visible watchdog flag (lookback_timeout above) and the next C-ABI call fails.
+// already started: no residency assumption, no deadlock.  A block that waits longer than the spin
+// bound raises the host-visible watchdog flag (lookback_timeout above) and goes on waiting.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t ST_LOCAL = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
 constexpr int MAX_PASSES = 4;
@@ -576,7 +580,7 @@ sort_sweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_
             constexpr int LOOKBACK = SR_SORT_LOOKBACK;
             int64_t pb = (int64_t)bid - 1;
             uint32_t spins = 0;
-            bool done = false;
+            bool done = false, reported = false;
             while (pb >= 0 && !done) {
                 uint32_t v[LOOKBACK];
 #pragma unroll
@@ -598,7 +602,7 @@ sort_sweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_
                 }
                 pb -= used;
                 if (used == 0) {
-                    if (++spins > g_spin_limit) { lookback_timeout(&st->error); break; }
+                    if (++spins > g_spin_limit && !reported) { reported = true; lookback_timeout(&st->error); }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
