@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 2
+#define SPLATRASTER_ABI_VERSION 3
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
@@ -240,6 +240,85 @@ int splatraster_activate_backward(int32_t P, int32_t sh_coeffs, int32_t active_s
 int splatraster_densification_stats(int32_t P, const float* viewspace_grad /* [P,3] */, const int32_t* radii,
                                     float* xyz_gradient_accum /* [P,1] */, float* denom /* [P,1] */,
                                     float* max_radii2D /* [P] */, void* stream);
+
+/* ---- densify / clone / split / prune + Adam over the parameter groups -------- */
+
+/* The raw (pre-activation) parameter tensors of the reference's GaussianModel, in the group order of
+ * GaussianModel.training_setup (gaussian_model.py:254-297): row-major [P, width], fp32, device memory.
+ * The same struct carries the Adam moments (exp_avg / exp_avg_sq of each group; NULL = the group has no
+ * optimizer state — SplatLoc's marker never receives a gradient in map()). */
+typedef struct splatraster_model {
+    int32_t P;
+    int32_t f_rest_width;  /* 3 * ((max_sh_degree + 1)^2 - 1); 0 in SplatLoc (f_rest is [P, 0, 3]) */
+    int32_t marker_width;  /* 1 (0 = absent) */
+    int32_t kp_width;      /* columns of _kp_score (1 in SplatLoc) */
+    int32_t scaling_width; /* 3, or 1 for an isotropic model */
+    float* xyz;            /* [P,3] */
+    float* f_dc;           /* [P,1,3] */
+    float* f_rest;         /* [P,f_rest_width] */
+    float* opacity;        /* [P,1]  logit */
+    float* marker;         /* [P,marker_width] */
+    float* kp_score;       /* [P,kp_width] */
+    float* scaling;        /* [P,scaling_width]  log */
+    float* rotation;       /* [P,4]  un-normalised quaternion (w,x,y,z) */
+} splatraster_model;
+
+/* GaussianModel.densify_and_prune(max_grad, min_opacity, extent, max_screen_size)
+ * (gaussian_model.py:655-675 with densify_and_clone :632-653, densify_and_split :590-630, prune_points
+ * :510-526 and the optimizer surgery :477-587) as one compaction:
+ *   plan   decides clone / split / prune per row from xyz_gradient_accum / denom, the scales, opacity and
+ *          (primitive_reg) the marker, scans the keep flags and returns the new row count (one
+ *          device->host read: it sizes the caller's allocations);
+ *   apply  writes the re-sized parameter tensors and Adam moments in the reference's row order
+ *          [originals | clones | split children copy 0 | copy 1]; new rows get zero moments.
+ * The caller zeroes the statistics afterwards (densification_postfix resets xyz_gradient_accum, denom
+ * AND max_radii2D, gaussian_model.py:585-587 — which is why max_screen_size can only act as the on/off
+ * switch of the world-size prune: use_size_prune = (max_screen_size != 0)).
+ * Split children: xyz + R(q/|q|) (z * exp(scaling)), z ~ N(0, I).  unit_noise [2,P,3] supplies z by
+ * (copy, source row) when given (tests: the recorded table of tests/golden/densify.npz); otherwise z is
+ * drawn from Philox4x32-10 keyed by (seed, draw_id, source row, copy), so data-parallel replicas that pass
+ * the same (seed, draw_id) split identically without a broadcast. */
+size_t splatraster_densify_workspace_bytes(int32_t P);
+int splatraster_densify_plan(const splatraster_model* model, const float* xyz_gradient_accum /* [P,1] */,
+                             const float* denom /* [P,1] */, float max_grad, float min_opacity, float extent,
+                             float percent_dense, int32_t use_size_prune, int32_t primitive_reg, void* workspace,
+                             int32_t* new_P, void* stream);
+int splatraster_densify_apply(const splatraster_model* model, const splatraster_model* exp_avg /* or NULL */,
+                              const splatraster_model* exp_avg_sq /* or NULL */, const float* unit_noise /* or NULL */,
+                              uint64_t seed, uint64_t draw_id, void* workspace /* from plan */, int32_t new_P,
+                              splatraster_model* out_model, splatraster_model* out_exp_avg,
+                              splatraster_model* out_exp_avg_sq, int32_t* source_row /* [new_P] or NULL */,
+                              int32_t* source_kind /* [new_P] or NULL: 0 original, 1 clone, 2 / 3 split child */,
+                              void* stream);
+
+/* One torch.optim.Adam step (no weight decay, no amsgrad: gaussian_model.py:287) over up to 16 parameter
+ * groups in ONE launch.  `step` is the group's step count AFTER this step (>= 1): the bias corrections
+ * and 1 - beta are formed on the host in double like torch does (hence the double betas).  A group with grad == NULL is skipped (torch
+ * semantics: no state is touched).  row_gate (or NULL): per-ROW gate values; rows with
+ * gate > row_gate_threshold see a ZERO gradient — the key-primitive freeze `get_xyz.grad[key_mask] = 0`
+ * of train_gaussians.py:231-234 (gate = the marker, threshold 0.005) without its .cpu() sync. */
+typedef struct splatraster_adam_group {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    const float* row_gate;
+    int64_t numel;
+    int32_t row_width; /* elements per row (for row_gate) */
+    float lr;
+    double step;
+} splatraster_adam_group;
+int splatraster_adam_step(int32_t n_groups, const splatraster_adam_group* groups, double beta1, double beta2, double eps,
+                          float row_gate_threshold, void* stream);
+
+/* Isotropic scale regulariser of SplatLoc.map (train_gaussians.py:222-228):
+ *   mask = marker > 0.005;  loss = mean_{mask} | mean_k scaling[i,k] / (0.02 (1 - marker_i)) - 1 |
+ * scaling is the ACTIVATED [P, scaling_cols] tensor.  row_grad[i] = d|x_i - 1| / d scaling[i,k] (equal for
+ * every k; 0 outside the mask); out[0] = loss, out[1] = 1 / |mask| (both 0 for an empty mask), so
+ * d loss / d scaling[i,k] = out[1] * row_grad[i].  No host synchronisation. */
+size_t splatraster_isotropic_loss_workspace_bytes(int32_t P);
+int splatraster_isotropic_loss(int32_t P, int32_t scaling_cols, const float* scaling, const float* marker,
+                               float* row_grad /* [P] */, float* out /* [2] */, void* workspace, void* stream);
 
 /* ---- per-view mapping loss + gradient ---------------------------------- */
 

@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 2   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 3   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 _ERR_NAMES = {1: "bad argument", 2: "HIP runtime error", 3: "unsupported configuration",
@@ -48,6 +48,21 @@ class ImageLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "total")]
 
 
+class Model(C.Structure):
+    """struct splatraster_model: the 8 raw parameter tensors of GaussianModel (or their Adam moments)"""
+    _fields_ = [("P", C.c_int32), ("f_rest_width", C.c_int32), ("marker_width", C.c_int32), ("kp_width", C.c_int32),
+                ("scaling_width", C.c_int32)] + [(n, C.c_void_p) for n in
+                                                 ("xyz", "f_dc", "f_rest", "opacity", "marker", "kp_score", "scaling",
+                                                  "rotation")]
+
+
+class AdamGroup(C.Structure):
+    """struct splatraster_adam_group"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("row_gate", C.c_void_p), ("numel", C.c_int64), ("row_width", C.c_int32), ("lr", C.c_float),
+                ("step", C.c_double)]
+
+
 # every symbol include/splatraster.h declares: (name, restype, argtypes)
 _vp, _i32, _i64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
 SYMBOLS = {
@@ -71,6 +86,15 @@ SYMBOLS = {
     "splatraster_activate_forward": (C.c_int, [_i32] * 5 + [_vp] * 13),
     "splatraster_activate_backward": (C.c_int, [_i32] * 5 + [_vp] * 19),
     "splatraster_densification_stats": (C.c_int, [_i32] + [_vp] * 6),
+    "splatraster_densify_workspace_bytes": (_sz, [_i32]),
+    "splatraster_densify_plan": (C.c_int, [C.POINTER(Model), _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i32,
+                                           _i32, _vp, C.POINTER(_i32), _vp]),
+    "splatraster_densify_apply": (C.c_int, [C.POINTER(Model), C.POINTER(Model), C.POINTER(Model), _vp, C.c_uint64,
+                                            C.c_uint64, _vp, _i32, C.POINTER(Model), C.POINTER(Model), C.POINTER(Model),
+                                            _vp, _vp, _vp]),
+    "splatraster_adam_step": (C.c_int, [_i32, C.POINTER(AdamGroup), C.c_double, C.c_double, C.c_double, C.c_float, _vp]),
+    "splatraster_isotropic_loss_workspace_bytes": (_sz, [_i32]),
+    "splatraster_isotropic_loss": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_mapping_loss_workspace_bytes": (_sz, [_i32]),
     "splatraster_mapping_loss": (C.c_int, [_i32] + [_vp] * 6 + [C.c_float] + [_vp] * 7),
     "splatraster_refinement_loss_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -32,3 +32,132 @@ def add_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, x
         _native.check(_native.load().splatraster_densification_stats(
             P, _ptr(g), _ptr(radii.contiguous()), _ptr(xyz_gradient_accum), _ptr(denom), _ptr(max_radii2D),
             _stream(dev)), "densification_stats")
+
+
+# ---------------------------------------------------------------------------------------------------
+# densify / clone / split / prune with optimizer-state surgery (gaussian_model.py:477-675)
+# ---------------------------------------------------------------------------------------------------
+GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "marker", "kp_score", "scaling", "rotation")
+ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+        "marker": "_marker", "kp_score": "_kp_score", "scaling": "_scaling", "rotation": "_rotation"}
+
+
+def _row_width(t: torch.Tensor) -> int:
+    n = 1
+    for d in t.shape[1:]:
+        n *= int(d)
+    return n
+
+
+def _model_struct(tensors: dict, P: int, widths: dict):
+    import ctypes as C
+    m = _native.Model()
+    m.P, m.f_rest_width, m.marker_width = P, widths["f_rest"], widths["marker"]
+    m.kp_width, m.scaling_width = widths["kp_score"], widths["scaling"]
+    for k in GROUPS:
+        t = tensors.get(k)
+        setattr(m, k, None if (t is None or t.numel() == 0) else C.c_void_p(t.data_ptr()))
+    return m
+
+
+def densify_tensors(params: dict, exp_avg: dict, exp_avg_sq: dict, xyz_gradient_accum, denom, max_grad, min_opacity,
+                    extent, max_screen_size, percent_dense, primitive_reg, unit_noise=None, seed: int = 0,
+                    draw_id: int = 0, return_sources: bool = False):
+    """Tensor-level entry.  params / exp_avg / exp_avg_sq: dicts by group name (GROUPS) of contiguous float32
+    ROCm tensors [P, ...]; a group without Adam state is missing (or None) in the two moment dicts.
+    Returns (new_params, new_exp_avg, new_exp_avg_sq[, source_row, source_kind]) — freshly allocated tensors
+    in the reference's row order.  ONE device->host read (the new row count)."""
+    import ctypes as C
+    lib = _native.load()
+    xyz = params["xyz"]
+    _require_gpu(xyz, "xyz")
+    dev = xyz.device
+    P = int(xyz.shape[0])
+    for k in GROUPS:
+        t = params[k]
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev or int(t.shape[0]) != P:
+            raise RuntimeError(f"densify: group `{k}` must be a contiguous float32 tensor with {P} rows on {dev}")
+    widths = {k: _row_width(params[k]) for k in GROUPS}
+    if (widths["xyz"], widths["f_dc"], widths["opacity"], widths["rotation"]) != (3, 3, 1, 4):
+        raise RuntimeError("densify: unexpected parameter shapes")
+    src = _model_struct(params, P, widths)
+    acc = xyz_gradient_accum.to(torch.float32).contiguous()
+    den = denom.to(torch.float32).contiguous()
+    ws = torch.empty((lib.splatraster_densify_workspace_bytes(P),), dtype=torch.uint8, device=dev)
+    new_P = C.c_int32(0)
+    with torch.cuda.device(dev):
+        _native.check(lib.splatraster_densify_plan(
+            C.byref(src), _ptr(acc), _ptr(den), C.c_float(max_grad), C.c_float(min_opacity), C.c_float(extent),
+            C.c_float(percent_dense), int(bool(max_screen_size)), int(bool(primitive_reg)), _ptr(ws), C.byref(new_P),
+            _stream(dev)), "densify_plan")
+    n = int(new_P.value)
+    f32 = dict(dtype=torch.float32, device=dev)
+    new_params = {k: torch.empty((n,) + tuple(params[k].shape[1:]), **f32) for k in GROUPS}
+    has = [k for k in GROUPS if exp_avg.get(k) is not None and exp_avg_sq.get(k) is not None]
+    new_m = {k: torch.empty_like(new_params[k]) for k in has}
+    new_v = {k: torch.empty_like(new_params[k]) for k in has}
+    srow = torch.empty((n,), dtype=torch.int32, device=dev) if return_sources else None
+    skind = torch.empty((n,), dtype=torch.int32, device=dev) if return_sources else None
+    noise = None
+    if unit_noise is not None:
+        noise = unit_noise.to(device=dev, dtype=torch.float32).contiguous()
+        if tuple(noise.shape) != (2, P, 3):
+            raise RuntimeError("densify: unit_noise must be [2, P, 3]")
+    if P and n:
+        m_in = _model_struct({k: exp_avg[k].contiguous() for k in has}, P, widths) if has else None
+        v_in = _model_struct({k: exp_avg_sq[k].contiguous() for k in has}, P, widths) if has else None
+        out = _model_struct(new_params, n, widths)
+        m_out = _model_struct(new_m, n, widths) if has else None
+        v_out = _model_struct(new_v, n, widths) if has else None
+        ref = lambda s: None if s is None else C.byref(s)  # noqa: E731
+        with torch.cuda.device(dev):
+            _native.check(lib.splatraster_densify_apply(
+                C.byref(src), ref(m_in), ref(v_in), _ptr(noise), C.c_uint64(int(seed)), C.c_uint64(int(draw_id)),
+                _ptr(ws), n, C.byref(out), ref(m_out), ref(v_out), _ptr(srow), _ptr(skind), _stream(dev)),
+                "densify_apply")
+    if return_sources:
+        return new_params, new_m, new_v, srow, skind
+    return new_params, new_m, new_v
+
+
+def densify_and_prune(gaussians, max_grad, min_opacity, extent, max_screen_size, *, seed: int = 0, draw_id: int = None,
+                      unit_noise=None):
+    """Drop-in for `GaussianModel.densify_and_prune(max_grad, min_opacity, extent, max_screen_size)`
+    (gaussian_model.py:655-675; call site train_gaussians.py:251-256) on the reference's own model object:
+    reads `gaussians._xyz ... _rotation`, `xyz_gradient_accum`, `denom`, `percent_dense`, `primitive_reg` and
+    the torch Adam state of `gaussians.optimizer`, and leaves the object as the reference does — new
+    `nn.Parameter`s bound to the model AND to the optimizer's groups, `exp_avg` / `exp_avg_sq` re-sized with
+    zero rows for new points and the `step` counters carried over, statistics (incl. `max_radii2D`) zeroed.
+    `draw_id` (default: an internal counter) distinguishes successive densifications under one `seed`."""
+    from torch import nn
+    opt = gaussians.optimizer
+    groups = {g["name"]: g for g in opt.param_groups}
+    params = {k: getattr(gaussians, ATTR[k]).detach().contiguous() for k in GROUPS}
+    m, v = {}, {}
+    for k in GROUPS:
+        st = opt.state.get(groups[k]["params"][0], None)
+        if st is not None and "exp_avg" in st:
+            m[k], v[k] = st["exp_avg"], st["exp_avg_sq"]
+    if draw_id is None:
+        draw_id = getattr(gaussians, "_splatloc_draws", 0)
+        gaussians._splatloc_draws = draw_id + 1
+    new_p, new_m, new_v = densify_tensors(params, m, v, gaussians.xyz_gradient_accum, gaussians.denom, max_grad,
+                                          min_opacity, extent, max_screen_size, gaussians.percent_dense,
+                                          gaussians.primitive_reg, unit_noise=unit_noise, seed=seed, draw_id=draw_id)
+    for k in GROUPS:
+        grp = groups[k]
+        old = grp["params"][0]
+        st = opt.state.pop(old, None)
+        p = nn.Parameter(new_p[k].requires_grad_(True))
+        grp["params"][0] = p
+        if st is not None:
+            if k in new_m:
+                st["exp_avg"], st["exp_avg_sq"] = new_m[k], new_v[k]
+            opt.state[p] = st
+        setattr(gaussians, ATTR[k], p)
+    n = new_p["xyz"].shape[0]
+    dev = new_p["xyz"].device
+    gaussians.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+    gaussians.denom = torch.zeros((n, 1), device=dev)
+    gaussians.max_radii2D = torch.zeros((n,), device=dev)
+    return n

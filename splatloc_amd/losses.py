@@ -129,3 +129,40 @@ def ssim(img1, img2, window_size: int = 11, size_average: bool = True):
 def l1_loss(network_output, gt):
     """gaussian_splatting/utils/loss_utils.py:21-22."""
     return _RefinementLoss.apply(network_output, gt, 0.0, 2)
+
+
+class _IsotropicLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaling, marker):
+        lib = _native.load()
+        _require_gpu(scaling, "scaling")
+        dev = scaling.device
+        P, SC = int(scaling.shape[0]), int(scaling.shape[1])
+        if SC not in (1, 3) or marker.numel() != P:
+            raise RuntimeError("isotropic_loss: expected scaling [P,3] (or [P,1]) and marker [P,1]")
+        s, mk = _prep(scaling, dev), _prep(marker, dev)
+        row_grad = torch.empty((P,), dtype=torch.float32, device=dev)
+        out = torch.empty((2,), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.splatraster_isotropic_loss_workspace_bytes(P),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(lib.splatraster_isotropic_loss(P, SC, _ptr(s), _ptr(mk), _ptr(row_grad), _ptr(out), _ptr(ws),
+                                                         _stream(dev)), "isotropic_loss")
+        ctx.save_for_backward(row_grad, out)
+        ctx.SC = SC
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        row_grad, out = ctx.saved_tensors
+        return ((g * out[1]) * row_grad).view(-1, 1).expand(-1, ctx.SC), None
+
+
+def isotropic_loss(scaling, marker):
+    """The isotropic scale regulariser of SplatLoc.map (train_gaussians.py:222-226):
+
+        mask = marker.detach().squeeze() > 0.005
+        torch.abs(scaling.mean(dim=1).view(-1, 1)[mask] / (0.02 * (1 - marker[mask])) - 1).mean()
+
+    value and gradient w.r.t. the ACTIVATED `scaling` in two small HIP launches, with no `.cpu()`
+    synchronisation for the mask.  An empty mask gives 0 (the reference's mean over nothing is NaN)."""
+    return _IsotropicLoss.apply(scaling, marker.detach())

@@ -130,7 +130,7 @@ def main():
                 key = {tuple(r.tolist()): i for i, r in enumerate(scal_after_clone)}
                 idx = torch.tensor([key[tuple(r.tolist())] for r in std[:n]], dtype=torch.long)
                 assert torch.equal(std[:n], std[n:])
-                src = idx % P if False else idx          # clones are never split (their padded grad is 0)
+                src = idx                                # clones are never split (their padded grad is 0)
                 assert int(src.max()) < P
                 return torch.cat((unit[0, src], unit[1, src]), 0) * std + mean
 
