@@ -3,17 +3,25 @@
 
 One "step" = one optimisation step of SplatLoc.map as far as the rasterizer is concerned
 (train_gaussians.py:187-229): `--views` = 5 frames (the reference's window_size, configs/*/
-base_config.yaml: window_size: 5), each one forward + one backward pass of the rasterizer hot
+base_config.yaml: window_size: 5) seen from 5 DIFFERENT cameras (the reference draws 5 different
+key-frames, train_gaussians.py:195), each one forward + one backward pass of the rasterizer hot
 path (diff_gauss.GaussianRasterizer through the C ABI) over the synthetic workload S2 (500k
 Gaussians, 1920x1080, 35 channels: RGB + 32 feature channels, + depth + alpha), inputs resident
-in HBM, gradients accumulated over the window.  With N > 1 ranks (one process per GPU, RCCL)
-every rank renders its own window of a full scene replica and the accumulated parameter
-gradients are SUM-all-reduced ONCE per step inside the timed region (the frame-parallel map()
-step of SURVEY.md §8e): weak scaling, value = 5 N frames per step / max-over-ranks step time.
+in HBM, gradients accumulated over the window.
+
+N > 1 ranks (one process per GPU, RCCL over xGMI), full scene replica per rank:
+  --scaling weak   (default) every rank renders its OWN window of 5 views (different per rank);
+                   value = 5 N frames per step / max-over-ranks step time;
+  --scaling strong the ONE window of 5 views is dealt round-robin to the ranks
+                   (frame_parallel.shard_views) — exactly the reference step, faster.
+In both the accumulated parameter gradients are SUM-all-reduced ONCE per step inside the timed
+region and the densification statistics of the step are synchronised (SUM / MAX) so that every
+replica would densify identically.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline`
 (dominant kernel, HIP events measured live on the launch stream) and `cpu_baseline`
-(the CPU oracle timed on this host's cores on one frame of the same workload).
+(the CPU oracle timed on this host's cores on the same workload: warm-up + 3 frames, median/min,
+plus a single-core figure from a bounded row band).
 """
 import argparse
 import json
@@ -34,7 +42,7 @@ BREAKDOWN_STEPS = 20   # untimed steps that collect the per-stage table (and bri
 
 
 def algorithmic_bytes(P, R, W, H, C, tiles):
-    """Compulsory bytes: per stage and per fwd+bwd frame."""
+    """Compulsory bytes of the LINEAGE formulation: per stage and per fwd+bwd frame."""
     tile_bits = max(1, (tiles - 1).bit_length())
     n_pass = (32 + tile_bits + 7) // 8
     stage = {
@@ -47,27 +55,85 @@ def algorithmic_bytes(P, R, W, H, C, tiles):
         "composite_fwd": R * (32 + 4 * C) + W * H * (4 * C + 16),
         "composite_bwd": R * (32 + 4 * C) + W * H * (4 * C + 16) + P * (28 + 4 * C),
         "preprocess_bwd": P * (100 + 4 * C + 56 + 4 * C),
-        "payload": R * (8 + 32 + 33),  # not in the lineage: ids + gathered records in, records + mask out (+ tile ranges)
+        "payload": 0,  # not in the lineage
     }
     frame = P * (296 + 16 * C) + R * (20 + 24 * n_pass + 2 * (32 + 4 * C)) + W * H * (8 * C + 32)
     return stage, frame, n_pass
 
 
-def cpu_baseline(workload):
-    """The oracle (OpenMP build, all host cores) on ONE fwd+bwd frame of the same workload."""
+def actual_bytes(P, V, R, W, H, C, tiles):
+    """Compulsory bytes of THIS implementation's stages (every array once per pass that needs it; L2 /
+    Infinity-Cache hits, atomics and re-reads not counted) — the figure a stage's GB/s is quoted on.
+    DESIGN.md §4.2 derives each line."""
+    CP = (C + 3) & ~3
+    mo = C if ((C & 15) + 7 <= 16) else ((C + 15) & ~15)
+    grow = (mo + 7 + 15) & ~15                     # gacc_row_floats(C)
+    tile_bits = max(1, (tiles - 1).bit_length())
+    tile_passes = (tile_bits + 7) // 8
+    return {
+        "preprocess": P * (44 + 32 + 4 + 4 + 4 + 4),           # means/opacity/scale/quat in; record, tiles, radii, key, id out
+        "depth_sort": P * (4 + 4 * 16),                        # histogram read + 4 passes x (key, id) read + write
+        "scan": P * 12,                                        # tiles_touched (gathered), permutation, offsets
+        "emit": P * 20 + R * 8,                                # offsets, rect sources in; (tile id, gaussian id) out
+        "tile_sort": R * 20 * tile_passes,                     # per pass: histogram 4 + scatter 8 in + 8 out
+        "ranges": tiles * 8,
+        "payload": R * (8 + 32 + 33) + ((P * 4 * (C + CP)) if C % 4 else 0),   # ids + gathered records in; records + mask out; padded feature table
+        "composite_fwd": R * 37 + V * 4 * CP + W * H * (4 * C + 16),
+        "composite_bwd": R * 37 + V * 4 * CP + W * H * (8 * C + 20) + 2 * V * 4 * grow,
+        "preprocess_bwd": P * (4 * grow + 44 + 32 + 7) + P * (4 * C + 12 + 12 + 4 + 12 + 16),
+    }
+
+
+def cpu_baseline(workload, frames=3):
+    """the oracle (OpenMP build, every host core) on fwd+bwd frames of the same workload —
+    1 warm-up frame, then `frames` timed ones, median and min — plus a single-core figure from a bounded
+    sample: the non-OpenMP build on the full P-sized front end and a 64-row band of the image,
+    extrapolated to the full height."""
     from oracle import oracle
-    from splatloc_amd.synthetic import make_workload
+    from splatloc_amd.synthetic import WORKLOADS, make_workload
     from tests.helpers import oracle_backward, oracle_forward
     sc = make_workload(workload)
+    H = WORKLOADS[workload]["H"]
     oracle.build()
-    t0 = time.perf_counter()
-    f = oracle_forward(sc, omp=True)
-    t1 = time.perf_counter()
-    oracle_backward(f, sc, omp=True)
-    t2 = time.perf_counter()
-    return {"value": 1.0 / (t2 - t0), "unit": "frames/s", "cores": oracle.num_threads(True), "kind": "port",
-            "sample": f"1 fwd+bwd frame of {workload} (fwd {t1 - t0:.2f} s, bwd {t2 - t1:.2f} s), "
-                      f"oracle/splat_oracle.c built with -fopenmp",
+    oracle.set_row_band()
+    times = []
+    for k in range(frames + 1):
+        t0 = time.perf_counter()
+        f = oracle_forward(sc, omp=True)
+        t1 = time.perf_counter()
+        oracle_backward(f, sc, omp=True)
+        t2 = time.perf_counter()
+        if k:
+            times.append((t2 - t0, t1 - t0, t2 - t1))
+    times.sort()
+    med, best = times[len(times) // 2], times[0]
+    # single core: a band of `rows` image rows in the middle of the frame (the front end is run in full)
+    rows = 64
+    y0 = (H - rows) // 2 // 16 * 16
+    try:
+        oracle.set_row_band(y0, y0 + rows)
+        t0 = time.perf_counter()
+        f1 = oracle_forward(sc, omp=False)
+        t1 = time.perf_counter()
+        oracle_backward(f1, sc, omp=False)
+        t2 = time.perf_counter()
+        oracle.set_row_band(y0, y0)          # empty band: the P-sized front end + preprocess backward alone
+        t3 = time.perf_counter()
+        f0 = oracle_forward(sc, omp=False)
+        oracle_backward(f0, sc, omp=False)
+        t4 = time.perf_counter()
+    finally:
+        oracle.set_row_band()
+    front = t4 - t3
+    band = max((t2 - t0) - front, 1e-9)
+    single = front + band * (H / rows)
+    return {"value": 1.0 / med[0], "unit": "frames/s", "cores": oracle.num_threads(True), "kind": "port",
+            "sample": f"{frames} fwd+bwd frames of {workload} after 1 warm-up frame, oracle/splat_oracle.c built with "
+                      f"-fopenmp: median {med[0]:.2f} s (fwd {med[1]:.2f} + bwd {med[2]:.2f}), min {best[0]:.2f} s",
+            "min_frames_per_s": 1.0 / best[0],
+            "single_core": {"value": 1.0 / single, "unit": "frames/s", "cores": 1,
+                            "sample": f"non-OpenMP build: full front end + preprocess backward ({front:.2f} s) + compositing "
+                                      f"fwd+bwd of image rows [{y0}, {y0 + rows}) ({band:.2f} s), extrapolated x {H}/{rows}"},
             "host_cpu_count": os.cpu_count()}
 
 
@@ -262,33 +328,51 @@ def bench_loss(args, dev):
 
 def bench_map_step(args, dev):
     """--stage map_step: one optimisation step of SplatLoc.map (train_gaussians.py:187-267) on the
-    S2 shapes — 5 views x (render -> per-view mapping loss), ONE backward, densification
-    statistics, Adam over the parameter groups — with the fused front-end / loss
-    (splatloc_amd.fused.render, splatloc_amd.losses.mapping_loss, splatloc_amd.densify) and, for comparison, with the
-    reference's chains of torch ops around the same rasterizer.  Secondary figure, not the
-    BASELINE metric (which is the rasterizer fwd+bwd alone)."""
+    S2 shapes — 5 views x (render -> per-view mapping loss), the isotropic regulariser, ONE backward,
+    densification statistics, the key-primitive gradient gate + Adam over the 8 parameter groups, and
+    densify_and_prune every `--densify-every` steps — with the fused device-side pieces
+    (splatloc_amd.fused.render, .losses.mapping_loss / isotropic_loss, .densify, .optim.Adam) and, for
+    comparison, with the reference's chains of torch ops around the same rasterizer (no densification in
+    that leg: the reference's densify is ~90 boolean-mask launches with host syncs; its cost is reported
+    separately for the fused path).  Secondary figure, not the BASELINE metric."""
     import types
     from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer
     from splatloc_amd.camera import PinholeCamera
-    from splatloc_amd.densify import add_densification_stats
+    from splatloc_amd.densify import add_densification_stats, densify_and_prune
     from splatloc_amd.fused import render as fused_render
-    from splatloc_amd.losses import mapping_loss
+    from splatloc_amd.losses import isotropic_loss, mapping_loss
+    from splatloc_amd.optim import Adam as FusedAdam
     from splatloc_amd.synthetic import WORKLOADS, make_workload
     wl = WORKLOADS[args.workload]
     sc = make_workload(args.workload)
-    P, W, H, C = wl["P"], wl["W"], wl["H"], wl["C"]
+    P0, W, H, C = wl["P"], wl["W"], wl["H"], wl["C"]
     E = max(C - 3, 1)
-    g = torch.Generator().manual_seed(11)
-    par = lambda t: t.to(dev).requires_grad_(True)  # noqa: E731
     inv_sig = lambda p: torch.log(p / (1 - p))  # noqa: E731
-    pc = types.SimpleNamespace(
-        _xyz=par(sc.means3D.clone()), _features_dc=par(((sc.features[:, :3] - 0.5) / 0.28209479177387814)[:, None, :].contiguous()),
-        _features_rest=par(torch.zeros(P, 0, 3)), _scaling=par(torch.log(sc.scales)), _rotation=par(sc.rotations.clone()),
-        _opacity=par(inv_sig(sc.opacities.clamp(1e-4, 1 - 1e-4))), _kp_score=par(torch.rand(P, E, generator=g)),
-        active_sh_degree=0, max_sh_degree=0)
-    params = [pc._xyz, pc._features_dc, pc._scaling, pc._rotation, pc._opacity, pc._kp_score]
-    opt = torch.optim.Adam([{"params": [p_], "lr": lr} for p_, lr in zip(params, (1.6e-4, 2.5e-3, 1e-3, 1e-3, 5e-2, 5e-2))],
-                           lr=0.0, eps=1e-15, fused=True)
+    NAMES = ("xyz", "f_dc", "f_rest", "opacity", "marker", "kp_score", "scaling", "rotation")
+    ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+            "marker": "_marker", "kp_score": "_kp_score", "scaling": "_scaling", "rotation": "_rotation"}
+    LR = {"xyz": 1.6e-4 * 6.0, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 5e-2, "marker": 5e-2, "kp_score": 5e-2,
+          "scaling": 1e-3 * 6.0, "rotation": 1e-3}
+
+    def make_model(adam_cls, **adam_kw):
+        g = torch.Generator().manual_seed(11)
+        par = lambda t: torch.nn.Parameter(t.to(dev).contiguous().requires_grad_(True))  # noqa: E731
+        pc = types.SimpleNamespace(
+            _xyz=par(sc.means3D.clone()),
+            _features_dc=par(((sc.features[:, :3] - 0.5) / 0.28209479177387814)[:, None, :].contiguous()),
+            _features_rest=par(torch.zeros(P0, 0, 3)), _opacity=par(inv_sig(sc.opacities.clamp(1e-4, 1 - 1e-4))),
+            _marker=par((torch.rand(P0, 1, generator=g) < 0.05).float() * torch.rand(P0, 1, generator=g) * 0.9),
+            _kp_score=par(torch.rand(P0, E, generator=g)), _scaling=par(torch.log(sc.scales)),
+            _rotation=par(sc.rotations.clone()), active_sh_degree=0, max_sh_degree=0, percent_dense=0.01,
+            primitive_reg=True)
+        pc.optimizer = adam_cls([{"params": [getattr(pc, ATTR[k])], "lr": LR[k], "name": k} for k in NAMES], lr=0.0,
+                                eps=1e-15, **adam_kw)
+        pc.xyz_gradient_accum = torch.zeros(P0, 1, device=dev)
+        pc.denom = torch.zeros(P0, 1, device=dev)
+        pc.max_radii2D = torch.zeros(P0, device=dev)
+        return pc
+
+    g = torch.Generator().manual_seed(12)
     views = []
     for k in range(5):
         ang = torch.tensor(0.02 * (k - 2))
@@ -303,11 +387,8 @@ def bench_map_step(args, dev):
     bg = torch.zeros(3, device=dev)
     pipe = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
     cfg = {"Training": {"rgb_boundary_threshold": 0.01}}
-    accum = torch.zeros(P, 1, device=dev)
-    denom = torch.zeros(P, 1, device=dev)
-    max_radii = torch.zeros(P, device=dev)
 
-    def composed_render(cam):   # gaussian_renderer/__init__.py:59-126 with torch ops
+    def composed_render(pc, cam):   # gaussian_renderer/__init__.py:59-126 with torch ops
         rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
                                            cam.world_view_transform, cam.full_proj_transform, 0, cam.camera_center,
                                            False, False)
@@ -330,50 +411,78 @@ def bench_map_step(args, dev):
             + torch.nn.functional.binary_cross_entropy(torch.sigmoid(marker.view(-1)), cam.kp_score.view(-1).float(),
                                                        reduction="mean")
 
-    def step(fused):
+    def step(pc, fused, it, densify_ms):
         loss, pkgs = 0, []
         for cam in views:
-            pkg = fused_render(cam, pc, pipe, bg) if fused else composed_render(cam)
+            pkg = fused_render(cam, pc, pipe, bg) if fused else composed_render(pc, cam)
             if fused:
                 loss = loss + mapping_loss(cfg, pkg["render"], pkg["depth"], pkg["kp_prob"], cam)
             else:
                 loss = loss + composed_loss(cam, pkg["render"], pkg["depth"], pkg["kp_prob"])
             pkgs.append(pkg)
+        if fused:      # train_gaussians.py:221-228, no .cpu() sync
+            loss = loss + 0.01 * isotropic_loss(torch.exp(pc._scaling), pc._marker)
+        else:
+            scaling, score = torch.exp(pc._scaling), pc._marker.detach()
+            mask = score.cpu().squeeze() > 0.005
+            loss = loss + 0.01 * torch.abs(scaling.mean(dim=1).view(-1, 1)[mask] / (0.02 * (1 - score[mask])) - 1).mean()
         loss.backward()
-        with torch.no_grad():   # train_gaussians.py:238-246, gaussian_model.py:677-679
+        with torch.no_grad():   # train_gaussians.py:231-267, gaussian_model.py:677-679
+            if fused:
+                pc.optimizer.set_key_gate(pc._marker, 0.005)
+            else:
+                key_mask = pc._marker.detach().cpu().squeeze() > 0.005
+                pc._xyz.grad[key_mask] = 0
             for pkg in pkgs:
                 if fused:
-                    add_densification_stats(pkg["viewspace_points"].grad, pkg["radii"], accum, denom, max_radii)
+                    add_densification_stats(pkg["viewspace_points"].grad, pkg["radii"], pc.xyz_gradient_accum, pc.denom,
+                                            pc.max_radii2D)
                     continue
                 vis = pkg["visibility_filter"]
-                max_radii[vis] = torch.max(max_radii[vis], pkg["radii"][vis].float())
-                accum[vis] += torch.norm(pkg["viewspace_points"].grad[vis, :2], dim=-1, keepdim=True)
-                denom[vis] += 1
-            opt.step()
-            opt.zero_grad(set_to_none=True)
+                pc.max_radii2D[vis] = torch.max(pc.max_radii2D[vis], pkg["radii"][vis].float())
+                pc.xyz_gradient_accum[vis] += torch.norm(pkg["viewspace_points"].grad[vis, :2], dim=-1, keepdim=True)
+                pc.denom[vis] += 1
+            if fused and args.densify_every and it % args.densify_every == args.densify_every // 3:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                n_before = pc._xyz.shape[0]
+                densify_and_prune(pc, 0.0002, 0.005, 6.0, 20, seed=7)   # thresholds of configs/replica_nerf/base_config.yaml (init_gaussian_th)
+                e1.record()
+                densify_ms.append((e0, e1, n_before, pc._xyz.shape[0]))
+            pc.optimizer.step()
+            pc.optimizer.zero_grad(set_to_none=True)
             for cam in views:
                 cam.exposure_a.grad = cam.exposure_b.grad = None
 
     def time_it(fused):
-        for _ in range(args.warmup):
-            step(fused)
+        pc = make_model(FusedAdam) if fused else make_model(torch.optim.Adam, fused=True)
+        dens = []
+        for it in range(args.warmup):
+            step(pc, fused, -1, dens)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(fused)
+        for it in range(args.steps):
+            step(pc, fused, it, dens)
         torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / args.steps * 1e3
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        return ms, [(a.elapsed_time(b), n0, n1) for a, b, n0, n1 in dens]
 
-    ms_f = time_it(True)
-    ms_c = time_it(False)
+    ms_f, dens = time_it(True)
+    ms_c, _ = time_it(False)
+    dens_total = sum(d[0] for d in dens)
     print(json.dumps({
         "metric": "SplatLoc.map optimisation steps/s (5 views/step; secondary figure, NOT the BASELINE metric)",
         "value": round(1e3 / ms_f, 2), "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_f, 3), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: P={P}, {W}x{H}, C={3 + E} ([rgb | {E} kp/feature columns]) + depth + alpha; "
-                               "5 views x (render + mapping loss), one backward, densification stats, fused Adam"},
+        "config": {"workload": f"{args.workload}: P={P0}, {W}x{H}, C={3 + E} ([rgb | {E} kp/feature columns]) + depth + alpha; "
+                               "5 views x (render + mapping loss), isotropic regulariser, one backward, densification "
+                               f"stats, key gate + fused Adam over 8 groups, densify_and_prune every {args.densify_every} steps"},
         "views_per_s": round(5e3 / ms_f, 1),
-        "torch_front_end_and_loss_same_rasterizer": {"ms_per_step": round(ms_c, 3), "speedup": round(ms_c / ms_f, 3)},
+        "densify": {"calls_in_timed_region": len(dens), "ms_per_call": [round(d[0], 3) for d in dens],
+                    "rows_before_after": [[d[1], d[2]] for d in dens],
+                    "ms_per_step_without_densify": round((ms_f * args.steps - dens_total) / args.steps, 3)},
+        "torch_front_end_loss_adam_same_rasterizer_no_densify": {"ms_per_step": round(ms_c, 3),
+                                                                 "speedup": round(ms_c / ((ms_f * args.steps - dens_total) / args.steps), 3)},
     }), flush=True)
 
 
@@ -385,6 +494,10 @@ def main():
     ap.add_argument("--workload", default="S2")
     ap.add_argument("--views", type=int, default=5,
                     help="frames per optimisation step (SplatLoc.map's window_size = 5); gradients accumulate")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank renders its own window; strong = one window dealt to the ranks")
+    ap.add_argument("--densify-every", type=int, default=10,
+                    help="--stage map_step: densify_and_prune every N steps (the reference: 150, offset 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
     ap.add_argument("--stage", default="raster", choices=["raster", "activations", "loss", "map_step"],
@@ -419,40 +532,69 @@ def main():
         return
 
     from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer, _native
-    from splatloc_amd.frame_parallel import allreduce_grads
+    from splatloc_amd.camera import PinholeCamera
+    from splatloc_amd.densify import add_densification_stats
+    from splatloc_amd.frame_parallel import allreduce_grads, shard_views, sync_densification_stats
     from splatloc_amd.synthetic import WORKLOADS, make_workload
 
     wl = WORKLOADS[args.workload]
     sc = make_workload(args.workload).to(dev)
-    cam = sc.camera
     P, W, H, C = wl["P"], wl["W"], wl["H"], wl["C"]
     leaf = lambda t: t.clone().requires_grad_(True)  # noqa: E731
     means3D, colors, opac = leaf(sc.means3D), leaf(sc.features), leaf(sc.opacities)
     scales, rots = leaf(sc.scales), leaf(sc.rotations)
-    means2D = torch.zeros_like(means3D, requires_grad=True)
-    params = [means3D, means2D, colors, opac, scales, rots]
-    rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, sc.bg, 1.0, cam.world_view_transform,
-                                       cam.full_proj_transform, 0, cam.camera_center, False, False)
-    rast = GaussianRasterizer(raster_settings=rs)
-    g_out = (sc.dL_dcolor, sc.dL_ddepth, sc.dL_dalpha)
-    info = {}
+    params = [means3D, colors, opac, scales, rots]
 
-    def step():
+    # The window: `--views` DIFFERENT cameras (small rotations / translations about the scene's camera, as
+    # consecutive key-frames are), different on every rank in weak mode.  Nothing of one frame (lists,
+    # payload, images) can be found in a cache by the next.  Strong mode deals ONE window to the ranks.
+    def make_view(j):
+        ang = torch.tensor(0.02 * ((j % 5) - 2) + 0.0037 * (j // 5))
+        Rm = torch.tensor([[torch.cos(ang), 0, torch.sin(ang)], [0, 1, 0], [-torch.sin(ang), 0, torch.cos(ang)]])
+        cam = PinholeCamera(W, H, W / 2.0, W / 2.0, (W - 1) / 2.0, (H - 1) / 2.0, Rm,
+                            torch.tensor([0.01 * (j % 5) + 0.002 * (j // 5), 0.0, 0.0])).to(dev)
+        rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, sc.bg, 1.0, cam.world_view_transform,
+                                           cam.full_proj_transform, 0, cam.camera_center, False, False)
+        # a different dL/dout per view: the seeded gradient images, rolled
+        g = tuple(torch.roll(t, shifts=37 * j, dims=-1).contiguous() for t in (sc.dL_dcolor, sc.dL_ddepth, sc.dL_dalpha))
+        return GaussianRasterizer(raster_settings=rs), g
+
+    if args.scaling == "strong":
+        my_ids = shard_views(list(range(args.views)), rank, world)
+    else:
+        my_ids = [rank * args.views + k for k in range(args.views)]
+    views = [make_view(j) for j in my_ids]
+    frames_per_step = args.views if args.scaling == "strong" else world * args.views
+    accum = torch.zeros(P, 1, device=dev)
+    denom = torch.zeros(P, 1, device=dev)
+    max_radii = torch.zeros(P, device=dev)
+    info = {"R": [], "V": []}
+
+    def step(record=False):
         for p in params:
             p.grad = None
-        for _ in range(args.views):   # the window: every frame one forward + one backward, grads accumulate
+        if world > 1:
+            accum.zero_()
+            denom.zero_()
+        for rast, g_out in views:   # every frame one forward + one backward, parameter gradients accumulate
+            means2D = torch.zeros_like(means3D, requires_grad=True)   # per-view grad carrier (render(): screenspace_points)
             color, depth, alpha, radii = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors,
                                               opacities=opac, scales=scales, rotations=rots, cov3D_precomp=None)
-            info["R"] = color.grad_fn.num_rendered
-            info["radii"] = radii
+            if record:
+                info["R"].append(int(color.grad_fn.num_rendered))
+                info["V"].append(int((radii > 0).sum().item()))
             if not args.fwd_only:
                 torch.autograd.backward((color, depth, alpha), g_out)
-        if not args.fwd_only:
-            if world > 1:
-                # parameter gradients only: the viewspace (means2D) gradient feeds per-view
-                # densification statistics, which replicas sync through their own accumulators
-                # (frame_parallel.sync_densification_stats), not through a gradient sum
-                allreduce_grads([p.grad for p in params if p is not means2D])
+                if world > 1:   # the step's densification statistics (train_gaussians.py:238-245)
+                    add_densification_stats(means2D.grad, radii, accum, denom, max_radii)
+        if not args.fwd_only and world > 1:
+            # ONE SUM all-reduce of the accumulated parameter gradients (a rank without views in strong
+            # mode contributes zeros) + the statistics every replica needs to densify identically
+            for p in params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            info["reduce_path"] = allreduce_grads([p.grad for p in params])
+            sync_densification_stats(accum, denom, max_radii)
 
     def barrier():
         if world > 1:
@@ -461,6 +603,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    step(record=True)
     # (1) untimed breakdown pass: every stage bracketed by HIP events.  An event record between
     #     two kernels idles the GPU for ~10 us, so this is NOT done inside the timed region.
     barrier()
@@ -471,7 +614,7 @@ def main():
     barrier()
     _native.timing_enable(False)
     stages = _native.timing_collect()
-    dom = max(stages, key=lambda s: stages[s][0])
+    dom = max(stages, key=lambda s: stages[s][0]) if views else "composite_bwd"
     # (2) timed region: only the dominant kernel is bracketed (roofline.achieved is measured live
     #     here, on the launch stream)
     _native.timing_select([dom])
@@ -489,48 +632,65 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        R = int(info["R"])
-        V = int((info["radii"] > 0).sum().item())
+        Rs, Vs = info["R"], info["V"]
+        R = int(round(sum(Rs) / max(len(Rs), 1)))
+        V = int(round(sum(Vs) / max(len(Vs), 1)))
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         st_bytes, frame_bytes, n_pass = algorithmic_bytes(P, R, W, H, C, tiles)
+        act_bytes = actual_bytes(P, V, R, W, H, C, tiles)
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.views * args.steps / elapsed
+        value = frames_per_step * args.steps / elapsed
         per_stage = {}
         for s, (ms, cnt) in stages.items():
             if cnt:
                 avg = ms / cnt
-                per_stage[s] = {"avg_ms": round(avg, 4), "launches": int(cnt),
-                                "algorithmic_GBps": round(st_bytes[s] / (avg * 1e-3) / 1e9, 1)}
+                per_stage[s] = {"avg_ms": round(avg, 4), "launches": int(cnt), "lineage_bytes": int(st_bytes[s]),
+                                "actual_bytes": int(act_bytes[s]),
+                                "actual_GBps": round(act_bytes[s] / (avg * 1e-3) / 1e9, 1)}
         per_stage[dom]["measured"] = "live in the timed region"
-        ach = per_stage[dom]["algorithmic_GBps"]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom)
-            except Exception:  # noqa: BLE001
-                traffic = None
+        dom_avg = stages[dom][0] / max(stages[dom][1], 1)
+        ach = round(st_bytes[dom] / (dom_avg * 1e-3) / 1e9, 1)     # roofline: SURVEY §8d algorithmic bytes / duration
+        prof = {}
+        for name in ("traffic.json", "valu.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath):
+                try:
+                    prof[name] = json.load(open(tpath))
+                except Exception:  # noqa: BLE001
+                    pass
+        traffic = prof.get("traffic.json", {}).get(dom)
         out = {
             "metric": "fwd+bwd frames/s @1080p, 500k Gaussians, 32 feat-ch; HBM GB/s vs roofline",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: P={P} Gaussians, {W}x{H}, C={C} channels "
-                                   f"(3 RGB + {C - 3} feature) + depth + alpha, seed {wl['seed']}",
-                       "tile_instances_R": R, "visible_gaussians_V": V, "frames_per_step": world * args.views, "views_per_rank_per_step": args.views,
+                                   f"(3 RGB + {C - 3} feature) + depth + alpha, seed {wl['seed']}; "
+                                   f"{args.views} different cameras per window",
+                       "tile_instances_R_per_view": Rs, "visible_gaussians_V_per_view": Vs,
+                       "tile_instances_R": R, "visible_gaussians_V": V,
+                       "frames_per_step": frames_per_step, "views_on_rank0_per_step": len(views),
                        "parallelism": f"frame-parallel dp{world}, scene replica per GPU"
-                                      + (", one RCCL SUM all-reduce of the accumulated parameter grads per step" if world > 1 else "")},
+                                      + (", one RCCL SUM all-reduce of the accumulated parameter grads + densification-"
+                                         "statistics sync per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "note": "composite kernels are VALU/LDS-bound, not HBM-bound (DESIGN.md)"},
+                         "algorithmic_bytes_per_launch": int(st_bytes[dom]), "avg_ms": round(dom_avg, 4),
+                         "note": "composite kernels are VALU/LDS-bound, not HBM-bound (DESIGN.md); see frame_valu"},
             "frame_hbm": {"algorithmic_bytes_per_frame": frame_bytes, "lineage_radix_passes": n_pass,
                           "achieved_GBps": round(frame_bytes * value / world / 1e9, 1),
                           "frac_of_peak": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5),
-                          "ms_per_frame": round(ms_per_step / args.views, 4)},
+                          "ms_per_frame": round(ms_per_step / max(len(views), 1), 4)},
+            "frame_valu": prof.get("valu.json"),
             "stages": per_stage,
             "stages_note": f"per-stage table from {BREAKDOWN_STEPS} untimed steps with every stage bracketed by HIP "
-                           f"events; only '{dom}' is bracketed inside the timed region",
+                           f"events; only '{dom}' is bracketed inside the timed region. lineage_bytes = SURVEY 8d's "
+                           "compulsory figure for the lineage's formulation of the stage; actual_bytes = compulsory "
+                           "bytes of this implementation's stage (actual_GBps is quoted on it; P-sized inputs are "
+                           "shared by the 5 views of a step and may be served by the 256-MiB Infinity Cache)",
         }
+        if world > 1:
+            out["config"]["grad_allreduce_path"] = info.get("reduce_path")
         if args.fwd_only:
             out["metric"] = "DEBUG fwd-only frames/s (not the BASELINE metric)"
         if world == 1 and not args.no_cpu_baseline:

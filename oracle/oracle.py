@@ -228,3 +228,9 @@ def set_alpha_mode(mode: int) -> None:
     """0 = shared arithmetic contract (default), 1 = the lineage's literal expf form (both builds)."""
     for omp in (False, True):
         _lib(omp).orc_set_alpha_mode(C.c_int(mode))
+
+
+def set_row_band(y0: int = 0, y1: int = 0x7FFFFFFF) -> None:
+    """Restrict the compositing passes to image rows [y0, y1) (bench.py's single-core sample)."""
+    for omp in (False, True):
+        _lib(omp).orc_set_row_band(C.c_int(y0), C.c_int(y1))

@@ -71,13 +71,20 @@ def allreduce_grads(tensors: Iterable[Optional[torch.Tensor]], group=None, bucke
     reduced where they are, as one call; the rest are coalesced into flat buckets.
     Tensors that are None are skipped (a rank whose views saw no Gaussian still has dense
     zero grads from the rasterizer, so shapes agree across ranks).
+
+    Returns which path the payload took, e.g. {"spans": 1, "span_bytes": 92000000, "buckets": 0,
+    "bucket_bytes": 0} — the in-place span path depends on autograd keeping the rasterizer's gradient
+    views as `.grad` (it does when a parameter's first gradient of the step is one of them); a silent
+    fall-back to the staged bucket path would otherwise go unnoticed (None when not distributed).
     """
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return
+        return None
     with torch.no_grad():
         spans, ts = _shared_spans([t for t in tensors if t is not None])
     bucket, size = [], 0
     pending = []
+    path = {"spans": len(spans), "span_bytes": sum(sp.numel() * sp.element_size() for sp in spans), "buckets": 0,
+            "bucket_bytes": sum(t.numel() * t.element_size() for t in ts)}
     for span in spans:
         pending.append((dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group, async_op=True), None, None))
 
@@ -85,6 +92,7 @@ def allreduce_grads(tensors: Iterable[Optional[torch.Tensor]], group=None, bucke
         nonlocal bucket, size
         if not bucket:
             return
+        path["buckets"] += 1
         if len(bucket) == 1 and bucket[0].is_contiguous():
             pending.append((dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=group, async_op=True), None, None))
         else:
@@ -107,6 +115,7 @@ def allreduce_grads(tensors: Iterable[Optional[torch.Tensor]], group=None, bucke
                 n = t.numel()
                 t.copy_(flat[off:off + n].view_as(t))
                 off += n
+    return path
 
 
 def sync_densification_stats(grad_accum_inc: torch.Tensor, denom_inc: torch.Tensor, max_radii2D: torch.Tensor,

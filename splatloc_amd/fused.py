@@ -128,7 +128,15 @@ def _covariance_python(scales, scaling_modifier, rotation_raw):
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
            mask=None) -> Optional[dict]:
-    """Drop-in for gaussian_renderer.render (gaussian_renderer/__init__.py:13-141)."""
+    """Drop-in for gaussian_renderer.render (gaussian_renderer/__init__.py:13-141): same signature, same
+    return dict, same values and gradients (tests/test_gpu_activations.py against the reference's own render()).
+
+    Two corners where the reference's code path is dead or broken, and what happens here:
+      * `override_color` is IGNORED, exactly as in the reference (`colors_precomp` is reset to None right before
+        the `if colors_precomp is None` test, gaussian_renderer/__init__.py:83-98, so the `else` is unreachable);
+      * `mask` with `pipe.convert_SHs_python=True` raises TypeError in the reference (`shs[mask]` with shs = None,
+        :108); here it renders the masked subset with the [rgb | kp_score] table like the unmasked call.  With
+        `convert_SHs_python=False` both render 3 SH channels and `kp_prob` is channel 2, as in the reference."""
     xyz = pc._xyz
     if xyz.shape[0] == 0:
         return None
@@ -150,17 +158,15 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     sel = (lambda t: t) if mask is None else (lambda t: t[mask])
     means3D, means2D = sel(xyz), sel(screenspace_points)
     f_dc, f_rest = sel(pc._features_dc), sel(pc._features_rest)
-    convert_shs = bool(pipe.convert_SHs_python) and override_color is None
+    convert_shs = bool(pipe.convert_SHs_python)
     # the packed colours are only needed when the rasterizer is fed colors_precomp
-    want_colors = convert_shs or override_color is not None
+    want_colors = convert_shs
     scales, rotations, opacity, colors = activate_pack(
         means3D, f_dc, f_rest, sel(pc._scaling), sel(pc._rotation), sel(pc._opacity),
         extra=sel(pc._kp_score) if want_colors else None, campos=campos,
         active_sh_degree=pc.active_sh_degree if convert_shs else 0)
     shs = colors_precomp = cov3D_precomp = None
-    if override_color is not None:
-        colors_precomp = torch.cat((sel(override_color), sel(pc._kp_score)), dim=1)
-    elif convert_shs:
+    if convert_shs:
         colors_precomp = colors
     else:
         shs = torch.cat((f_dc, f_rest), dim=1)

@@ -100,6 +100,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             Cn, M = 3, int(shs.shape[1])
         elif col is not None:
             Cn, M = int(col.shape[1]), 0
+        elif colors_precomp is not None and colors_precomp.dim() == 2 and colors_precomp.shape[1] > 0:
+            Cn, M = int(colors_precomp.shape[1]), 0     # P = 0: the channel count is still the table's width
         else:
             Cn, M = (3, 0)
         st = _native.Settings(H, W, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),

@@ -202,12 +202,16 @@ def test_render_variants_and_errors():
     cov = render(cam, pc, types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=True), bg)
     assert float((cov["render"] - base["render"]).abs().max()) <= 2e-4
     assert torch.equal(cov["radii"], base["radii"])
-    # override colour + mask
-    mask = torch.arange(1500, device=DEV) % 3 != 0
+    # override_color is ignored exactly as in the reference (gaussian_renderer/__init__.py:83-98: dead branch)
     oc = torch.rand(1500, 3, device=DEV)
-    out = render(cam, pc, types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False), bg,
-                 override_color=oc, mask=mask)
+    ov = render(cam, pc, types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False), bg, override_color=oc)
+    assert torch.equal(ov["render"], base["render"]) and torch.equal(ov["kp_prob"], base["kp_prob"])
+    # mask: the masked subset; with convert_SHs_python False 3 SH channels and kp_prob = channel 2 (reference :104-115)
+    mask = torch.arange(1500, device=DEV) % 3 != 0
+    out = render(cam, pc, types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False), bg, mask=mask)
     assert out["radii"].shape[0] == int(mask.sum())
+    outs = render(cam, pc, types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False), bg, mask=mask)
+    assert torch.equal(outs["kp_prob"], outs["render"][2]) and float((outs["render"] - out["render"]).abs().max()) <= 2e-5
     # empty model -> None, like the reference
     empty = types.SimpleNamespace(_xyz=torch.empty(0, 3, device=DEV))
     assert render(cam, empty, None, bg) is None
