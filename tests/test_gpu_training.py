@@ -127,25 +127,33 @@ def test_parameter_grads_of_a_frame_form_one_span():
             assert l.grad.data_ptr() % 16 == 0 and torch.isfinite(l.grad).all()
 
 
-def test_bench_two_ranks_on_one_gpu_gloo():
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu_gloo(scaling):
     """bench.py --gpus 2 through torch.distributed.run (the driver's launch line), gloo backend,
-    both ranks on cuda:0: exercises rank/world plumbing, the gradient all-reduce and the
-    max-over-ranks timing.  (RCCL itself needs 2 GPUs; this box has one.)"""
+    both ranks on cuda:0: exercises rank/world plumbing, the per-rank views, the gradient all-reduce
+    (in-place span path), the densification-statistics sync and the max-over-ranks timing, in the weak
+    (own window per rank) and the strong (one window of 3 views dealt to 2 ranks) mode.
+    (RCCL itself needs 2 GPUs; this box has one.)"""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, SPLATLOC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    views = 2 if scaling == "weak" else 3
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--workload", "S0", "--no-cpu-baseline", "--views", "2"]
+           "--warmup", "1", "--workload", "S0", "--no-cpu-baseline", "--views", str(views), "--scaling", scaling]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]     # rank 0 prints ONE line
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["frames_per_step"] == 4 and out["scaling"] == "weak"
-    assert out["config"]["views_per_rank_per_step"] == 2
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    assert out["config"]["frames_per_step"] == (4 if scaling == "weak" else 3)
+    assert out["config"]["views_on_rank0_per_step"] == 2          # weak: its own 2; strong: views 0 and 2 of 3
+    path = out["config"]["grad_allreduce_path"]
+    assert path["spans"] == 1 and path["buckets"] == 0, path     # the gradients were reduced where the backward left them
     assert out["value"] > 0 and out["steps"] == 3 and "roofline" in out and "cpu_baseline" not in out
+    assert len(set(out["config"]["tile_instances_R_per_view"])) == 2   # different cameras -> different lists
 
 
 @pytest.mark.parametrize("stage,extra", [("activations", []), ("loss", []), ("map_step", ["--workload", "S0"])])
