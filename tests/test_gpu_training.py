@@ -169,3 +169,60 @@ def test_bench_secondary_stages_run(stage, extra):
     assert out["value"] > 0 and out["unit"].endswith("/s") and "NOT the BASELINE metric" in out["metric"]
     if stage != "map_step":
         assert 0 < out["roofline"]["frac"] < 1
+
+
+def test_map_shaped_step_matches_reference_recording(golden_dir):
+    """one SplatLoc.map step — 5 views x (render -> get_loss_mapping + get_loss_marker), the
+    isotropic regulariser, ONE backward — recorded from the reference's own render() / GaussianModel / Camera /
+    loss functions (tests/golden/make_golden_map_step.py; the oracle stands in for the un-vendored rasterizer),
+    against the device path: fused front end, HIP rasterizer, fused losses."""
+    import types
+    from splatloc_amd.camera import PinholeCamera
+    from splatloc_amd.fused import render
+    from splatloc_amd.losses import isotropic_loss, mapping_loss
+    from tests.helpers import assert_grad_close
+    d = np.load(os.path.join(golden_dir, "map_step.npz"))
+    dev = torch.device("cuda:0")
+    fx, fy, cx, cy, W, H = (float(v) for v in d["intr"][:6])
+    W, H = int(W), int(H)
+    names = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+             "marker": "_marker", "kp_score": "_kp_score", "scaling": "_scaling", "rotation": "_rotation"}
+    pc = types.SimpleNamespace(active_sh_degree=0, max_sh_degree=0)
+    for k, a in names.items():
+        setattr(pc, a, torch.from_numpy(d["raw_" + k]).to(dev).requires_grad_(True))
+    assert pc._features_rest.shape[1:] == (0, 3)
+    pipe = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
+    cfg = {"Training": {"primitive_reg": True, "rgb_boundary_threshold": 0.01}}
+    bg = torch.zeros(3, device=dev)
+    loss, pkgs, cams = 0, [], []
+    for k in range(5):
+        T = torch.from_numpy(d[f"view{k}_T"])
+        cam = PinholeCamera(W, H, fx, fy, cx, cy, T[:3, :3], T[:3, 3]).to(dev)
+        cam.original_image = torch.from_numpy(d[f"view{k}_color"]).to(dev)
+        cam.depth = d[f"view{k}_depth"]                                   # numpy, as the reference's Camera holds it
+        cam.kp_score = torch.from_numpy(d[f"view{k}_kp"]).to(dev)
+        ea, eb = d[f"view{k}_exposure"]
+        cam.exposure_a = torch.tensor([float(ea)], device=dev, requires_grad=True)
+        cam.exposure_b = torch.tensor([float(eb)], device=dev, requires_grad=True)
+        pkg = render(cam, pc, pipe, bg)
+        loss = loss + mapping_loss(cfg, pkg["render"], pkg["depth"], pkg["kp_prob"], cam)
+        pkgs.append(pkg)
+        cams.append(cam)
+    loss = loss + 0.01 * isotropic_loss(torch.exp(pc._scaling), pc._marker)
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(d["loss"]), rtol=2e-5)
+    assert pc._marker.grad is None and not bool(d["has_grad_marker"])     # train_gaussians.py never reaches the marker
+    for k, a in names.items():
+        if not bool(d["has_grad_" + k]):
+            continue
+        got = getattr(pc, a).grad
+        assert got is not None, k
+        if d["grad_" + k].size == 0:
+            assert got.numel() == 0
+            continue
+        assert_grad_close(k, got.cpu().numpy(), d["grad_" + k])
+    for k in range(5):
+        assert np.array_equal(pkgs[k]["radii"].cpu().numpy(), d[f"view{k}_radii"])
+        assert_grad_close(f"viewspace {k}", pkgs[k]["viewspace_points"].grad.cpu().numpy(), d[f"view{k}_viewspace_grad"])
+        ge = np.array([float(cams[k].exposure_a.grad), float(cams[k].exposure_b.grad)])
+        np.testing.assert_allclose(ge, d[f"view{k}_exposure_grad"], rtol=2e-3, atol=1e-6)
