@@ -99,10 +99,10 @@ def activate_pack(xyz, f_dc, f_rest, scaling, rotation, opacity, extra=None, cam
     Returns (scales, rotations, opacities, colors[P,3+E])."""
     if active_sh_degree < 0 or active_sh_degree > 3:
         raise RuntimeError("activate_pack: SH degree must be 0..3")
-    if f_rest is not None and f_rest.shape[1] == 0:
-        f_rest_arg = None
-    else:
-        f_rest_arg = f_rest
+    # an empty f_rest ([P,0,3], SplatLoc's SH degree 0) stays an autograd input: it receives an empty gradient,
+    # as it does from the reference's `torch.cat((features_dc, features_rest), dim=1)` (gaussian_model.py:96-100),
+    # so torch.optim.Adam creates (empty) state for the group exactly as in the reference
+    f_rest_arg = f_rest
     K = 1 + (0 if f_rest_arg is None else int(f_rest_arg.shape[1]))
     if (active_sh_degree + 1) ** 2 > K:
         raise RuntimeError("activate_pack: not enough SH coefficients for the active degree")

@@ -6,6 +6,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
