@@ -198,6 +198,16 @@ ImgView img_view(void* base, int32_t W, int32_t H)
     return v;
 }
 
+// The compositing kernels index feature / accumulator rows with 24-bit x 24-bit multiplies (one
+// full-rate instruction instead of a 64-bit multiply-add pair per address): Gaussian ids must fit 24
+// bits and a row's float offset 32 bits.  16.7 M Gaussians per scene — SplatLoc maps hold < 1 M.
+static int check_row_index_range(int32_t P, int32_t C)
+{
+    const uint64_t row = (uint64_t)(gacc_row_floats(C) > padded_channels(C) ? gacc_row_floats(C) : padded_channels(C));
+    if ((uint64_t)P > (1ull << 24) || (uint64_t)P * row >= (1ull << 32)) return SPLATRASTER_ERR_UNSUPPORTED;
+    return SPLATRASTER_OK;
+}
+
 static int check_settings(const splatraster_settings* s)
 {
     if (!s) return SPLATRASTER_ERR_BAD_ARG;
@@ -339,6 +349,8 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
     if (P < 0 || R < 0 || !image || !out_color || !out_depth || !out_alpha) return SPLATRASTER_ERR_BAD_ARG;
     if (s->bg_channels > 0 && !bg) return SPLATRASTER_ERR_BAD_ARG;
     if (P > 0 && (!geometry || !binning)) return SPLATRASTER_ERR_BAD_ARG;
+    st = check_row_index_range(P, s->channels);
+    if (st) return st;
     st = lookback_error_poll();
     if (st) return st;
     if (R > 0 && !binning) return SPLATRASTER_ERR_BAD_ARG;
@@ -422,6 +434,8 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     if (!shs && (!colors_precomp || !dL_dcolors)) return SPLATRASTER_ERR_BAD_ARG;
     if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
         return SPLATRASTER_ERR_BAD_ARG;
+    st = check_row_index_range(P, s->channels);
+    if (st) return st;
     st = lookback_error_poll();   // this frame's tile sort (when the GPU got that far) or an earlier call
     if (st) return st;
     const int W = s->image_width, H = s->image_height;

@@ -36,9 +36,12 @@
 #define SR_ABLATE_HOT(x) (x)
 #endif
 #ifndef SR_STAGE_UNROLL
-#define SR_STAGE_UNROLL 2  // gather iterations in flight together while staging feature rows
+#define SR_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2, 5 cameras: 2: 0.947, 3: 0.914 ms)
 #endif
 
+#ifndef SR_BWD_LDSDMA
+#define SR_BWD_LDSDMA 0  // 1 = stage the feature rows with LDS-DMA loads (A/B in DESIGN.md)
+#endif
 #ifndef SR_BWD_MINW
 #define SR_BWD_MINW 4  // waves per SIMD the register allocator must allow (A/B on S2: 1.035 vs 1.07 ms at 3)
 #endif
@@ -216,7 +219,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         for (int r = 0; r < 4; ++r) {
             const int gs = 4 * (lane >> 4) + r;
             if (gs < count) {
-                float* dst = gacc + (size_t)s_gid[gs] * GROW + c0 + (lane & 15);
+                float* dst = gacc + (size_t)(__umul24(s_gid[gs], (uint32_t)GROW) + (uint32_t)(c0 + (lane & 15)));
 #if SR_BWD_ABLATE_ATOMIC
                 asm volatile("" ::"v"(dst), "v"(D0[r]), "v"(D1[r]));
 #else
@@ -288,12 +291,29 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             first_round = false;
             __builtin_amdgcn_wave_barrier();
             // 16-byte pieces of the 16-byte-aligned padded rows
+#if SR_BWD_LDSDMA
+            // LDS-DMA (global_load_lds_dwordx4): lane l of issue k lands at s_feat + 16 (64 k + l) without passing
+            // through VGPRs, so EVERY piece of the round is in flight at once (one memory latency per round
+            // instead of one per SR_STAGE_UNROLL pieces)
+#pragma unroll
+            for (int k = 0; k < (FS * PPR + WAVE - 1) / WAVE; ++k) {
+                const int e = k * WAVE + lane;
+                if (k * WAVE < ncand * PPR && e < ncand * PPR) {
+                    const int row = e / PPR, pc = e - row * PPR;
+                    __builtin_amdgcn_global_load_lds(&featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))],
+                                                     reinterpret_cast<float4*>(s_feat) + k * WAVE, 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#else
 #pragma unroll SR_STAGE_UNROLL
             for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
-                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)SR_ABLATE_HOT(s_cgid[row]) * CP4 + (c0 >> 2) + pc];
+                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];
             }
             __builtin_amdgcn_wave_barrier();
+#endif
 #ifdef SR_BWD_PROFILE
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
@@ -332,19 +352,18 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     }
                 }
                 // ---- Gaussian 0, then Gaussian 1 (sequential in T and S) ----
+                // Branch-free: a miss has w = 0 (S unchanged), dA = 0 and keeps T.  1 / (1 - alpha) is the
+                // hardware reciprocal (1 ulp; alpha <= 0.99 keeps the argument >= 0.01): the correctly
+                // rounded __frcp_rn expanded to a 10-instruction division per Gaussian.  T itself follows
+                // the forward's two-rounding transmit() bit for bit.
                 const float w0 = hit0 ? al0 * T : 0.0f;
-                float dA0 = 0.0f, dA1 = 0.0f;
-                if (hit0) {
-                    S -= w0 * qd0;
-                    dA0 = T * qd0 - S * __frcp_rn(1.0f - al0);
-                    T = transmit(T, al0);
-                }
+                S = fmaf(-w0, qd0, S);
+                const float dA0 = hit0 ? fmaf(T, qd0, -S * __builtin_amdgcn_rcpf(1.0f - al0)) : 0.0f;
+                T = hit0 ? transmit(T, al0) : T;
                 const float w1 = hit1 ? al1 * T : 0.0f;
-                if (hit1) {
-                    S -= w1 * qd1;
-                    dA1 = T * qd1 - S * __frcp_rn(1.0f - al1);
-                    T = transmit(T, al1);
-                }
+                S = fmaf(-w1, qd1, S);
+                const float dA1 = hit1 ? fmaf(T, qd1, -S * __builtin_amdgcn_rcpf(1.0f - al1)) : 0.0f;
+                T = hit1 ? transmit(T, al1) : T;
                 float red[2 * KV];
 #pragma unroll
                 for (int ch = 0; ch < NV; ++ch) {
@@ -384,7 +403,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 BP_ADD(4, tp3 - tp2);
                 const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];
                 const uint32_t gi = slot_second ? gi1 : gi0;
-                float* dst = gacc + (size_t)gi * GROW + slot_off;
+                float* dst = gacc + (size_t)(__umul24(gi, (uint32_t)GROW) + (uint32_t)slot_off);   // gi < 2^24 (checked on the host)
 #if SR_BWD_ABLATE_ATOMIC
                 asm volatile("" ::"v"(dst), "v"(outv));
 #else

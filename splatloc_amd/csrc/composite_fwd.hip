@@ -36,6 +36,9 @@
 #define SR_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2: 1: 0.429, 2: 0.456, 3: 0.416, 5: 0.478 ms)
 #endif
 
+#ifndef SR_FWD_LDSDMA
+#define SR_FWD_LDSDMA 0  // 1 = stage the feature rows with LDS-DMA loads
+#endif
 #ifndef SR_FWD_MINW
 #define SR_FWD_MINW 4  // waves per SIMD the register allocator must allow
 #endif
@@ -177,12 +180,26 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
             if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid;
             __builtin_amdgcn_wave_barrier();
             // 16-byte pieces of the 16-byte-aligned padded rows
+#if SR_FWD_LDSDMA
+#pragma unroll
+            for (int k = 0; k < (FS * PPR + WAVE - 1) / WAVE; ++k) {
+                const int e = k * WAVE + lane;
+                if (k * WAVE < ncand * PPR && e < ncand * PPR) {
+                    const int row = e / PPR, pc = e - row * PPR;
+                    __builtin_amdgcn_global_load_lds(&featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))],
+                                                     reinterpret_cast<float4*>(s_feat) + k * WAVE, 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#else
 #pragma unroll SR_STAGE_UNROLL
             for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
-                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)SR_ABLATE_HOT(s_cgid[row]) * CP4 + (c0 >> 2) + pc];
+                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];   // ids < 2^24: checked on the host
             }
             __builtin_amdgcn_wave_barrier();
+#endif
             // ---- composite them front to back, two at a time ----
 #pragma unroll 1
             for (int slot = 0; slot < ncand; slot += 2) {
