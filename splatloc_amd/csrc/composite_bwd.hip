@@ -35,6 +35,11 @@
 #else
 #define SR_ABLATE_HOT(x) (x)
 #endif
+#ifdef SR_ABLATE_NO_STAGE  // timing experiment only: the feature gather is skipped (wrong results)
+#define SR_ABLATE_STAGE_N(n) 0
+#else
+#define SR_ABLATE_STAGE_N(n) (n)
+#endif
 #ifndef SR_STAGE_UNROLL
 #define SR_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2, 5 cameras: 2: 0.947, 3: 0.914 ms)
 #endif
@@ -308,7 +313,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             __builtin_amdgcn_wave_barrier();
 #else
 #pragma unroll SR_STAGE_UNROLL
-            for (int e = lane; e < ncand * PPR; e += WAVE) {
+            for (int e = lane; e < SR_ABLATE_STAGE_N(ncand * PPR); e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
                 reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];
             }
