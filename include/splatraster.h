@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 3
+#define SPLATRASTER_ABI_VERSION 4
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
@@ -391,6 +391,13 @@ int splatraster_poll_errors(void);
 /* test hooks: spin bound of the look-backs (default 1 << 24; 0 makes every block that has to wait at
  * all report), and y[i] = the device's 2^x (the alpha arithmetic shared with the CPU oracle). */
 int splatraster_debug_set_spin_limit(uint32_t limit);
+/* Deterministic-sum debug mode of the backward (process-wide switch, default off).  The compositing
+ * backward sums per-(wave, Gaussian) partials into per-Gaussian rows with float atomics, whose arrival
+ * order — and therefore the last bits of every gradient — changes from run to run.  With the switch on,
+ * each partial is converted to 2^-40 fixed point and accumulated with 64-bit INTEGER atomics (associative:
+ * the totals are bit-reproducible; range +-8.4e6, resolution 9.1e-13), then converted back.  ~10 % slower;
+ * meant for regression hunting and strict tests (tests/test_gpu_parity.py). */
+int splatraster_debug_set_deterministic(int on);
 int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
 
 const char* splatraster_error_string(int status);

@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 3   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 4   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 _ERR_NAMES = {1: "bad argument", 2: "HIP runtime error", 3: "unsupported configuration",
@@ -104,6 +104,7 @@ SYMBOLS = {
     "splatraster_abi_version": (C.c_int, []),
     "splatraster_poll_errors": (C.c_int, []),
     "splatraster_debug_set_spin_limit": (C.c_int, [C.c_uint32]),
+    "splatraster_debug_set_deterministic": (C.c_int, [C.c_int]),
     "splatraster_debug_exp2": (C.c_int, [_i64, _vp, _vp, _vp]),
 }
 
@@ -174,3 +175,8 @@ def timing_collect() -> dict:
     cnt = (C.c_int64 * n)()
     check(load().splatraster_timing_collect(ms, cnt), "timing_collect")
     return {s: (ms[i], cnt[i]) for i, s in enumerate(STAGES)}
+
+
+def set_deterministic(on: bool) -> None:
+    """Deterministic-sum debug mode of the backward (bit-reproducible gradients; see splatraster.h)."""
+    check(load().splatraster_debug_set_deterministic(int(bool(on))), "set_deterministic")

@@ -11,6 +11,7 @@
 namespace sr {
 
 static thread_local std::string g_last_error;
+static int g_deterministic = 0;   // splatraster_debug_set_deterministic
 
 void set_hip_error(hipError_t e, const char* what)
 {
@@ -147,7 +148,7 @@ GeomView geom_view(void* base, int32_t P)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, gacc64, bytes;
 };
 static BinLayout bin_layout(int32_t P, int64_t R, int32_t W, int32_t H, int32_t C)
 {
@@ -167,6 +168,8 @@ static BinLayout bin_layout(int32_t P, int64_t R, int32_t W, int32_t H, int32_t 
     // padded feature table only when the rows are not already 16-byte aligned
     L.featp = take((C % 4) ? (size_t)(P > 0 ? P : 1) * padded_channels(C) * sizeof(float) : 16);
     L.gacc = take((size_t)(P > 0 ? P : 1) * gacc_row_floats(C) * sizeof(float));
+    // reserved for the deterministic debug mode (untouched otherwise: address space, not bandwidth)
+    L.gacc64 = take((size_t)(P > 0 ? P : 1) * gacc_row_floats(C) * sizeof(long long));
     L.bytes = o;
     return L;
 }
@@ -186,6 +189,7 @@ BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H, int32_t
     v.imask = reinterpret_cast<uint8_t*>(b + L.imask);
     v.featp = reinterpret_cast<float*>(b + L.featp);
     v.gacc = reinterpret_cast<float*>(b + L.gacc);
+    v.gacc64 = reinterpret_cast<long long*>(b + L.gacc64);
     return v;
 }
 
@@ -446,13 +450,22 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     const float* feat = shs ? g.rgb : colors_precomp;
     // zero the accumulator rows (outside the stage bracket: the stage is the kernel alone, so its
     // figure can be held against the per-kernel rocprofv3 average)
-    SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * (size_t)gacc_row_floats(C) * (size_t)P, stream));
+    const size_t gacc_n = (size_t)gacc_row_floats(C) * (size_t)P;
+    const bool det = g_deterministic != 0;
+    if (det)
+        SR_HIP_CHECK(hipMemsetAsync(b.gacc64, 0, sizeof(long long) * gacc_n, stream));
+    else
+        SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * gacc_n, stream));
     {
         StageTimer t(SPLATRASTER_STAGE_COMPOSITE_BWD, stream);
         st = launch_composite_bwd(*s, P, R, g, b, im, (C % 4) ? b.featp : feat, C, out_color, out_depth, dL_dout_color,
-                                  dL_dout_depth, dL_dout_alpha, b.gacc, stream);
+                                  dL_dout_depth, dL_dout_alpha, b.gacc, det ? b.gacc64 : nullptr, stream);
     }
     if (st) return st;
+    if (det) {
+        st = launch_fixed_to_float((int64_t)gacc_n, b.gacc64, b.gacc, stream);
+        if (st) return st;
+    }
     StageTimer t(SPLATRASTER_STAGE_PREPROCESS_BWD, stream);
     return launch_preprocess_bwd(*s, P, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                  campos, radii, g.clamped, g.rec, b.gacc, C, shs ? nullptr : dL_dcolors, dL_dmeans3D,
@@ -473,6 +486,12 @@ int splatraster_mark_visible(int32_t P, const float* means3D, const float* viewm
 }
 
 int splatraster_poll_errors(void) { return lookback_error_poll(); }
+
+int splatraster_debug_set_deterministic(int on)
+{
+    g_deterministic = on ? 1 : 0;
+    return SPLATRASTER_OK;
+}
 
 int splatraster_debug_set_spin_limit(uint32_t limit)
 {

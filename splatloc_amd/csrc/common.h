@@ -76,6 +76,7 @@ struct BinView {
     uint8_t* imask;       // [R] bit q: the Gaussian may reach quadrant q of its tile
     float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows)
     float* gacc;          // [P * gacc_row_floats(C)] backward gradient accumulator rows
+    long long* gacc64;    // same shape, 2^-40 fixed point: the deterministic debug mode's accumulator
 };
 struct ImgView {
     float* final_T;
@@ -140,7 +141,9 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, co
                          const float* dL_ddepth, const float* dL_dalpha,
                          float* gacc /*[P, gacc_row_floats(C)]: dL/dfeature | moments sum E dx, E dy, E dx^2,
                                       E dx dy, E dy^2, E, w g_D*/,
+                         long long* gacc64 /*non-NULL: deterministic fixed-point accumulation into this buffer*/,
                          hipStream_t stream);
+int launch_fixed_to_float(int64_t n, const long long* src, float* dst, hipStream_t stream);
 
 int launch_activate_fwd(int32_t P, int32_t K, int32_t deg, int32_t SC, int32_t E, const float* xyz,
                         const float* f_dc, const float* f_rest, const float* scaling, const float* rotation,

@@ -93,7 +93,22 @@ struct BwdCfg {
     static constexpr int WS = 17;              // LDS row stride of the weight panel [64 pix][GROUP]
 };
 
-template <int NC>
+// Gradient accumulation.  Normal mode: float atomics (memory-side adds; the order in which the quadrant-waves
+// of different tiles reach a Gaussian's row varies from run to run, so sums differ in the last bits).
+// DET (splatraster_debug_set_deterministic): every wave-level partial — itself computed in a fixed order — is
+// converted to 2^-40 fixed point and added with a 64-bit INTEGER atomic: integer addition is associative, so
+// the totals are bit-reproducible whatever the arrival order (range +-8.4e6, resolution 9.1e-13).
+constexpr float DET_SCALE = 1099511627776.0f;   // 2^40
+template <bool DET>
+__device__ __forceinline__ void acc_add(float* gacc, long long* gacc64, size_t idx, float v)
+{
+    if (DET)
+        atomicAdd(reinterpret_cast<unsigned long long*>(gacc64) + idx, (unsigned long long)__float2ll_rn(v * DET_SCALE));
+    else
+        atomicAdd(gacc + idx, v);
+}
+
+template <int NC, bool DET>
 __global__ void __launch_bounds__(WAVE, SR_BWD_MINW)
 composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass, int tiles,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -103,7 +118,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                      const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                      const float* __restrict__ dL_dalpha, float* __restrict__ gacc /*[P, GROW]*/, int GROW,
-                     int MO)
+                     int MO, long long* __restrict__ gacc64 /*[P, GROW] fixed point, DET only*/)
 {
     using Cfg = BwdCfg<NC>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
@@ -224,12 +239,12 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         for (int r = 0; r < 4; ++r) {
             const int gs = 4 * (lane >> 4) + r;
             if (gs < count) {
-                float* dst = gacc + (size_t)(__umul24(s_gid[gs], (uint32_t)GROW) + (uint32_t)(c0 + (lane & 15)));
+                const size_t di = (size_t)(__umul24(s_gid[gs], (uint32_t)GROW) + (uint32_t)(c0 + (lane & 15)));
 #if SR_BWD_ABLATE_ATOMIC
-                asm volatile("" ::"v"(dst), "v"(D0[r]), "v"(D1[r]));
+                asm volatile("" ::"v"(di), "v"(D0[r]), "v"(D1[r]));
 #else
-                atomicAdd(dst, D0[r]);
-                atomicAdd(dst + 16, D1[r]);
+                acc_add<DET>(gacc, gacc64, di, D0[r]);
+                acc_add<DET>(gacc, gacc64, di + 16, D1[r]);
 #endif
             }
         }
@@ -408,11 +423,11 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 BP_ADD(4, tp3 - tp2);
                 const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];
                 const uint32_t gi = slot_second ? gi1 : gi0;
-                float* dst = gacc + (size_t)(__umul24(gi, (uint32_t)GROW) + (uint32_t)slot_off);   // gi < 2^24 (checked on the host)
+                const size_t di = (size_t)(__umul24(gi, (uint32_t)GROW) + (uint32_t)slot_off);   // gi < 2^24 (checked on the host)
 #if SR_BWD_ABLATE_ATOMIC
-                asm volatile("" ::"v"(dst), "v"(outv));
+                asm volatile("" ::"v"(di), "v"(outv));
 #else
-                if (slot_ok && (has1 || !slot_second)) atomicAdd(dst, outv);
+                if (slot_ok && (has1 || !slot_second)) acc_add<DET>(gacc, gacc64, di, outv);
 #endif
                 if (MFMA) {
                     // park the weights (0 for pixels that miss); a pair never straddles a flush
@@ -506,20 +521,21 @@ extern "C" int splatraster_debug_bwd_prof(unsigned long long* out, int reset)
 #endif
 
 
-template <int NC>
+template <int NC, bool DET>
 static int launch_one_bwd(const splatraster_settings& s, int c0, int first, const GeomView& g,
                           const BinView& b, const ImgView& im, const float* feat, int feat_stride,
                           const float* out_color, const float* out_depth, const float* dL_dcolor,
-                          const float* dL_ddepth, const float* dL_dalpha, float* gacc, hipStream_t stream)
+                          const float* dL_ddepth, const float* dL_dalpha, float* gacc, long long* gacc64,
+                          hipStream_t stream)
 {
     (void)g;
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
     const int tiles = gx * gy;
     const unsigned blocks = (unsigned)((tiles + 7) / 8) * 32u;  // 4 quadrants per tile, tiles padded to 8
-    hipLaunchKernelGGL(composite_bwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
+    hipLaunchKernelGGL((composite_bwd_kernel<NC, DET>), dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
                        s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, b.ranges,
                        b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), out_color, out_depth, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth,
-                       dL_dalpha, gacc, gacc_row_floats(s.channels), gacc_moment_offset(s.channels));
+                       dL_dalpha, gacc, gacc_row_floats(s.channels), gacc_moment_offset(s.channels), gacc64);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
@@ -527,14 +543,17 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
 int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g,
                          const BinView& b, const ImgView& im, const float* feat, int feat_stride,
                          const float* out_color, const float* out_depth, const float* dL_dcolor,
-                         const float* dL_ddepth, const float* dL_dalpha, float* gacc, hipStream_t stream)
+                         const float* dL_ddepth, const float* dL_dalpha, float* gacc, long long* gacc64,
+                         hipStream_t stream)
 {
     (void)P;
     if (R == 0) return SPLATRASTER_OK;
+    const bool det = gacc64 != nullptr;
     const int C = s.channels;
-#define SR_BWD_ARGS g, b, im, feat, feat_stride, out_color, out_depth, dL_dcolor, dL_ddepth, dL_dalpha, gacc, stream
+#define SR_BWD_ARGS g, b, im, feat, feat_stride, out_color, out_depth, dL_dcolor, dL_ddepth, dL_dalpha, gacc, gacc64, stream
+#define SR_BWD_ONE(N, c0_, first_) (det ? launch_one_bwd<N, true>(s, c0_, first_, SR_BWD_ARGS) : launch_one_bwd<N, false>(s, c0_, first_, SR_BWD_ARGS))
 #define SR_BWD_CASE(N) \
-    case N: return launch_one_bwd<N>(s, 0, 1, SR_BWD_ARGS);
+    case N: return SR_BWD_ONE(N, 0, 1);
     switch (C) {
         SR_BWD_CASE(1) SR_BWD_CASE(2) SR_BWD_CASE(3) SR_BWD_CASE(4) SR_BWD_CASE(8) SR_BWD_CASE(16)
         SR_BWD_CASE(32) SR_BWD_CASE(35)
@@ -544,15 +563,16 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, co
     int c0 = 0, first = 1, st = SPLATRASTER_OK;
     while (c0 < C && st == SPLATRASTER_OK) {
         const int left = C - c0;
-        if (left >= 32) { st = launch_one_bwd<32>(s, c0, first, SR_BWD_ARGS); c0 += 32; }
-        else if (left >= 16) { st = launch_one_bwd<16>(s, c0, first, SR_BWD_ARGS); c0 += 16; }
-        else if (left >= 8) { st = launch_one_bwd<8>(s, c0, first, SR_BWD_ARGS); c0 += 8; }
-        else if (left >= 4) { st = launch_one_bwd<4>(s, c0, first, SR_BWD_ARGS); c0 += 4; }
-        else if (left == 3) { st = launch_one_bwd<3>(s, c0, first, SR_BWD_ARGS); c0 += 3; }
-        else if (left == 2) { st = launch_one_bwd<2>(s, c0, first, SR_BWD_ARGS); c0 += 2; }
-        else { st = launch_one_bwd<1>(s, c0, first, SR_BWD_ARGS); c0 += 1; }
+        if (left >= 32) { st = SR_BWD_ONE(32, c0, first); c0 += 32; }
+        else if (left >= 16) { st = SR_BWD_ONE(16, c0, first); c0 += 16; }
+        else if (left >= 8) { st = SR_BWD_ONE(8, c0, first); c0 += 8; }
+        else if (left >= 4) { st = SR_BWD_ONE(4, c0, first); c0 += 4; }
+        else if (left == 3) { st = SR_BWD_ONE(3, c0, first); c0 += 3; }
+        else if (left == 2) { st = SR_BWD_ONE(2, c0, first); c0 += 2; }
+        else { st = SR_BWD_ONE(1, c0, first); c0 += 1; }
         first = 0;
     }
+#undef SR_BWD_ONE
 #undef SR_BWD_ARGS
     return st;
 }

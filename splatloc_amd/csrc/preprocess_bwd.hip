@@ -338,6 +338,22 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
 
 // dL/dcolors [P, C] out of the 64-byte aligned accumulator rows: one thread per element,
 // contiguous reads inside a row, fully coalesced writes.
+// deterministic debug mode: the fixed-point accumulator rows -> the float rows the kernels below read
+__global__ void __launch_bounds__(256)
+fixed_to_float_kernel(int64_t n, const long long* __restrict__ src, float* __restrict__ dst)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) dst[e] = (float)((double)src[e] * (1.0 / 1099511627776.0));
+}
+
+int launch_fixed_to_float(int64_t n, const long long* src, float* dst, hipStream_t stream)
+{
+    if (n <= 0) return SPLATRASTER_OK;
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, src, dst);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
 __global__ void __launch_bounds__(256)
 gather_dcolors_kernel(int64_t n, int C, int GROW, const float* __restrict__ gacc, float* __restrict__ dL_dcolors)
 {

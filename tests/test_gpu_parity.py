@@ -382,3 +382,37 @@ def test_device_exp2_is_the_oracles_exp2_bit_for_bit():
     ref = oracle.exp2(x)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), \
         f"{(got.view(np.uint32) != ref.view(np.uint32)).sum()} of {x.size} values differ"
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(P=6_000, W=320, H=240, C=4, seed=81, scale_median=0.03),     # reference channel layout (VALU reductions)
+    dict(P=4_000, W=333, H=201, C=35, seed=82, scale_median=0.03),    # matrix-pipe reductions + butterfly
+])
+def test_deterministic_sum_mode_is_bit_reproducible_and_strict(cfg):
+    """Deterministic-sum debug mode (splatraster_debug_set_deterministic): the per-Gaussian gradient rows are summed
+    with 64-bit integer atomics in 2^-40 fixed point, so two runs agree BIT FOR BIT (the float-atomic mode agrees
+    only to rounding), and the gradients meet a 20x tighter bar against the oracle's double-precision sums."""
+    from splatloc_amd import _native
+    sc = make_scene(**cfg)
+    b = oracle_backward(oracle_forward(sc), sc)
+    _native.set_deterministic(True)
+    try:
+        runs = [HipRun(sc) for _ in range(3)]
+    finally:
+        _native.set_deterministic(False)
+    names = ["means3D", "means2D", "opacities", "colors", "scales", "rotations"]
+    for r in runs[1:]:
+        for n in names:
+            assert torch.equal(getattr(r, n).grad, getattr(runs[0], n).grad), f"{n} differs between deterministic runs"
+    run = runs[0]
+    kw = dict(rtol=1e-4, atol_scale=5e-6)
+    assert_grad_close("dL_dmeans3D", run.np(run.means3D.grad), b["dL_dmeans3D"], **kw)
+    assert_grad_close("dL_dmeans2D", run.np(run.means2D.grad), b["dL_dmeans2D"], **kw)
+    assert_grad_close("dL_dopacities", run.np(run.opacities.grad), b["dL_dopacities"], **kw)
+    assert_grad_close("dL_dcolors", run.np(run.colors.grad), b["dL_dcolors"], **kw)
+    assert_grad_close("dL_dscales", run.np(run.scales.grad), b["dL_dscales"], **kw)
+    assert_grad_close("dL_drotations", run.np(run.rotations.grad), b["dL_drotations"], **kw)
+    # and the default mode still agrees with it to rounding
+    free = HipRun(sc)
+    for n in names:
+        assert_grad_close(n, free.np(getattr(free, n).grad), run.np(getattr(run, n).grad), rtol=2e-3, atol_scale=1e-4)

@@ -11,12 +11,13 @@ from splatloc_amd import _native
 from splatloc_amd.synthetic import make_workload
 from tests.helpers import HipRun
 _native.load()
-sc = make_workload("S2")
+sc = make_workload(sys.argv[1] if len(sys.argv) > 1 else "S2")
 HipRun(sc, backward=True)
 HipRun(sc, backward=True)
 torch.cuda.synchronize()
 raw = C.CDLL(os.environ["SPLATRASTER_LIB"])
-n = 32640
+n = 4 * ((sc.camera.image_width + 15) // 16) * ((sc.camera.image_height + 15) // 16)
+n = (n + 31) // 32 * 32
 for k in ("fwd", "bwd"):
     buf = (C.c_ulonglong * (2 * n))()
     assert getattr(raw, "splatraster_debug_trace_" + k)(buf, n) == 0
