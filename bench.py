@@ -496,6 +496,8 @@ def main():
                     help="frames per optimisation step (SplatLoc.map's window_size = 5); gradients accumulate")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank renders its own window; strong = one window dealt to the ranks")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the views of a window are spread over (1 = the reference's serial loop)")
     ap.add_argument("--densify-every", type=int, default=10,
                     help="--stage map_step: densify_and_prune every N steps (the reference: 150, offset 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -570,23 +572,41 @@ def main():
     max_radii = torch.zeros(P, device=dev)
     info = {"R": [], "V": []}
 
+    side = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
+
+    def one_view(rast, g_out, record):
+        means2D = torch.zeros_like(means3D, requires_grad=True)   # per-view grad carrier (render(): screenspace_points)
+        color, depth, alpha, radii = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors,
+                                          opacities=opac, scales=scales, rotations=rots, cov3D_precomp=None)
+        if record:
+            info["R"].append(int(color.grad_fn.num_rendered))
+            info["V"].append(int((radii > 0).sum().item()))
+        if not args.fwd_only:
+            torch.autograd.backward((color, depth, alpha), g_out)
+            if world > 1:   # the step's densification statistics (train_gaussians.py:238-245)
+                add_densification_stats(means2D.grad, radii, accum, denom, max_radii)
+
     def step(record=False):
         for p in params:
             p.grad = None
         if world > 1:
             accum.zero_()
             denom.zero_()
-        for rast, g_out in views:   # every frame one forward + one backward, parameter gradients accumulate
-            means2D = torch.zeros_like(means3D, requires_grad=True)   # per-view grad carrier (render(): screenspace_points)
-            color, depth, alpha, radii = rast(means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors,
-                                              opacities=opac, scales=scales, rotations=rots, cov3D_precomp=None)
-            if record:
-                info["R"].append(int(color.grad_fn.num_rendered))
-                info["V"].append(int((radii > 0).sum().item()))
-            if not args.fwd_only:
-                torch.autograd.backward((color, depth, alpha), g_out)
-                if world > 1:   # the step's densification statistics (train_gaussians.py:238-245)
-                    add_densification_stats(means2D.grad, radii, accum, denom, max_radii)
+        if side:
+            # the views of a window are independent until their gradients are summed: view j runs on HIP stream
+            # j % K, so the latency-bound kernels of a small frame overlap with another view's (autograd runs
+            # each backward on its forward's stream and orders the accumulation into .grad)
+            main = torch.cuda.current_stream(dev)
+            for st in side:
+                st.wait_stream(main)
+            for j, (rast, g_out) in enumerate(views):
+                with torch.cuda.stream(side[j % len(side)]):
+                    one_view(rast, g_out, record)
+            for st in side:
+                main.wait_stream(st)
+        else:
+            for rast, g_out in views:   # every frame one forward + one backward, parameter gradients accumulate
+                one_view(rast, g_out, record)
         if not args.fwd_only and world > 1:
             # ONE SUM all-reduce of the accumulated parameter gradients (a rank without views in strong
             # mode contributes zeros) + the statistics every replica needs to densify identically
@@ -631,6 +651,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Secondary figure (N = 1): the same step with the window's views spread over K HIP streams
+    # (splatloc_amd.fused.render_window does this for the product path).  Not `value`: kernel durations
+    # measured under overlap are not the dominant kernel's own, so the roofline stays on the serial run.
+    multi_stream = []
+    if world == 1 and not side and not args.fwd_only and len(views) > 1:
+        for K in (2, 4):
+            side[:] = [torch.cuda.Stream(device=dev) for _ in range(K)]
+            for _ in range(2):
+                step()
+            barrier()
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            el = time.perf_counter() - ts
+            multi_stream.append({"streams": K, "value": round(frames_per_step * args.steps / el, 3),
+                                 "ms_per_step": round(1e3 * el / args.steps, 4)})
+        side[:] = []
+
     if rank == 0:
         Rs, Vs = info["R"], info["V"]
         R = int(round(sum(Rs) / max(len(Rs), 1)))
@@ -670,6 +709,7 @@ def main():
                        "tile_instances_R_per_view": Rs, "visible_gaussians_V_per_view": Vs,
                        "tile_instances_R": R, "visible_gaussians_V": V,
                        "frames_per_step": frames_per_step, "views_on_rank0_per_step": len(views),
+                       "hip_streams_per_window": max(args.streams, 1),
                        "parallelism": f"frame-parallel dp{world}, scene replica per GPU"
                                       + (", one RCCL SUM all-reduce of the accumulated parameter grads + densification-"
                                          "statistics sync per step" if world > 1 else "")},
@@ -682,6 +722,7 @@ def main():
                           "frac_of_peak": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5),
                           "ms_per_frame": round(ms_per_step / max(len(views), 1), 4)},
             "frame_valu": prof.get("valu.json"),
+            "multi_stream": multi_stream or None,
             "stages": per_stage,
             "stages_note": f"per-stage table from {BREAKDOWN_STEPS} untimed steps with every stage bracketed by HIP "
                            f"events; only '{dom}' is bracketed inside the timed region. lineage_bytes = SURVEY 8d's "

@@ -179,3 +179,49 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     return {"render": rendered_image[:3, :, :], "kp_prob": rendered_image[-1, :, :],
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
             "depth": depth, "opacity": alpha}
+
+
+_WINDOW_STREAMS: dict = {}
+
+
+def window_streams(device, n: int):
+    """`n` HIP streams (cached per device) for render_window."""
+    key = (torch.device(device).index, n)
+    if key not in _WINDOW_STREAMS:
+        _WINDOW_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _WINDOW_STREAMS[key]
+
+
+def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, streams: int = 2, per_view=None):
+    """The render loop of one optimisation window (`for cam_idx in ...: render_pkg = render(viewpoint, ...)`,
+    train_gaussians.py:195-219) with view k enqueued on HIP stream k % `streams`.
+
+    The views of a window are independent until their losses are summed, and at SplatLoc's own frame size
+    (640x480, C = 4) one frame's kernels leave most of the MI355X idle (a 1200-tile frame is 4800 waves for
+    8192 wave slots; the kernel lasts as long as its longest list).  Spreading the views over a few streams
+    lets another view's kernels fill the machine: +30 % frames/s at 640x480 with 2 streams, +7 % at 1080p
+    (DESIGN.md).  `per_view(k, viewpoint, pkg)` — e.g. the view's loss — runs on the view's stream as
+    well; its return values are collected.  Autograd replays every backward on its forward's stream and
+    serialises the accumulation into the shared parameters' .grad, so `loss.backward()` needs no change.
+    Returns (pkgs, per_view results).  streams <= 1 is the reference's serial loop."""
+    viewpoints = list(viewpoints)
+    pkgs, extra = [], []
+    dev = pc._xyz.device
+    if streams <= 1 or len(viewpoints) <= 1:
+        for k, vp in enumerate(viewpoints):
+            pkg = render(vp, pc, pipe, bg_color, scaling_modifier)
+            pkgs.append(pkg)
+            extra.append(per_view(k, vp, pkg) if per_view is not None else None)
+        return pkgs, extra
+    main = torch.cuda.current_stream(dev)
+    side = window_streams(dev, min(streams, len(viewpoints)))
+    for st in side:
+        st.wait_stream(main)          # the parameters (and whatever else main produced) are ready
+    for k, vp in enumerate(viewpoints):
+        with torch.cuda.stream(side[k % len(side)]):
+            pkg = render(vp, pc, pipe, bg_color, scaling_modifier)
+            pkgs.append(pkg)
+            extra.append(per_view(k, vp, pkg) if per_view is not None else None)
+    for st in side:
+        main.wait_stream(st)          # join: everything above is visible to the caller's stream
+    return pkgs, extra

@@ -227,3 +227,53 @@ def test_map_shaped_step_matches_reference_recording(golden_dir):
         assert_grad_close(f"viewspace {k}", pkgs[k]["viewspace_points"].grad.cpu().numpy(), d[f"view{k}_viewspace_grad"])
         ge = np.array([float(cams[k].exposure_a.grad), float(cams[k].exposure_b.grad)])
         np.testing.assert_allclose(ge, d[f"view{k}_exposure_grad"], rtol=2e-3, atol=1e-6)
+
+
+def test_render_window_streams_match_serial_loop(golden_dir):
+    """render_window on 2 / 3 HIP streams == the serial loop of render() calls: same images, and the same parameter
+    gradients after ONE backward of the summed per-view losses (autograd replays each view's backward on its
+    forward's stream).  Inputs: the reference-recorded map() step (tests/golden/map_step.npz)."""
+    import types
+    from splatloc_amd.camera import PinholeCamera
+    from splatloc_amd.fused import render_window
+    from splatloc_amd.losses import mapping_loss
+    from tests.helpers import assert_grad_close
+    d = np.load(os.path.join(golden_dir, "map_step.npz"))
+    dev = torch.device("cuda:0")
+    fx, fy, cx, cy, W, H = (float(v) for v in d["intr"][:6])
+    W, H = int(W), int(H)
+    names = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+             "marker": "_marker", "kp_score": "_kp_score", "scaling": "_scaling", "rotation": "_rotation"}
+    pipe = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
+    cfg = {"Training": {"primitive_reg": True, "rgb_boundary_threshold": 0.01}}
+    bg = torch.zeros(3, device=dev)
+    results = {}
+    for streams in (1, 2, 3):
+        pc = types.SimpleNamespace(active_sh_degree=0, max_sh_degree=0)
+        for k, a in names.items():
+            setattr(pc, a, torch.from_numpy(d["raw_" + k]).to(dev).requires_grad_(True))
+        cams = []
+        for k in range(5):
+            T = torch.from_numpy(d[f"view{k}_T"])
+            cam = PinholeCamera(W, H, fx, fy, cx, cy, T[:3, :3], T[:3, 3]).to(dev)
+            cam.original_image = torch.from_numpy(d[f"view{k}_color"]).to(dev)
+            cam.depth = d[f"view{k}_depth"]
+            cam.kp_score = torch.from_numpy(d[f"view{k}_kp"]).to(dev)
+            cam.exposure_a = torch.zeros(1, device=dev, requires_grad=True)
+            cam.exposure_b = torch.zeros(1, device=dev, requires_grad=True)
+            cams.append(cam)
+        for rep in range(3):      # several windows back to back: stream reuse across windows
+            for a in names.values():
+                getattr(pc, a).grad = None
+            pkgs, losses = render_window(cams, pc, pipe, bg, streams=streams,
+                                         per_view=lambda k, vp, pkg: mapping_loss(cfg, pkg["render"], pkg["depth"], pkg["kp_prob"], vp))
+            sum(losses).backward()
+        torch.cuda.synchronize()
+        results[streams] = (torch.stack([p["render"] for p in pkgs]).cpu(), [p["radii"].cpu() for p in pkgs],
+                            {a: getattr(pc, a).grad.cpu().numpy() for a in names.values() if getattr(pc, a).grad is not None
+                             and getattr(pc, a).grad.numel()})
+    for streams in (2, 3):
+        assert torch.equal(results[streams][0], results[1][0])               # forward: bit-identical
+        assert all(torch.equal(a, b) for a, b in zip(results[streams][1], results[1][1]))
+        for a, g in results[1][2].items():
+            assert_grad_close(a, results[streams][2][a], g)                   # float atomics reorder sums
