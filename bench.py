@@ -500,6 +500,7 @@ def main():
                     help="HIP streams the views of a window are spread over (1 = the reference's serial loop)")
     ap.add_argument("--densify-every", type=int, default=10,
                     help="--stage map_step: densify_and_prune every N steps (the reference: 150, offset 50)")
+    ap.add_argument("--no-multi-stream", action="store_true", help="skip the secondary multi-stream legs (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
     ap.add_argument("--stage", default="raster", choices=["raster", "activations", "loss", "map_step"],
@@ -655,7 +656,7 @@ def main():
     # (splatloc_amd.fused.render_window does this for the product path).  Not `value`: kernel durations
     # measured under overlap are not the dominant kernel's own, so the roofline stays on the serial run.
     multi_stream = []
-    if world == 1 and not side and not args.fwd_only and len(views) > 1:
+    if world == 1 and not side and not args.fwd_only and len(views) > 1 and not args.no_multi_stream:
         for K in (2, 4):
             side[:] = [torch.cuda.Stream(device=dev) for _ in range(K)]
             for _ in range(2):

@@ -11,7 +11,7 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
             "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT GRBM_GUI_ACTIVE" \
             "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_WAIT_INST_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_IFETCH SQ_WAVE32_INSTS"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $ctrs -d $OUT/pass$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $OUT/pass$i.err || tail -3 $OUT/pass$i.err
+  rocprofv3 --kernel-trace --pmc $ctrs -d $OUT/pass$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-multi-stream "$@" > /dev/null 2> $OUT/pass$i.err || tail -3 $OUT/pass$i.err
 done
 cd $R
 python3 - "$OUT" <<'PY'
