@@ -4,7 +4,7 @@ from __future__ import annotations
 import torch
 
 from . import _native
-from .rasterizer import _ptr, _require_gpu, _stream
+from .rasterizer import _ptr, _require_gpu, _stream, _on_device
 
 
 def add_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, xyz_gradient_accum: torch.Tensor,
@@ -28,7 +28,7 @@ def add_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, x
     g = viewspace_grad.detach()
     if g.dtype != torch.float32 or not g.is_contiguous() or tuple(g.shape) != (P, 3):
         g = g.to(torch.float32).reshape(P, 3).contiguous()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _native.check(_native.load().splatraster_densification_stats(
             P, _ptr(g), _ptr(radii.contiguous()), _ptr(xyz_gradient_accum), _ptr(denom), _ptr(max_radii2D),
             _stream(dev)), "densification_stats")
@@ -85,7 +85,7 @@ def densify_tensors(params: dict, exp_avg: dict, exp_avg_sq: dict, xyz_gradient_
     den = denom.to(torch.float32).contiguous()
     ws = torch.empty((lib.splatraster_densify_workspace_bytes(P),), dtype=torch.uint8, device=dev)
     new_P = C.c_int32(0)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _native.check(lib.splatraster_densify_plan(
             C.byref(src), _ptr(acc), _ptr(den), C.c_float(max_grad), C.c_float(min_opacity), C.c_float(extent),
             C.c_float(percent_dense), int(bool(max_screen_size)), int(bool(primitive_reg)), _ptr(ws), C.byref(new_P),
@@ -110,7 +110,7 @@ def densify_tensors(params: dict, exp_avg: dict, exp_avg_sq: dict, xyz_gradient_
         m_out = _model_struct(new_m, n, widths) if has else None
         v_out = _model_struct(new_v, n, widths) if has else None
         ref = lambda s: None if s is None else C.byref(s)  # noqa: E731
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _native.check(lib.splatraster_densify_apply(
                 C.byref(src), ref(m_in), ref(v_in), _ptr(noise), C.c_uint64(int(seed)), C.c_uint64(int(draw_id)),
                 _ptr(ws), n, C.byref(out), ref(m_out), ref(v_out), _ptr(srow), _ptr(skind), _stream(dev)),

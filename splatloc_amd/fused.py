@@ -24,7 +24,7 @@ from typing import Optional
 import torch
 
 from . import _native
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, _prep, _ptr, _require_gpu, _stream
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, _prep, _ptr, _require_gpu, _stream, _on_device
 
 
 class _ActivatePack(torch.autograd.Function):
@@ -49,7 +49,7 @@ class _ActivatePack(torch.autograd.Function):
         rotations = torch.empty((P, 4), **f32)
         opacities = torch.empty((P, 1), **f32)
         colors = torch.empty((P, 3 + E), **f32)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _native.check(lib.splatraster_activate_forward(
                 P, K, int(active_sh_degree), SC, E, _ptr(x), _ptr(fd), _ptr(fr), _ptr(sc), _ptr(ro), _ptr(op),
                 _ptr(ex), _ptr(cp), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(colors), _stream(dev)),
@@ -83,7 +83,7 @@ class _ActivatePack(torch.autograd.Function):
         d_ro = torch.empty((P, 4), **f32)
         d_op = torch.empty((P, 1), **f32)
         d_ex = torch.empty((P, E), **f32) if E else None
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _native.check(lib.splatraster_activate_backward(
                 P, K, deg, SC, E, _ptr(x), _ptr(fd), _ptr(fr), _ptr(sc), _ptr(ro), _ptr(op), _ptr(cp),
                 _ptr(gs), _ptr(gr), _ptr(go), _ptr(gc), _ptr(d_xyz), _ptr(d_fd),

@@ -6,6 +6,7 @@ import ctypes as C
 import torch
 
 from . import _native
+from .rasterizer import _on_device
 
 
 def distCUDA2(points: torch.Tensor) -> torch.Tensor:
@@ -20,7 +21,7 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     if N == 0:
         return out
     ws = torch.empty((lib.splatknn_workspace_bytes(N),), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _native.check(lib.splatknn_dist2(N, C.c_void_p(pts.data_ptr()), C.c_void_p(out.data_ptr()),
                                          C.c_void_p(ws.data_ptr()),
                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "distCUDA2")

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _native
-from .rasterizer import _prep, _ptr, _require_gpu, _stream
+from .rasterizer import _prep, _ptr, _require_gpu, _stream, _on_device
 
 
 class _MappingLoss(torch.autograd.Function):
@@ -43,7 +43,7 @@ class _MappingLoss(torch.autograd.Function):
         g_marker = torch.empty(tuple(marker.shape), **f32)
         out = torch.empty((4,), **f32)
         ws = torch.empty((lib.splatraster_mapping_loss_workspace_bytes(HW),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _native.check(lib.splatraster_mapping_loss(
                 HW, _ptr(im), _ptr(de), _ptr(ma), _ptr(gi), _ptr(gd), _ptr(k8), C.c_float(float(threshold)), _ptr(ex),
                 _ptr(g_image), _ptr(g_depth), _ptr(g_marker), _ptr(out), _ptr(ws), _stream(dev)), "mapping_loss")
@@ -99,7 +99,7 @@ class _RefinementLoss(torch.autograd.Function):
         g_image = torch.empty((Cn, H, W), dtype=torch.float32, device=dev)
         out = torch.empty((3,), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.splatraster_refinement_loss_workspace_bytes(Cn, H, W),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _native.check(lib.splatraster_refinement_loss(Cn, H, W, C.c_float(lam), _ptr(im), _ptr(g), _ptr(g_image),
                                                           _ptr(out), _ptr(ws), _stream(dev)), "refinement_loss")
         ctx.save_for_backward(g_image)
@@ -144,7 +144,7 @@ class _IsotropicLoss(torch.autograd.Function):
         row_grad = torch.empty((P,), dtype=torch.float32, device=dev)
         out = torch.empty((2,), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.splatraster_isotropic_loss_workspace_bytes(P),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _native.check(lib.splatraster_isotropic_loss(P, SC, _ptr(s), _ptr(mk), _ptr(row_grad), _ptr(out), _ptr(ws),
                                                          _stream(dev)), "isotropic_loss")
         ctx.save_for_backward(row_grad, out)

@@ -17,7 +17,7 @@ import ctypes as C
 import torch
 
 from . import _native
-from .rasterizer import _require_gpu, _stream
+from .rasterizer import _require_gpu, _stream, _on_device
 
 
 class Adam(torch.optim.Adam):
@@ -78,7 +78,7 @@ class Adam(torch.optim.Adam):
                 raise RuntimeError("splatloc_amd.optim.Adam: at most 16 parameters per step")
             arr = (_native.AdamGroup * len(entries))(*entries)
             thr = self.key_gate[1] if self.key_gate is not None else 0.0
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 _native.check(lib.splatraster_adam_step(len(entries), arr, C.c_double(betas[0]), C.c_double(betas[1]),
                                                         C.c_double(eps), C.c_float(thr), _stream(dev)), "adam_step")
         del keep

@@ -41,15 +41,44 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _prep(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
-    """contiguous fp32 on `device`, 16-byte aligned (kernels use 128-bit loads)."""
+    """contiguous fp32 on `device`, 16-byte aligned (kernels use 128-bit loads).  The common case — the
+    tensor already is all that — costs three attribute checks (host time is what bounds small frames)."""
     if t is None or t.numel() == 0:
         return None
+    if t.dtype is torch.float32 and t.device == device and t.is_contiguous() and not (t.data_ptr() & 15):
+        return t.detach() if t.requires_grad else t
     t = t.detach()
     if t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
         t = t.to(device=device, dtype=torch.float32).contiguous()
     if t.data_ptr() % 16:
         t = t.clone()
     return t
+
+
+_EMPTY: dict = {}
+
+
+def _empty(device) -> torch.Tensor:
+    """one shared zero-element placeholder per device for the `None` slots of save_for_backward"""
+    e = _EMPTY.get(device)
+    if e is None:
+        e = _EMPTY[device] = torch.empty(0, device=device)
+    return e
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when `dev` is not already current (the context manager costs ~10 us)."""
+
+    def __init__(self, device):
+        self.ctx = None if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def _stream(device) -> C.c_void_p:
@@ -116,7 +145,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         img = torch.empty((lib.splatraster_image_bytes(W, H),), dtype=torch.uint8, device=dev)
         stream = _stream(dev)
         R = C.c_int64(0)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _native.check(lib.splatraster_forward_geometry(
                 C.byref(st), P, _ptr(m3), _ptr(shs), _ptr(opa), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(view),
                 _ptr(proj), _ptr(campos), _ptr(geom), _ptr(radii), C.byref(R), stream), "forward_geometry")
@@ -131,7 +160,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = int(R.value)
         ctx.shapes = (tuple(means3D.shape), None if sh is None else tuple(sh.shape))
         ctx.have = (shs is not None, col is not None, sca is not None, cov is not None)
-        ctx.save_for_backward(*[t if t is not None else torch.empty(0, device=dev) for t in
+        none = _empty(dev)
+        ctx.save_for_backward(*[t if t is not None else none for t in
                                 (m3, shs, col, opa, sca, rot, cov, bg, view, proj, campos)],
                               radii, geom, binning, img, color, depth, alpha)
         ctx.mark_non_differentiable(radii)
@@ -194,7 +224,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_view = torch.empty((4, 4), **f32) if want_pose else None
         d_proj = torch.empty((4, 4), **f32) if want_pose else None
         d_cam = torch.zeros((3,), **f32) if (want_pose and campos is not None) else None
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _native.check(lib.splatraster_backward(
                 C.byref(st), P, ctx.num_rendered, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(opa),
                 _ptr(sca), _ptr(rot), _ptr(cov), _ptr(view), _ptr(proj), _ptr(campos), _ptr(radii),
