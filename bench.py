@@ -339,7 +339,7 @@ def bench_map_step(args, dev):
     from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer
     from splatloc_amd.camera import PinholeCamera
     from splatloc_amd.densify import add_densification_stats, densify_and_prune
-    from splatloc_amd.fused import render as fused_render
+    from splatloc_amd.fused import render as fused_render, render_window
     from splatloc_amd.losses import isotropic_loss, mapping_loss
     from splatloc_amd.optim import Adam as FusedAdam
     from splatloc_amd.synthetic import WORKLOADS, make_workload
@@ -413,13 +413,18 @@ def bench_map_step(args, dev):
 
     def step(pc, fused, it, densify_ms):
         loss, pkgs = 0, []
-        for cam in views:
-            pkg = fused_render(cam, pc, pipe, bg) if fused else composed_render(pc, cam)
-            if fused:
-                loss = loss + mapping_loss(cfg, pkg["render"], pkg["depth"], pkg["kp_prob"], cam)
-            else:
-                loss = loss + composed_loss(cam, pkg["render"], pkg["depth"], pkg["kp_prob"])
-            pkgs.append(pkg)
+        if fused and args.streams > 1:   # the window's views on several HIP streams
+            pkgs, losses = render_window(views, pc, pipe, bg, streams=args.streams,
+                                         per_view=lambda k, cam, pkg: mapping_loss(cfg, pkg["render"], pkg["depth"], pkg["kp_prob"], cam))
+            loss = sum(losses)
+        else:
+            for cam in views:
+                pkg = fused_render(cam, pc, pipe, bg) if fused else composed_render(pc, cam)
+                if fused:
+                    loss = loss + mapping_loss(cfg, pkg["render"], pkg["depth"], pkg["kp_prob"], cam)
+                else:
+                    loss = loss + composed_loss(cam, pkg["render"], pkg["depth"], pkg["kp_prob"])
+                pkgs.append(pkg)
         if fused:      # train_gaussians.py:221-228, no .cpu() sync
             loss = loss + 0.01 * isotropic_loss(torch.exp(pc._scaling), pc._marker)
         else:
@@ -476,7 +481,8 @@ def bench_map_step(args, dev):
         "ms_per_step": round(ms_f, 3), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: P={P0}, {W}x{H}, C={3 + E} ([rgb | {E} kp/feature columns]) + depth + alpha; "
                                "5 views x (render + mapping loss), isotropic regulariser, one backward, densification "
-                               f"stats, key gate + fused Adam over 8 groups, densify_and_prune every {args.densify_every} steps"},
+                               f"stats, key gate + fused Adam over 8 groups, densify_and_prune every {args.densify_every} steps; "
+                               f"{max(args.streams, 1)} HIP stream(s) per window"},
         "views_per_s": round(5e3 / ms_f, 1),
         "densify": {"calls_in_timed_region": len(dens), "ms_per_call": [round(d[0], 3) for d in dens],
                     "rows_before_after": [[d[1], d[2]] for d in dens],

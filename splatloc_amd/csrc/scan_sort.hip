@@ -495,6 +495,10 @@ struct SweepState {        // all zeroed by one memset before the passes
     uint32_t pad[3];
 };
 
+// ITEMS keys per thread: the one-sweep kernels are latency-bound chains per block, so a sort of P = 500 k keys
+// in 4096-key tiles (123 blocks) leaves half of the 256 CUs idle; with 2048-key tiles every CU has a block
+// and each block's chain is half as long (sweep_items below picks the tile)
+template <int ITEMS>
 __global__ void __launch_bounds__(SORT_THREADS)
 sort_hist_all_kernel(int64_t n, const uint32_t* __restrict__ keys, int passes, SweepState* __restrict__ st)
 {
@@ -502,9 +506,9 @@ sort_hist_all_kernel(int64_t n, const uint32_t* __restrict__ keys, int passes, S
 #pragma unroll
     for (int p = 0; p < MAX_PASSES; ++p) hist[p][threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    const int64_t base = (int64_t)blockIdx.x * (SORT_THREADS * ITEMS);
 #pragma unroll 4
-    for (int k = 0; k < SORT_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const int64_t i = base + (int64_t)k * SORT_THREADS + threadIdx.x;
         if (i < n) {
             const uint32_t key = keys[i];
@@ -518,6 +522,7 @@ sort_hist_all_kernel(int64_t n, const uint32_t* __restrict__ keys, int passes, S
     }
 }
 
+template <int ITEMS>
 __global__ void __launch_bounds__(SORT_THREADS)
 sort_sweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int pass,
@@ -535,18 +540,18 @@ sort_sweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_
     __syncthreads();
     const uint32_t bid = s_bid;
 
-    const int64_t wbase = (int64_t)bid * SORT_TILE + (int64_t)w * (SORT_ITEMS * WAVE);
-    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+    const int64_t wbase = (int64_t)bid * (SORT_THREADS * ITEMS) + (int64_t)w * (ITEMS * WAVE);
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const int64_t i = wbase + (int64_t)k * WAVE + lane;
         const bool valid = i < n;
         key[k] = valid ? keys_in[i] : 0u;
         val[k] = valid ? vals_in[i] : 0u;
     }
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const int64_t i = wbase + (int64_t)k * WAVE + lane;
         const bool valid = i < n;
         const uint32_t digit = (key[k] >> shift) & (RADIX - 1);
@@ -625,7 +630,7 @@ sort_sweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
+    for (int k = 0; k < ITEMS; ++k) {
         const int64_t i = wbase + (int64_t)k * WAVE + lane;
         if (i < n) {
             const uint32_t digit = (key[k] >> shift) & (RADIX - 1);
@@ -640,13 +645,28 @@ sort_sweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_
 #define SR_SORT_ONESWEEP 1  // 0 = histogram / scan / scatter kernels per pass (A/B baseline)
 #endif
 
+// keys per thread of the one-sweep path (0: the sort takes the histogram / scan / scatter passes instead)
+static int sweep_items(int64_t n)
+{
+    if (!SR_SORT_ONESWEEP || n <= 0) return 0;
+    if (n <= (int64_t)256 * SORT_THREADS * 8) return 8;            // <= 524 288 keys: 2048-key tiles, <= 256 blocks
+    if (n <= (int64_t)256 * SORT_TILE) return SORT_ITEMS;          // <= 1 048 576 keys: 4096-key tiles
+    return 0;
+}
+static int64_t sweep_blocks(int64_t n)
+{
+    const int64_t tile = (int64_t)SORT_THREADS * sweep_items(n);
+    return tile ? (n + tile - 1) / tile : 0;
+}
+
 size_t sort_tmp_bytes(int64_t n)
 {
     const int64_t nb = (n + SORT_TILE - 1) / SORT_TILE;
     const size_t nbz = (size_t)(nb > 0 ? nb : 1);
     const size_t table = align_up(nbz * RADIX * sizeof(uint32_t), 256);
     const size_t legacy = table + scan_tmp_bytes((int64_t)nbz * RADIX);
-    const size_t sweep = align_up(sizeof(SweepState), 256) + MAX_PASSES * table;
+    const size_t stable = align_up((size_t)(sweep_blocks(n) > 0 ? sweep_blocks(n) : 1) * RADIX * sizeof(uint32_t), 256);
+    const size_t sweep = align_up(sizeof(SweepState), 256) + MAX_PASSES * stable;
     return legacy > sweep ? legacy : sweep;
 }
 
@@ -654,8 +674,8 @@ size_t sort_tmp_bytes(int64_t n)
 // zeroes them itself passes tmp_zeroed = true
 size_t sort_zero_bytes(int64_t n, int key_bits)
 {
-    const int64_t nb = (n + SORT_TILE - 1) / SORT_TILE;
-    if (n <= 0 || key_bits <= 0 || !(SR_SORT_ONESWEEP && nb <= 256)) return 0;
+    if (n <= 0 || key_bits <= 0 || !sweep_items(n)) return 0;
+    const int64_t nb = sweep_blocks(n);
     const int passes = (key_bits + 7) / 8;
     return align_up(sizeof(SweepState), 256) + (size_t)passes * align_up((size_t)nb * RADIX * sizeof(uint32_t), 256);
 }
@@ -672,17 +692,27 @@ int sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt
     // one-sweep for small sorts (launch-latency-bound); the serial look-back of thread d over
     // its predecessors costs more than it saves beyond a few hundred blocks (S2 tile sort:
     // 0.161 vs 0.121 ms with 975 blocks), there the histogram/scan/scatter passes are kept.
-    if (SR_SORT_ONESWEEP && nb <= 256) {
-        const size_t table = align_up((size_t)nb * RADIX * sizeof(uint32_t), 256);
+    if (sweep_items(n)) {
+        const int items = sweep_items(n);
+        const int64_t nbs = sweep_blocks(n);
+        const size_t table = align_up((size_t)nbs * RADIX * sizeof(uint32_t), 256);
         const size_t head = align_up(sizeof(SweepState), 256);
         SweepState* st = reinterpret_cast<SweepState*>(tmp);
         char* status0 = reinterpret_cast<char*>(tmp) + head;
         if (!tmp_zeroed) SR_HIP_CHECK(hipMemsetAsync(tmp, 0, head + (size_t)passes * table, stream));
-        hipLaunchKernelGGL(sort_hist_all_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, n, kin, passes, st);
+        if (items == 8)
+            hipLaunchKernelGGL(sort_hist_all_kernel<8>, dim3((unsigned)nbs), dim3(SORT_THREADS), 0, stream, n, kin, passes, st);
+        else
+            hipLaunchKernelGGL(sort_hist_all_kernel<SORT_ITEMS>, dim3((unsigned)nbs), dim3(SORT_THREADS), 0, stream, n, kin, passes, st);
         SR_LAUNCH_CHECK();
         for (int p = 0; p < passes; ++p) {
-            hipLaunchKernelGGL(sort_sweep_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, n, kin, vin,
-                               kout, vout, p, st, reinterpret_cast<uint32_t*>(status0 + (size_t)p * table));
+            uint32_t* status = reinterpret_cast<uint32_t*>(status0 + (size_t)p * table);
+            if (items == 8)
+                hipLaunchKernelGGL(sort_sweep_kernel<8>, dim3((unsigned)nbs), dim3(SORT_THREADS), 0, stream, n, kin, vin, kout,
+                                   vout, p, st, status);
+            else
+                hipLaunchKernelGGL(sort_sweep_kernel<SORT_ITEMS>, dim3((unsigned)nbs), dim3(SORT_THREADS), 0, stream, n, kin, vin,
+                                   kout, vout, p, st, status);
             SR_LAUNCH_CHECK();
             uint32_t* t = kin; kin = kout; kout = t;
             t = vin; vin = vout; vout = t;
