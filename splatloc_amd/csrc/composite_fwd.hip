@@ -125,10 +125,10 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
     } trace_end{__builtin_amdgcn_s_memrealtime(), g_trace_fwd};
 #endif
     int tile, quad;
-    quadrant_of_block(blockIdx.x, tile, quad);
+    const int gx = (W + TILE - 1) / TILE;
+    quadrant_of_block(blockIdx.x, tiles, gx, tile, quad);
     if (tile >= tiles) return;
     const int lane = threadIdx.x;
-    const int gx = (W + TILE - 1) / TILE;
     const int qx = (tile % gx) * TILE + (quad & 1) * 8, qy = (tile / gx) * TILE + (quad >> 1) * 8;
     const int px = qx + (lane & 7), py = qy + (lane >> 3);
     const bool inside = px < W && py < H;
@@ -312,7 +312,7 @@ static int launch_one(const splatraster_settings& s, int c0, int write_aux, cons
     (void)g;
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
     const int tiles = gx * gy;
-    const unsigned blocks = (unsigned)((tiles + 7) / 8) * 32u;  // 4 quadrants per tile, tiles padded to 8
+    const unsigned blocks = quadrant_blocks(tiles, gx);  // 4 quadrants per tile (+ padding of the id space)
     hipLaunchKernelGGL(composite_fwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
                        s.image_height, padded_channels(feat_stride) / 4, c0, s.bg_channels, write_aux, tiles, b.ranges,
                        b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(featp), bg, out_color, out_depth, out_alpha, im.final_T,
