@@ -25,7 +25,7 @@
 #include "composite_common.h"
 
 #ifndef SR_FWD_FS
-#define SR_FWD_FS 32  // feature rows staged per round (<= 64)
+#define SR_FWD_FS 24  // feature rows staged per round (<= 64; A/B on S2, 5 cameras: 12: 0.399, 16: 0.417, 20: 0.411, 24: 0.391, 32: 0.401, 40: 0.417, 48: 0.442 ms)
 #endif
 #ifdef SR_ABLATE_HOT_ROWS  // timing experiment only: every gather hits the same few rows
 #define SR_ABLATE_HOT(x) ((x) & 1023u)
