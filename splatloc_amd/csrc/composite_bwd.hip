@@ -40,8 +40,8 @@
 #else
 #define SR_ABLATE_STAGE_N(n) (n)
 #endif
-#ifndef SR_STAGE_UNROLL
-#define SR_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2, 5 cameras: 2: 0.947, 3: 0.914 ms)
+#ifndef SR_BWD_STAGE_UNROLL
+#define SR_BWD_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2, 5 cameras: 2: 0.947, 3: 0.914 ms)
 #endif
 
 #ifndef SR_BWD_LDSDMA
@@ -314,7 +314,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #if SR_BWD_LDSDMA
             // LDS-DMA (global_load_lds_dwordx4): lane l of issue k lands at s_feat + 16 (64 k + l) without passing
             // through VGPRs, so EVERY piece of the round is in flight at once (one memory latency per round
-            // instead of one per SR_STAGE_UNROLL pieces)
+            // instead of one per SR_BWD_STAGE_UNROLL pieces)
 #pragma unroll
             for (int k = 0; k < (FS * PPR + WAVE - 1) / WAVE; ++k) {
                 const int e = k * WAVE + lane;
@@ -327,7 +327,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #else
-#pragma unroll SR_STAGE_UNROLL
+#pragma unroll SR_BWD_STAGE_UNROLL
             for (int e = lane; e < SR_ABLATE_STAGE_N(ncand * PPR); e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
                 reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];

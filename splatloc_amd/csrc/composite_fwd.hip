@@ -37,8 +37,8 @@
 #else
 #define SR_ABLATE_STAGE_N(n) (n)
 #endif
-#ifndef SR_STAGE_UNROLL
-#define SR_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2: 1: 0.429, 2: 0.456, 3: 0.416, 5: 0.478 ms)
+#ifndef SR_FWD_STAGE_UNROLL
+#define SR_FWD_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2: 1: 0.429, 2: 0.456, 3: 0.416, 5: 0.478 ms)
 #endif
 
 #ifndef SR_FWD_LDSDMA
@@ -198,7 +198,7 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #else
-#pragma unroll SR_STAGE_UNROLL
+#pragma unroll SR_FWD_STAGE_UNROLL
             for (int e = lane; e < SR_ABLATE_STAGE_N(ncand * PPR); e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
                 reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];   // ids < 2^24: checked on the host
