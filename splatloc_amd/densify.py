@@ -161,3 +161,37 @@ def densify_and_prune(gaussians, max_grad, min_opacity, extent, max_screen_size,
     gaussians.denom = torch.zeros((n, 1), device=dev)
     gaussians.max_radii2D = torch.zeros((n,), device=dev)
     return n
+
+
+def reset_opacity_nonvisible(gaussians, visibility_filters) -> None:
+    """`GaussianModel.reset_opacity_nonvisible(visibility_filters)` (gaussian_model.py:384-392; call site
+    train_gaussians.py:260-263, every `gaussian_reset` iterations) on the reference's own model object, with the
+    optimizer surgery of `replace_tensor_to_optimizer` (gaussian_model.py:477-490: the opacity group's Adam moments
+    are zeroed, its step counter is kept).  Mirrors the reference exactly, including its quirk: a Gaussian seen by
+    any of the filters keeps its ACTIVATED opacity as the new logit (`opacities_new[filter] = self.get_opacity[filter]`),
+    every other one is reset to inverse_sigmoid(0.4).  A handful of elementwise device ops every ~2000 iterations:
+    no kernel of its own, and no device->host synchronisation (the reference's boolean-mask stores each imply one)."""
+    from torch import nn
+    op = gaussians._opacity.detach()
+    act = torch.sigmoid(op)                                   # get_opacity
+    x = torch.ones_like(act) * 0.4
+    new = torch.log(x / (1 - x))                              # inverse_sigmoid(0.4), general_utils.py:20-21
+    seen = None
+    for f in visibility_filters:
+        f = f.reshape(-1).to(torch.bool)
+        seen = f if seen is None else (seen | f)
+    if seen is not None:
+        new = torch.where(seen.view(-1, 1), act, new)
+    opt = gaussians.optimizer
+    for grp in opt.param_groups:
+        if grp["name"] != "opacity":
+            continue
+        old = grp["params"][0]
+        st = opt.state.pop(old, None)
+        p = nn.Parameter(new.contiguous().requires_grad_(True))
+        grp["params"][0] = p
+        if st is not None:
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
+            opt.state[p] = st
+        gaussians._opacity = p

@@ -95,3 +95,27 @@ def test_adam_and_densify_against_reference(golden_dir, case):
     for k, st in _state(d, case + "s3_").items():
         assert state[k]["step"] == st["step"] == 5.0
         np.testing.assert_allclose(state[k]["m"], st["m"], rtol=1e-5, atol=1e-10)
+
+
+def test_reset_opacity_nonvisible_matches_reference(golden_dir):
+    """splatloc_amd.densify.reset_opacity_nonvisible (elementwise torch ops, runs on any device) against the state
+    recorded from the reference's GaussianModel.reset_opacity_nonvisible + replace_tensor_to_optimizer."""
+    import types
+    import torch
+    from splatloc_amd.densify import reset_opacity_nonvisible
+    d = np.load(os.path.join(golden_dir, "reset_opacity.npz"))
+    p = torch.nn.Parameter(torch.from_numpy(d["opacity_before"]).requires_grad_(True))
+    other = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.Adam([{"params": [other], "lr": 0.1, "name": "xyz"}, {"params": [p], "lr": 0.05, "name": "opacity"}], lr=0.0, eps=1e-15)
+    opt.state[p] = {"step": torch.tensor(float(d["step_before"])), "exp_avg": torch.from_numpy(d["m_before"].copy()),
+                    "exp_avg_sq": torch.from_numpy(d["v_before"].copy())}
+    gm = types.SimpleNamespace(_opacity=p, optimizer=opt)
+    reset_opacity_nonvisible(gm, [torch.from_numpy(d["filter0"]), torch.from_numpy(d["filter1"])])
+    assert isinstance(gm._opacity, torch.nn.Parameter) and gm._opacity is opt.param_groups[1]["params"][0] and gm._opacity is not p
+    assert np.array_equal(gm._opacity.detach().numpy(), d["opacity_after"])
+    st = opt.state[gm._opacity]
+    assert np.array_equal(st["exp_avg"].numpy(), d["m_after"]) and np.array_equal(st["exp_avg_sq"].numpy(), d["v_after"])
+    assert float(st["step"]) == float(d["step_after"]) == float(d["step_before"]) and not d["m_after"].any()
+    seen = d["filter0"] | d["filter1"]
+    assert np.allclose(d["opacity_after"][~seen], np.log(0.4 / 0.6), atol=1e-6)       # the reset value
+    assert (d["opacity_after"][seen] > 0).all() and (d["opacity_after"][seen] < 1).all()  # the reference's quirk: sigmoid kept as logit
