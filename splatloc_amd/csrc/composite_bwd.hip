@@ -60,6 +60,9 @@
 #ifndef SR_BWD_DOT_CHAINS
 #define SR_BWD_DOT_CHAINS 2  // (>= 1) independent accumulators of the 4x4x1 MFMA dot product (A/B: 1: 0.950, 2: 0.928, 3: 0.944 (other box), 6 spills)
 #endif
+#ifndef SR_BWD_SMALL_PANEL_MAX_WAVES
+#define SR_BWD_SMALL_PANEL_MAX_WAVES 6144  // frames with at most this many quadrant-waves use the small-layout panel variant (0 = never)
+#endif
 #ifndef SR_BWD_DOTM_MIN
 #define SR_BWD_DOTM_MIN 8  // channels from which the 4x4x1 MFMA dot product is used
 #endif
@@ -81,12 +84,22 @@ __device__ unsigned long long g_bwd_prof[12];
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NC>
+template <int NC, bool SP>
 struct BwdCfg {
-    static constexpr bool MFMA = NC >= 32;
-    static constexpr int NM = MFMA ? 32 : 0;   // channels reduced on the matrix pipe
+    // Small layouts (NC <= 15: SplatLoc's own C = 4, and 1 / 2 / 3 / 8), variant SP: ALL channels and the depth
+    // weight w g_D are ONE 16-column block of the flush contraction, so only the six geometric moments go
+    // through the butterfly (12 instead of 22 values per pair at C = 4) — at the price of 91 instead of 59 VGPRs
+    // (5 instead of 8 waves per SIMD).  It is chosen per launch: when the frame's quadrant-waves all fit the
+    // machine at once anyway (SplatLoc's 640x480: 4 800 waves) the lost occupancy costs nothing and the kernel
+    // is 8 % faster (C = 4: 0.252 -> 0.231 ms); on large frames the butterfly variant at full occupancy wins
+    // (S1, 1200x680: 0.198 vs 0.238 ms), and below 4 channels the flush costs what it saves.
+    static constexpr bool SMALLP = NC <= 15 && SP;
+    static constexpr bool MFMA = NC >= 32 || SMALLP;
+    static constexpr int NM = NC >= 32 ? 32 : (SMALLP ? NC : 0);   // channels reduced on the matrix pipe
+    static constexpr int NB = NC >= 32 ? 2 : 1;                    // 16-column blocks of the contraction
+    static constexpr bool XD = SMALLP;                             // column NC of the block = the depth weight
     static constexpr int NV = NC - NM;         // channels reduced with the packed butterfly
-    static constexpr int KV = NV + 7;          // butterfly values per Gaussian
+    static constexpr int KV = NV + (XD ? 6 : 7);   // butterfly values per Gaussian
     static constexpr int NCP = (NC + 3) & ~3;
     static constexpr int FS = SR_BWD_FS;             // feature rows staged per round
     static constexpr int GROUP = 16;           // Gaussians per MFMA flush (M of v_mfma_f32_16x16x4_f32)
@@ -108,7 +121,7 @@ __device__ __forceinline__ void acc_add(float* gacc, long long* gacc64, size_t i
         atomicAdd(gacc + idx, v);
 }
 
-template <int NC, bool DET>
+template <int NC, bool DET, bool SP>
 __global__ void __launch_bounds__(WAVE, SR_BWD_MINW)
 composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass, int tiles,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -120,10 +133,11 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      const float* __restrict__ dL_dalpha, float* __restrict__ gacc /*[P, GROW]*/, int GROW,
                      int MO, long long* __restrict__ gacc64 /*[P, GROW] fixed point, DET only*/)
 {
-    using Cfg = BwdCfg<NC>;
+    using Cfg = BwdCfg<NC, SP>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
     constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
-    constexpr bool MFMA = Cfg::MFMA;
+    constexpr bool MFMA = Cfg::MFMA, XD = Cfg::XD;
+    constexpr int NB = Cfg::NB;
     constexpr bool DOTM = NC >= SR_BWD_DOTM_MIN;  // dot products q = f . g on the matrix pipe
     constexpr int PPR = NCP / 4;  // 16-byte pieces per staged row
     static_assert(2 * KV <= WAVE, "at most 25 butterfly-reduced channels per pass");
@@ -186,13 +200,16 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     // B operand of the contraction, kept in registers for the whole tile: for k-step kk and
     // channel half t, lane l holds dL/dcolor[pix = 4 kk + (l >> 4)][ch = 16 t + (l & 15)].
     // Built once by transposing through the (still unused) weight panel.
-    float gt[MFMA ? 16 : 1][2];
+    float gt[MFMA ? 16 : 1][NB];
     if (MFMA) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NB; ++t) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int ch = 0; ch < 16; ++ch) s_w[lane * WS + ch] = g[16 * t + ch];
+            for (int ch = 0; ch < 16; ++ch) {
+                const int c = 16 * t + ch;
+                s_w[lane * WS + ch] = c < NC ? g[c < NC ? c : 0] : ((XD && c == NC) ? gD : 0.0f);
+            }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) gt[kk][t] = s_w[(4 * kk + (lane >> 4)) * WS + (lane & 15)];
@@ -233,18 +250,22 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         for (int kk = 0; kk < 16; ++kk) {
             const float a = s_w[4 * kk * WS + row];
             D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][0], D0, 0, 0, 0);
-            D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][1], D1, 0, 0, 0);
+            if (NB > 1) D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][NB > 1 ? 1 : 0], D1, 0, 0, 0);
         }
+        // one block: column j < NC is channel c0 + j, column NC the depth weight (moment slot 6, first pass only)
+        const int j0c = lane & 15;
+        const bool col_ok = NB > 1 || j0c < NC || (XD && j0c == NC && first_pass);
+        const int col_off = (NB > 1 || j0c < NC) ? (c0 + j0c) : (MO + 6);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gs = 4 * (lane >> 4) + r;
             if (gs < count) {
-                const size_t di = (size_t)(__umul24(s_gid[gs], (uint32_t)GROW) + (uint32_t)(c0 + (lane & 15)));
+                const size_t di = (size_t)(__umul24(s_gid[gs], (uint32_t)GROW) + (uint32_t)col_off);
 #if SR_BWD_ABLATE_ATOMIC
                 asm volatile("" ::"v"(di), "v"(D0[r]), "v"(D1[r]));
 #else
-                acc_add<DET>(gacc, gacc64, di, D0[r]);
-                acc_add<DET>(gacc, gacc64, di + 16, D1[r]);
+                if (col_ok) acc_add<DET>(gacc, gacc64, di, D0[r]);
+                if (NB > 1) acc_add<DET>(gacc, gacc64, di + 16, D1[r]);
 #endif
             }
         }
@@ -401,7 +422,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     red[NV + 3] = Ex * dy0;
                     red[NV + 4] = Ey * dy0;
                     red[NV + 5] = E;
-                    red[NV + 6] = w0 * gD;
+                    if (!XD) red[NV + (XD ? 5 : 6)] = w0 * gD;
                 }
                 {
                     const float E = G1 * dA1, Ex = E * dx1, Ey = E * dy1;
@@ -411,7 +432,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     red[KV + NV + 3] = Ex * dy1;
                     red[KV + NV + 4] = Ey * dy1;
                     red[KV + NV + 5] = E;
-                    red[KV + NV + 6] = w1 * gD;
+                    if (!XD) red[KV + NV + (XD ? 5 : 6)] = w1 * gD;
                 }
                 BP_T(tp2);
                 BP_ADD(3, tp2 - tp1);
@@ -532,10 +553,21 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
     const int tiles = gx * gy;
     const unsigned blocks = quadrant_blocks(tiles, gx);  // 4 quadrants per tile (+ padding of the id space)
-    hipLaunchKernelGGL((composite_bwd_kernel<NC, DET>), dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
-                       s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, b.ranges,
-                       b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), out_color, out_depth, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth,
-                       dL_dalpha, gacc, gacc_row_floats(s.channels), gacc_moment_offset(s.channels), gacc64);
+#define SR_BWD_LAUNCH(SPV)                                                                                          \
+    hipLaunchKernelGGL((composite_bwd_kernel<NC, DET, SPV>), dim3(blocks), dim3(WAVE), 0, stream, s.image_width,        \
+                       s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, b.ranges,      \
+                       b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), out_color, out_depth,     \
+                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, gacc, gacc_row_floats(s.channels),   \
+                       gacc_moment_offset(s.channels), gacc64)
+    if constexpr (NC >= 4 && NC <= 15) {   // C = 3 and below: the flush costs what the 8 saved butterfly values gain (A/B: S0 0.036 vs 0.041 ms)
+        if (4 * tiles <= SR_BWD_SMALL_PANEL_MAX_WAVES)
+            SR_BWD_LAUNCH(true);
+        else
+            SR_BWD_LAUNCH(false);
+    } else {
+        SR_BWD_LAUNCH(false);
+    }
+#undef SR_BWD_LAUNCH
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

@@ -76,6 +76,8 @@ def _check_backward(run: HipRun, b: dict, allow_frac=0.0):
     dict(P=2_000, W=200, H=120, C=7, seed=24, scale_median=0.04),    # generic C: chunked passes 4+3
     dict(P=1_500, W=160, H=96, C=40, seed=25, scale_median=0.04),    # 32 + 8
     dict(P=20_000, W=256, H=256, C=3, seed=26, scale_median=0.05),   # deep lists: several LDS batches
+    dict(P=30_000, W=1280, H=720, C=4, seed=27, scale_median=0.02),  # C = 4 on a LARGE frame: the butterfly variant of the backward (small frames take the panel variant)
+    dict(P=6_000, W=320, H=240, C=8, seed=28, scale_median=0.03),    # C = 8: panel variant + matrix-pipe dot products
 ])
 def test_forward_backward_parity(cfg):
     sc = make_scene(**cfg)
