@@ -63,6 +63,9 @@
 #ifndef SR_BWD_SMALL_PANEL_MAX_WAVES
 #define SR_BWD_SMALL_PANEL_MAX_WAVES 6144  // frames with at most this many quadrant-waves use the small-layout panel variant (0 = never)
 #endif
+#ifndef SR_BWD_DOT_PREFETCH
+#define SR_BWD_DOT_PREFETCH 1  // double-buffered LDS reads in the 4x4x1 dot (A/B on S2: 0.8645 -> 0.860 ms)
+#endif
 #ifndef SR_BWD_DOTM_MIN
 #define SR_BWD_DOTM_MIN 8  // channels from which the 4x4x1 MFMA dot product is used
 #endif
@@ -480,9 +483,26 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 f32x4 Qc[CH];
 #pragma unroll
                 for (int c = 0; c < CH; ++c) Qc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if SR_BWD_DOT_PREFETCH
+                // the next 16-byte piece of the row is requested before the four MFMAs of the current one
+                const float4* f4 = reinterpret_cast<const float4*>(fr);
+                float4 cur = f4[0];
+#pragma unroll
+                for (int i = 0; i < PPR; ++i) {
+                    const float4 nxt = f4[i + 1 < PPR ? i + 1 : i];
+                    const float v[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ch = 4 * i + q;
+                        if (ch < NC) Qc[ch % CH] = __builtin_amdgcn_mfma_f32_4x4x1f32(v[q], g[ch < NC ? ch : 0], Qc[ch % CH], 0, 0, 0);
+                    }
+                    cur = nxt;
+                }
+#else
 #pragma unroll
                 for (int ch = 0; ch < NC; ++ch)
                     Qc[ch % CH] = __builtin_amdgcn_mfma_f32_4x4x1f32(fr[ch], g[ch], Qc[ch % CH], 0, 0, 0);
+#endif
                 Qc[NC % CH] = __builtin_amdgcn_mfma_f32_4x4x1f32(zsel, gD, Qc[NC % CH], 0, 0, 0);
                 f32x4 Q = Qc[0];
 #pragma unroll
