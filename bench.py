@@ -413,8 +413,8 @@ def bench_map_step(args, dev):
 
     def step(pc, fused, it, densify_ms):
         loss, pkgs = 0, []
-        if fused and args.streams > 1:   # the window's views on several HIP streams
-            pkgs, losses = render_window(views, pc, pipe, bg, streams=args.streams,
+        if fused:   # one activate_pack per window; the views on --streams HIP streams
+            pkgs, losses = render_window(views, pc, pipe, bg, streams=max(args.streams, 1),
                                          per_view=lambda k, cam, pkg: mapping_loss(cfg, pkg["render"], pkg["depth"], pkg["kp_prob"], cam))
             loss = sum(losses)
         else:

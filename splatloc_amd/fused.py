@@ -126,8 +126,19 @@ def _covariance_python(scales, scaling_modifier, rotation_raw):
     return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=1)
 
 
+def shared_activations(pc, pipe):
+    """The rasterizer arguments that do not depend on the view — `exp(_scaling)`, `normalize(_rotation)`, `sigmoid(_opacity)`
+    and, at SH degree 0 (SplatLoc's configuration), the `[rgb | kp_score]` table — computed ONCE for all the views of a
+    window (`render_window`): one `activate_pack` forward and, through autograd, one backward per optimisation step instead
+    of one per view.  None when the colours are view dependent or the pipe asks for another path."""
+    if not bool(pipe.convert_SHs_python) or bool(pipe.compute_cov3D_python) or int(pc.active_sh_degree) != 0:
+        return None
+    return activate_pack(pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity,
+                         extra=pc._kp_score, campos=None, active_sh_degree=0)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
-           mask=None) -> Optional[dict]:
+           mask=None, _shared=None) -> Optional[dict]:
     """Drop-in for gaussian_renderer.render (gaussian_renderer/__init__.py:13-141): same signature, same
     return dict, same values and gradients (tests/test_gpu_activations.py against the reference's own render()).
 
@@ -161,10 +172,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     convert_shs = bool(pipe.convert_SHs_python)
     # the packed colours are only needed when the rasterizer is fed colors_precomp
     want_colors = convert_shs
-    scales, rotations, opacity, colors = activate_pack(
-        means3D, f_dc, f_rest, sel(pc._scaling), sel(pc._rotation), sel(pc._opacity),
-        extra=sel(pc._kp_score) if want_colors else None, campos=campos,
-        active_sh_degree=pc.active_sh_degree if convert_shs else 0)
+    if _shared is not None and mask is None:
+        scales, rotations, opacity, colors = _shared      # shared_activations(): the same tensors for every view of a window
+    else:
+        scales, rotations, opacity, colors = activate_pack(
+            means3D, f_dc, f_rest, sel(pc._scaling), sel(pc._rotation), sel(pc._opacity),
+            extra=sel(pc._kp_score) if want_colors else None, campos=campos,
+            active_sh_degree=pc.active_sh_degree if convert_shs else 0)
     shs = colors_precomp = cov3D_precomp = None
     if convert_shs:
         colors_precomp = colors
@@ -192,7 +206,8 @@ def window_streams(device, n: int):
     return _WINDOW_STREAMS[key]
 
 
-def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, streams: int = 2, per_view=None):
+def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, streams: int = 2, per_view=None,
+                  share_activations: bool = True):
     """The render loop of one optimisation window (`for cam_idx in ...: render_pkg = render(viewpoint, ...)`,
     train_gaussians.py:195-219) with view k enqueued on HIP stream k % `streams`.
 
@@ -203,13 +218,18 @@ def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier
     (DESIGN.md).  `per_view(k, viewpoint, pkg)` — e.g. the view's loss — runs on the view's stream as
     well; its return values are collected.  Autograd replays every backward on its forward's stream and
     serialises the accumulation into the shared parameters' .grad, so `loss.backward()` needs no change.
+    `share_activations`: at SH degree 0 the activated scales / rotations / opacities and the `[rgb | kp_score]` table are
+    the same for every view, so they are produced by ONE `activate_pack` per window (and differentiated once: autograd sums
+    the views' gradients at its outputs) instead of one per view.
     Returns (pkgs, per_view results).  streams <= 1 is the reference's serial loop."""
     viewpoints = list(viewpoints)
     pkgs, extra = [], []
     dev = pc._xyz.device
+    # view-independent activations once per window (on the caller's stream, before the fork)
+    shared = shared_activations(pc, pipe) if (share_activations and len(viewpoints) > 1 and pc._xyz.shape[0] > 0) else None
     if streams <= 1 or len(viewpoints) <= 1:
         for k, vp in enumerate(viewpoints):
-            pkg = render(vp, pc, pipe, bg_color, scaling_modifier)
+            pkg = render(vp, pc, pipe, bg_color, scaling_modifier, _shared=shared)
             pkgs.append(pkg)
             extra.append(per_view(k, vp, pkg) if per_view is not None else None)
         return pkgs, extra
@@ -219,7 +239,7 @@ def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier
         st.wait_stream(main)          # the parameters (and whatever else main produced) are ready
     for k, vp in enumerate(viewpoints):
         with torch.cuda.stream(side[k % len(side)]):
-            pkg = render(vp, pc, pipe, bg_color, scaling_modifier)
+            pkg = render(vp, pc, pipe, bg_color, scaling_modifier, _shared=shared)
             pkgs.append(pkg)
             extra.append(per_view(k, vp, pkg) if per_view is not None else None)
     for st in side:
