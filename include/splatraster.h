@@ -43,9 +43,11 @@ extern "C" {
 /* status codes */
 #define SPLATRASTER_OK 0
 #define SPLATRASTER_ERR_BAD_ARG 1      /* null pointer / inconsistent sizes / both-or-neither inputs */
-#define SPLATRASTER_ERR_HIP 2          /* a HIP runtime call or kernel launch failed, or a look-back watchdog fired */
+#define SPLATRASTER_ERR_HIP 2          /* a HIP runtime call or kernel launch failed (incl. a wedged look-back: hard spin bound -> trap) */
 #define SPLATRASTER_ERR_UNSUPPORTED 3  /* e.g. sh_degree > 3 */
 #define SPLATRASTER_ERR_OVERFLOW 4     /* tile instance count does not fit the binning buffer */
+#define SPLATRASTER_WARN_LOOKBACK_STALL 5 /* splatraster_poll_errors() only: a scan / sort block waited longer than the soft
+                                          * spin bound for a predecessor; NOT an error of any frame (results are late, never wrong) */
 
 /*
  * Mirror of diff_gauss.GaussianRasterizationSettings
@@ -381,14 +383,14 @@ int splatraster_timing_collect(double* ms, int64_t* counts);
 /* ---- misc ---------------------------------------------------------------------------- */
 
 /* The decoupled look-backs of the one-pass scan and of the one-sweep radix sort never give up with a
- * partial prefix (that would be a silently mis-sorted frame).  A block that has waited longer than the
- * spin bound raises a flag in host-mapped memory and keeps waiting; forward_geometry / forward_render /
- * backward / sort_pairs poll that flag (and forward_geometry again after its host wait) and return
- * SPLATRASTER_ERR_HIP: a stalling or wedged device is reported, results are never wrong.  The work is
- * asynchronous, so the reporting call may be a later one on the same device.
- * splatraster_poll_errors() polls explicitly (exact after a stream synchronize). */
+ * partial prefix (that would be a silently mis-sorted frame).  Soft bound: a block that has waited longer
+ * than the spin limit raises a flag in host-mapped memory and keeps waiting — the frame stays correct, so
+ * forward / backward / sort_pairs still return OK; splatraster_poll_errors() (exact after a stream
+ * synchronize) returns SPLATRASTER_WARN_LOOKBACK_STALL once per raised flag, for monitoring.  Hard bound
+ * (2^30 spins): the block traps, the kernel aborts and the following HIP calls fail -> SPLATRASTER_ERR_HIP:
+ * a wedged device is a fault, never a silent hang. */
 int splatraster_poll_errors(void);
-/* test hooks: spin bound of the look-backs (default 1 << 24; 0 makes every block that has to wait at
+/* test hooks: SOFT spin bound of the look-backs (default 1 << 24; 0 makes every block that has to wait at
  * all report), and y[i] = the device's 2^x (the alpha arithmetic shared with the CPU oracle). */
 int splatraster_debug_set_spin_limit(uint32_t limit);
 /* Deterministic-sum debug mode of the backward (process-wide switch, default off).  The compositing

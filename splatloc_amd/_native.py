@@ -14,8 +14,9 @@ _LIB = None
 ABI_VERSION = 4   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
+WARN_LOOKBACK_STALL = 5   # splatraster_poll_errors() only; not an error of any frame
 _ERR_NAMES = {1: "bad argument", 2: "HIP runtime error", 3: "unsupported configuration",
-              4: "tile instance count overflow"}
+              4: "tile instance count overflow", 5: "look-back stall (results late, never wrong)"}
 
 
 class Settings(C.Structure):
@@ -148,7 +149,7 @@ def load(build_if_missing: bool = True):
 def check(status: int, what: str) -> None:
     if status != OK:
         lib = load()
-        detail = lib.splatraster_last_hip_error().decode() if status == 2 else ""
+        detail = lib.splatraster_last_hip_error().decode() if status in (2, 5) else ""
         raise RuntimeError(f"{what} failed: {_ERR_NAMES.get(status, status)} {detail}".strip())
 
 
@@ -180,3 +181,12 @@ def timing_collect() -> dict:
 def set_deterministic(on: bool) -> None:
     """Deterministic-sum debug mode of the backward (bit-reproducible gradients; see splatraster.h)."""
     check(load().splatraster_debug_set_deterministic(int(bool(on))), "set_deterministic")
+
+
+def poll_stall() -> bool:
+    """True once per soft look-back stall raised since the last poll (monitoring; the frames are still correct)."""
+    st = load().splatraster_poll_errors()
+    if st == WARN_LOOKBACK_STALL:
+        return True
+    check(st, "poll_errors")
+    return False

@@ -6,6 +6,8 @@ Pure hipcc: no torch headers, no pybind — the library is loaded with ctypes
 """
 from __future__ import annotations
 
+import contextlib
+import fcntl
 import hashlib
 import json
 import os
@@ -19,6 +21,7 @@ LIB_DIR = os.path.join(_HERE, "_lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libsplatraster.so")
 MANIFEST = os.path.join(LIB_DIR, "manifest.json")
+LOCK_PATH = os.path.join(LIB_DIR, ".build.lock")
 # experiments only: SPLATRASTER_LIB points the loader at a variant build (tools/ablate.py)
 
 
@@ -88,10 +91,14 @@ def _compile_one(src: str, force: bool, manifest: dict) -> tuple:
     dig = _digest(src)
     if not force and os.path.exists(obj) and manifest.get(src) == dig:
         return obj, dig, False
-    cmd = [_hipcc(), *_flags(src), "-c", path, "-o", obj]
+    tmp = f"{obj}.{os.getpid()}.tmp"   # never a half-written object under the final name
+    cmd = [_hipcc(), *_flags(src), "-c", path, "-o", tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        with contextlib.suppress(OSError):
+            os.remove(tmp)
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, obj)
     return obj, dig, True
 
 
@@ -101,7 +108,32 @@ def up_to_date() -> bool:
     return os.path.exists(LIB_PATH) and all(m.get(s) == _digest(s) for s in SOURCES)
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """Exclusive inter-process lock on _lib/.build.lock: every rank of a `torchrun --nproc-per-node N` job imports
+    this package at the same time, and after a source edit each of them would otherwise compile the same objects,
+    link the same .so and write the same manifest concurrently (a rank could dlopen a half-written ELF).  The first
+    rank builds; the others block here, then find everything up to date."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    try:
+        f = open(LOCK_PATH, "a+")
+    except OSError:      # read-only tree: nothing can be rebuilt there anyway
+        yield
+        return
+    with f:
+        fcntl.flock(f.fileno(), fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f.fileno(), fcntl.LOCK_UN)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    with _build_lock():
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     if not force and up_to_date():
         if verbose:
@@ -111,12 +143,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         res = list(ex.map(lambda s: _compile_one(s, force, manifest), SOURCES))
     objs = [r[0] for r in res]
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB_PATH]
+    tmp_lib = f"{LIB_PATH}.{os.getpid()}.tmp"
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", tmp_lib]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        with contextlib.suppress(OSError):
+            os.remove(tmp_lib)
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    with open(MANIFEST, "w") as f:
+    os.replace(tmp_lib, LIB_PATH)        # atomic: a concurrent dlopen sees the old or the new library, never a torso
+    tmp_manifest = f"{MANIFEST}.{os.getpid()}.tmp"
+    with open(tmp_manifest, "w") as f:
         json.dump({s: r[1] for s, r in zip(SOURCES, res)}, f, indent=1)
+    os.replace(tmp_manifest, MANIFEST)
     if verbose:
         print("built", LIB_PATH, "(recompiled:", [s for s, r in zip(SOURCES, res) if r[2]], ")")
     return LIB_PATH

@@ -148,7 +148,7 @@ GeomView geom_view(void* base, int32_t P)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, gacc64, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, bytes;
 };
 static BinLayout bin_layout(int32_t P, int64_t R, int32_t W, int32_t H, int32_t C)
 {
@@ -168,8 +168,8 @@ static BinLayout bin_layout(int32_t P, int64_t R, int32_t W, int32_t H, int32_t 
     // padded feature table only when the rows are not already 16-byte aligned
     L.featp = take((C % 4) ? (size_t)(P > 0 ? P : 1) * padded_channels(C) * sizeof(float) : 16);
     L.gacc = take((size_t)(P > 0 ? P : 1) * gacc_row_floats(C) * sizeof(float));
-    // reserved for the deterministic debug mode (untouched otherwise: address space, not bandwidth)
-    L.gacc64 = take((size_t)(P > 0 ? P : 1) * gacc_row_floats(C) * sizeof(long long));
+    // (the deterministic debug mode's 64-bit accumulator is NOT part of this buffer: it is a stream-ordered
+    //  allocation made by splatraster_backward only while that mode is on)
     L.bytes = o;
     return L;
 }
@@ -189,7 +189,6 @@ BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H, int32_t
     v.imask = reinterpret_cast<uint8_t*>(b + L.imask);
     v.featp = reinterpret_cast<float*>(b + L.featp);
     v.gacc = reinterpret_cast<float*>(b + L.gacc);
-    v.gacc64 = reinterpret_cast<long long*>(b + L.gacc64);
     return v;
 }
 
@@ -236,6 +235,7 @@ const char* splatraster_error_string(int status)
         case SPLATRASTER_ERR_HIP: return "HIP runtime error";
         case SPLATRASTER_ERR_UNSUPPORTED: return "unsupported configuration";
         case SPLATRASTER_ERR_OVERFLOW: return "tile instance count overflow";
+        case SPLATRASTER_WARN_LOOKBACK_STALL: return "look-back stall (results late, never wrong)";
         default: return "unknown status";
     }
 }
@@ -300,8 +300,6 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
     }
     st = lookback_error_init();
     if (st) return st;
-    st = lookback_error_poll();   // a timed-out scan / sort of an earlier call on this device
-    if (st) return st;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const GeomLayout L = geom_layout(P);
     GeomView g = geom_view(geometry, P);
@@ -341,7 +339,7 @@ int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const
     for (size_t k = 0; k < nblk; ++k) total += slot->p[k];
     if (total >= ((uint64_t)1 << 31)) return SPLATRASTER_ERR_OVERFLOW;
     *num_rendered = (int64_t)total;
-    return lookback_error_poll();
+    return SPLATRASTER_OK;
 }
 
 int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t R, const float* bg,
@@ -354,8 +352,6 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
     if (s->bg_channels > 0 && !bg) return SPLATRASTER_ERR_BAD_ARG;
     if (P > 0 && (!geometry || !binning)) return SPLATRASTER_ERR_BAD_ARG;
     st = check_row_index_range(P, s->channels);
-    if (st) return st;
-    st = lookback_error_poll();
     if (st) return st;
     if (R > 0 && !binning) return SPLATRASTER_ERR_BAD_ARG;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -440,8 +436,6 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
         return SPLATRASTER_ERR_BAD_ARG;
     st = check_row_index_range(P, s->channels);
     if (st) return st;
-    st = lookback_error_poll();   // this frame's tile sort (when the GPU got that far) or an earlier call
-    if (st) return st;
     const int W = s->image_width, H = s->image_height;
     GeomView g = geom_view(geometry, P);
     BinView b = bin_view(const_cast<void*>(binning), P, R, W, H, s->channels);
@@ -452,20 +446,23 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     // figure can be held against the per-kernel rocprofv3 average)
     const size_t gacc_n = (size_t)gacc_row_floats(C) * (size_t)P;
     const bool det = g_deterministic != 0;
-    if (det)
-        SR_HIP_CHECK(hipMemsetAsync(b.gacc64, 0, sizeof(long long) * gacc_n, stream));
-    else
+    long long* gacc64 = nullptr;   // debug mode only: stream-ordered scratch, freed below (never part of `binning`)
+    if (det) {
+        SR_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&gacc64), sizeof(long long) * gacc_n, stream));
+        SR_HIP_CHECK(hipMemsetAsync(gacc64, 0, sizeof(long long) * gacc_n, stream));
+    } else {
         SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * gacc_n, stream));
+    }
     {
         StageTimer t(SPLATRASTER_STAGE_COMPOSITE_BWD, stream);
         st = launch_composite_bwd(*s, P, R, g, b, im, (C % 4) ? b.featp : feat, C, out_color, out_depth, dL_dout_color,
-                                  dL_dout_depth, dL_dout_alpha, b.gacc, det ? b.gacc64 : nullptr, stream);
+                                  dL_dout_depth, dL_dout_alpha, b.gacc, gacc64, stream);
+    }
+    if (det) {
+        if (!st) st = launch_fixed_to_float((int64_t)gacc_n, gacc64, b.gacc, stream);
+        (void)hipFreeAsync(gacc64, stream);
     }
     if (st) return st;
-    if (det) {
-        st = launch_fixed_to_float((int64_t)gacc_n, b.gacc64, b.gacc, stream);
-        if (st) return st;
-    }
     StageTimer t(SPLATRASTER_STAGE_PREPROCESS_BWD, stream);
     return launch_preprocess_bwd(*s, P, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                  campos, radii, g.clamped, g.rec, b.gacc, C, shs ? nullptr : dL_dcolors, dL_dmeans3D,
@@ -522,8 +519,6 @@ int splatraster_sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, int32_
     if (!keys || !vals || !tmp) return SPLATRASTER_ERR_BAD_ARG;
     {
         int st0 = lookback_error_init();
-        if (st0) return st0;
-        st0 = lookback_error_poll();
         if (st0) return st0;
     }
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

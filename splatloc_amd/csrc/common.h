@@ -76,7 +76,6 @@ struct BinView {
     uint8_t* imask;       // [R] bit q: the Gaussian may reach quadrant q of its tile
     float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows)
     float* gacc;          // [P * gacc_row_floats(C)] backward gradient accumulator rows
-    long long* gacc64;    // same shape, 2^-40 fixed point: the deterministic debug mode's accumulator
 };
 struct ImgView {
     float* final_T;

@@ -106,6 +106,9 @@ __device__ __forceinline__ float exp2_shared(float x)
 #ifdef SR_EXP2_HW
     return __builtin_amdgcn_exp2f(x);
 #else
+    // clamp first, exactly like orc_exp2: x = -inf would make f = NaN (and min(0.99, o * NaN) = 0.99, a spurious
+    // opaque hit), and (int)n of an out-of-range float is undefined.  2^-200 flushes to 0 in ldexp either way.
+    x = fminf(fmaxf(x, -200.0f), 200.0f);
     const float n = __builtin_rintf(x);
     const float f = x - n;
     float p = fmaf(EXP2_C5, f, EXP2_C4);

@@ -56,10 +56,12 @@ densify_flags_kernel(int P, int SC, const float* __restrict__ scaling, const flo
     const bool gate = !h.primitive_reg || marker[i] <= 0.005f;   // key primitives are never pruned
     const bool low = op < h.min_opacity;
     const bool prune_self = (low || (h.use_size_prune && smax > h.size_prune)) && gate;
-    // a child's stored scale is log(s / 1.6); the prune looks at exp of that
+    // a child's stored scale is log(s / 1.6); the prune looks at exp of that.  torch on the GPU evaluates
+    // `t / 1.6` (gaussian_model.py:603, a Python scalar divisor) as t * (1 / 1.6f), not as a division: mirrored,
+    // so the prune / size thresholds see the same last bit as the reference on its own device
     float cmax = -3.0e38f;
 #pragma unroll 3
-    for (int k = 0; k < SC; ++k) cmax = fmaxf(cmax, expf(logf(s[k] / 1.6f)));
+    for (int k = 0; k < SC; ++k) cmax = fmaxf(cmax, expf(logf(s[k] * (1.0f / 1.6f))));
     const bool prune_child = (low || (h.use_size_prune && cmax > h.size_prune)) && gate;
     flags[i] = (!split && !prune_self) ? 1u : 0u;
     flags[(size_t)P + i] = (clone && !prune_self) ? 1u : 0u;
@@ -155,7 +157,7 @@ densify_gather_kernel(int P, const uint32_t* __restrict__ flags, const uint32_t*
             dst[1] = (R10 * smp[0] + R11 * smp[1] + R12 * smp[2]) + src[1];
             dst[2] = (R20 * smp[0] + R21 * smp[1] + R22 * smp[2]) + src[2];
         } else if (sec >= 2 && gq == G_SCALING) {
-            for (int k = 0; k < w; ++k) dst[k] = logf(expf(src[k]) / 1.6f);   // / (0.8 * N), N = 2
+            for (int k = 0; k < w; ++k) dst[k] = logf(expf(src[k]) * (1.0f / 1.6f));   // / (0.8 * N), N = 2, as torch divides by a scalar
         } else {
             for (int k = 0; k < w; ++k) dst[k] = src[k];
         }
@@ -390,8 +392,7 @@ int splatraster_densify_plan(const splatraster_model* model, const float* xyz_gr
     st = densify_plan(model->P, model->scaling_width, model->scaling, model->opacity, model->marker, xyz_gradient_accum,
                       denom, max_grad, min_opacity, extent, percent_dense, use_size_prune, primitive_reg, workspace, new_P,
                       reinterpret_cast<hipStream_t>(stream));
-    if (st) return st;
-    return lookback_error_poll();
+    return st;
 }
 
 int splatraster_densify_apply(const splatraster_model* model, const splatraster_model* exp_avg,

@@ -9,6 +9,8 @@
 //          stable rank among equal digits; per-wave digit counters live in LDS.
 // Stability: keys are consumed in (block, wave, iteration, lane) order == memory order.
 // Both kernels are HBM-bound: per pass 2 key reads + 1 value read + 1 key/value write.
+#include <mutex>
+
 #include "common.h"
 
 namespace sr {
@@ -136,13 +138,17 @@ scan_apply_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ pe
 // ---- look-back watchdog ------------------------------------------------------------------
 // The decoupled look-backs below spin on predecessors that already hold a ticket, so they always
 // make progress on a healthy GPU.  They never give up with a partial prefix — a wrong prefix would be
-// a silently mis-sorted frame, and garbage offsets send the downstream kernels out of bounds.  Instead
-// a block that has waited longer than the spin bound raises a flag in HOST-mapped pinned memory
-// (system-scope store) and KEEPS WAITING: the result of the call is either correct or (wedged GPU)
-// never arrives, and every C-ABI entry point polls that word (lookback_error_poll) and returns
-// SPLATRASTER_ERR_HIP, so a stalling device is reported instead of hanging unexplained.  The bound is
-// a device global so that tests/test_gpu_edge_cases.py can force the report
+// a silently mis-sorted frame, and garbage offsets send the downstream kernels out of bounds.  Two bounds:
+//   soft (g_spin_limit, default 2^24 spins): the block raises a flag in HOST-mapped pinned memory
+//        (system-scope store) and KEEPS WAITING.  Results are late, never wrong, so this is NOT an error of
+//        any frame: only splatraster_poll_errors() reports it (SPLATRASTER_WARN_LOOKBACK_STALL) — forward /
+//        backward keep returning OK for their correct results;
+//   hard (2^30 spins, minutes): the predecessor is never going to publish (wedged device / lost block).
+//        The block executes s_trap: the kernel aborts and every later HIP call on the device returns an
+//        error, which the C ABI surfaces as SPLATRASTER_ERR_HIP — a wedge is a fault, not a silent hang.
+// The soft bound is a device global so that tests/test_gpu_edge_cases.py can force the report
 // (splatraster_debug_set_spin_limit).
+constexpr uint32_t SPIN_HARD_LIMIT = 1u << 30;
 __device__ uint32_t* g_err_sink = nullptr;          // device address of the host flag word
 __device__ uint32_t g_spin_limit = 1u << 24;
 
@@ -155,12 +161,14 @@ __device__ __forceinline__ void lookback_timeout(uint32_t* state_error)
 
 constexpr int MAX_DEVICES = 64;
 static uint32_t* g_err_host[MAX_DEVICES] = {};       // pinned, mapped; one word per device
+static std::mutex g_err_mu;                          // several host threads may make their first call at once
 
 int lookback_error_init()
 {
     int dev = 0;
     SR_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEVICES) return SPLATRASTER_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(g_err_mu);
     if (g_err_host[dev]) return SPLATRASTER_OK;
     uint32_t* h = nullptr;
     SR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped | hipHostMallocPortable));
@@ -172,16 +180,21 @@ int lookback_error_init()
     return SPLATRASTER_OK;
 }
 
-// SPLATRASTER_ERR_HIP once for every raised flag (the flag is cleared), else OK
+// SPLATRASTER_WARN_LOOKBACK_STALL once for every raised soft flag (the flag is cleared), else OK.  Only
+// splatraster_poll_errors() calls this: a soft stall never fails the frame that was late.
 int lookback_error_poll()
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES || !g_err_host[dev]) return SPLATRASTER_OK;
-    volatile uint32_t* h = g_err_host[dev];
-    if (*h == 0u) return SPLATRASTER_OK;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return SPLATRASTER_OK;
+    volatile uint32_t* h;
+    {
+        std::lock_guard<std::mutex> lk(g_err_mu);
+        h = g_err_host[dev];
+    }
+    if (!h || *h == 0u) return SPLATRASTER_OK;
     *h = 0u;
     set_error_text("look-back watchdog: a scan / radix-sort block waited longer than the spin bound for a predecessor (stalling device); results are late, never wrong");
-    return SPLATRASTER_ERR_HIP;
+    return SPLATRASTER_WARN_LOOKBACK_STALL;
 }
 
 int lookback_set_spin_limit(uint32_t limit)
@@ -257,6 +270,7 @@ scan_onepass_kernel(int64_t n, const uint32_t* in, const uint32_t* __restrict__ 
                 const uint64_t need = first == WAVE - 1 ? ~0ull : ((1ull << (first + 1)) - 1ull);
                 if ((ready & need) != need) {
                     if (++spins > g_spin_limit && !reported) { reported = true; if (lane == 0) lookback_timeout(&st->error); }
+                    if (spins > SPIN_HARD_LIMIT) __builtin_trap();   // wedged: fault instead of hanging for ever
                     __builtin_amdgcn_s_sleep(1);
                     continue;
                 }
@@ -608,6 +622,7 @@ sort_sweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in, const uint32_
                 pb -= used;
                 if (used == 0) {
                     if (++spins > g_spin_limit && !reported) { reported = true; lookback_timeout(&st->error); }
+                    if (spins > SPIN_HARD_LIMIT) __builtin_trap();   // wedged: fault instead of hanging for ever
                     __builtin_amdgcn_s_sleep(1);
                 }
             }

@@ -161,30 +161,27 @@ def test_forward_under_no_grad_like_eval_rendering():
 
 
 def test_lookback_stall_is_reported_and_never_wrong():
-    """A decoupled look-back (one-pass scan / one-sweep radix sort) that waits longer than its spin bound
-    must surface as a status code, and must never produce a wrong prefix: with the bound forced to 0
-    every block that has to wait at all raises the host-mapped watchdog flag — a C-ABI call fails with
-    SPLATRASTER_ERR_HIP — yet keeps waiting, so the frame itself stays bit-exact."""
+    """A decoupled look-back (one-pass scan / one-sweep radix sort) that waits longer than its SOFT spin bound
+    keeps waiting, so the frame stays bit-exact and the forward call still succeeds; the stall surfaces only
+    through splatraster_poll_errors() as the non-fatal SPLATRASTER_WARN_LOOKBACK_STALL.  With the bound forced
+    to 0 every block that has to wait at all raises the host-mapped flag."""
     from splatloc_amd import _native
     lib = _native.load()
     sc = make_scene(300_000, 640, 480, 3, seed=71, scale_median=0.006)   # 74 sort blocks, 147 scan tiles
     f = oracle_forward(sc)
-    _native.check(lib.splatraster_poll_errors(), "poll (clean start)")
+    assert lib.splatraster_poll_errors() in (0, _native.WARN_LOOKBACK_STALL)   # drain
+    assert lib.splatraster_poll_errors() == 0
     _native.check(lib.splatraster_debug_set_spin_limit(0), "set_spin_limit")
     try:
-        raised = False
+        warned = False
         for _ in range(4):                       # whether a block waits is timing dependent: a few frames make it certain
-            try:
-                run = HipRun(sc, backward=False)
-                torch.cuda.synchronize()
-                # late, never wrong: the sorted list of the frame that reported is still exact
-                assert np.array_equal(run.np(run.state["point_list"]).astype(np.uint32), f["point_list"])
-                _native.check(lib.splatraster_poll_errors(), "poll")
-            except RuntimeError as e:
-                assert "HIP" in str(e) and "look-back" in str(e), str(e)
-                raised = True
+            run = HipRun(sc, backward=False)     # never raises: a late frame is not a failed frame
+            torch.cuda.synchronize()
+            assert np.array_equal(run.np(run.state["point_list"]).astype(np.uint32), f["point_list"])
+            if _native.poll_stall():
+                warned = True
                 break
-        assert raised, "no look-back had to wait in 4 frames of 300k Gaussians?"
+        assert warned, "no look-back had to wait in 4 frames of 300k Gaussians?"
     finally:
         _native.check(lib.splatraster_debug_set_spin_limit(1 << 24), "restore spin limit")
         torch.cuda.synchronize()

@@ -5,7 +5,7 @@ import numpy as np
 
 from oracle import oracle
 from splatloc_amd.synthetic import make_scene
-from tests.helpers import oracle_forward
+from tests.helpers import oracle_backward, oracle_forward
 
 
 def test_exp2_accuracy_and_edges():
@@ -42,3 +42,28 @@ def test_contract_vs_lineage_literal_form():
     d = np.abs(f0["color"] - f1["color"]).max(axis=0)
     assert d[~flipped].max() <= 2e-6 and d.max() <= 1.0 / 255.0 + 1e-6
     assert np.abs(f0["final_T"] - f1["final_T"])[~flipped].max() <= 2e-6
+
+
+def test_contract_vs_lineage_literal_form_gradients():
+    """The same statement for the BACKWARD: every gradient of the derived contract (mode 0, what the device runs)
+    equals the gradient of the lineage-literal spec (mode 1) to rounding — 1e-4 relative + 1e-5 of the tensor's
+    scale, two orders below the float-atomic tolerance of the GPU tests — at BASELINE's config-1 shape (S0) and on a
+    scene of deep lists in the reference's C = 4 layout."""
+    for sc in (make_scene(P=10_000, W=640, H=480, C=3, seed=0, scale_median=0.02),
+               make_scene(P=6000, W=320, H=240, C=4, seed=11, scale_median=0.03)):
+        try:
+            oracle.set_alpha_mode(1)
+            f1 = oracle_forward(sc)
+            b1 = oracle_backward(f1, sc)
+        finally:
+            oracle.set_alpha_mode(0)
+        f0 = oracle_forward(sc)
+        b0 = oracle_backward(f0, sc)
+        flipped = (f0["n_contrib"] != f1["n_contrib"]).mean()
+        assert flipped <= 1e-3
+        for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacities", "dL_dcolors", "dL_dscales", "dL_drotations"):
+            got, ref = b0[k].astype(np.float64), b1[k].astype(np.float64)
+            tol = 1e-4 * np.abs(ref) + 1e-5 * np.abs(ref).max()
+            bad = np.abs(got - ref) > tol
+            # a flipped (pixel, Gaussian) pair moves that Gaussian's sums by one pixel's worth: allowed in proportion
+            assert bad.mean() <= max(flipped, 1e-5) * 50, (k, bad.sum(), flipped)

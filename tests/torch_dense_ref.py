@@ -62,9 +62,10 @@ def render_dense(H, W, tanfovx, tanfovy, bg, means3D, opacities, viewmatrix, pro
     the dL/dmeans2D the extension reports.
     """
     dt = means3D.dtype
+    dev = means3D.device      # fp64 on the GPU as well (tests/test_gpu_dense_ref.py): every tensor follows means3D
     P = means3D.shape[0]
     V, PM = viewmatrix.to(dt), projmatrix.to(dt)
-    ones = torch.ones(P, 1, dtype=dt)
+    ones = torch.ones(P, 1, dtype=dt, device=dev)
     hom = torch.cat([means3D, ones], dim=1)
     pv = hom @ V          # [P,4] view space (row-vector convention)
     ph = hom @ PM
@@ -115,7 +116,7 @@ def render_dense(H, W, tanfovx, tanfovy, bg, means3D, opacities, viewmatrix, pro
     radii = torch.where(ok, radius, torch.zeros_like(radius)).to(torch.int32)
 
     if shs is not None:
-        d = means3D - campos.to(dt)[None]
+        d = means3D - campos.to(device=dev, dtype=dt)[None]
         feat = eval_sh_rgb(sh_degree, shs, d / d.norm(dim=1, keepdim=True))
     else:
         feat = colors_precomp
@@ -125,7 +126,7 @@ def render_dense(H, W, tanfovx, tanfovy, bg, means3D, opacities, viewmatrix, pro
     keyd = torch.where(ok, tz.detach().to(torch.float32).double(), torch.full_like(tz, float("inf")).double())
     order = torch.argsort(keyd, stable=True)
     order = order[ok[order]]
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=dt), torch.arange(W, dtype=dt), indexing="ij")
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=dt, device=dev), torch.arange(W, dtype=dt, device=dev), indexing="ij")
     pxf, pyf = xs.reshape(-1), ys.reshape(-1)                 # [N]
     tpx, tpy = torch.div(pxf, TILE, rounding_mode="floor"), torch.div(pyf, TILE, rounding_mode="floor")
     o = order
@@ -146,12 +147,12 @@ def render_dense(H, W, tanfovx, tanfovy, bg, means3D, opacities, viewmatrix, pro
     alpha = torch.where(stopped, torch.zeros_like(alpha), alpha)
     one_m = 1.0 - alpha
     Tincl = torch.cumprod(one_m, dim=1)
-    Texcl = torch.cat([torch.ones(Tincl.shape[0], 1, dtype=dt), Tincl[:, :-1]], dim=1)
+    Texcl = torch.cat([torch.ones(Tincl.shape[0], 1, dtype=dt, device=dev), Tincl[:, :-1]], dim=1)
     w = alpha * Texcl                                            # [N,G]
-    Tfin = Tincl[:, -1] if Tincl.shape[1] else torch.ones(H * W, dtype=dt)
-    bgf = torch.zeros(Cn, dtype=dt)
+    Tfin = Tincl[:, -1] if Tincl.shape[1] else torch.ones(H * W, dtype=dt, device=dev)
+    bgf = torch.zeros(Cn, dtype=dt, device=dev)
     nb = min(Cn, bg.numel())
-    bgf[:nb] = bg.to(dt)[:nb]
+    bgf[:nb] = bg.to(device=dev, dtype=dt)[:nb]
     color = (w @ feat[o]) + Tfin[:, None] * bgf[None]
     depth = w @ tz[o]
     alpha_img = 1.0 - Tfin
