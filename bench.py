@@ -5,9 +5,12 @@ One "step" = one optimisation step of SplatLoc.map as far as the rasterizer is c
 (train_gaussians.py:187-229): `--views` = 5 frames (the reference's window_size, configs/*/
 base_config.yaml: window_size: 5) seen from 5 DIFFERENT cameras (the reference draws 5 different
 key-frames, train_gaussians.py:195), each one forward + one backward pass of the rasterizer hot
-path (diff_gauss.GaussianRasterizer through the C ABI) over the synthetic workload S2 (500k
-Gaussians, 1920x1080, 35 channels: RGB + 32 feature channels, + depth + alpha), inputs resident
-in HBM, gradients accumulated over the window.
+path over the synthetic workload S2 (500k Gaussians, 1920x1080, 35 channels: RGB + 32 feature
+channels, + depth + alpha), inputs resident in HBM, gradients accumulated over the window, the
+per-view densification statistics updated (train_gaussians.py:238-245).  By default the window goes
+through the window-batched C-ABI sequence (splatloc_amd.rasterize_window: ONE preprocess / depth sort /
+tile sort / compositing grid for the 5 views, per-view results bit-identical to 5 calls);
+`--no-window` runs the reference's loop of 5 diff_gauss.GaussianRasterizer calls instead.
 
 N > 1 ranks (one process per GPU, RCCL over xGMI), full scene replica per rank:
   --scaling weak   (default) every rank renders its OWN window of 5 views (different per rank);
@@ -506,7 +509,10 @@ def main():
                     help="HIP streams the views of a window are spread over (1 = the reference's serial loop)")
     ap.add_argument("--densify-every", type=int, default=10,
                     help="--stage map_step: densify_and_prune every N steps (the reference: 150, offset 50)")
-    ap.add_argument("--no-multi-stream", action="store_true", help="skip the secondary multi-stream legs (profiling runs)")
+    ap.add_argument("--no-window", action="store_true",
+                    help="render the window as a loop of per-view GaussianRasterizer calls (the reference's loop) instead of "
+                         "ONE window-batched launch sequence")
+    ap.add_argument("--no-multi-stream", action="store_true", help="skip the secondary legs (per-view loop, multi-stream) (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
     ap.add_argument("--stage", default="raster", choices=["raster", "activations", "loss", "map_step"],
@@ -540,7 +546,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer, _native
+    from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer, _native, rasterize_window
     from splatloc_amd.camera import PinholeCamera
     from splatloc_amd.densify import add_densification_stats
     from splatloc_amd.frame_parallel import allreduce_grads, shard_views, sync_densification_stats
@@ -566,7 +572,7 @@ def main():
                                            cam.full_proj_transform, 0, cam.camera_center, False, False)
         # a different dL/dout per view: the seeded gradient images, rolled
         g = tuple(torch.roll(t, shifts=37 * j, dims=-1).contiguous() for t in (sc.dL_dcolor, sc.dL_ddepth, sc.dL_dalpha))
-        return GaussianRasterizer(raster_settings=rs), g
+        return GaussianRasterizer(raster_settings=rs), g, rs
 
     if args.scaling == "strong":
         my_ids = shard_views(list(range(args.views)), rank, world)
@@ -580,6 +586,21 @@ def main():
     info = {"R": [], "V": []}
 
     side = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
+    mode = {"window": not args.no_window and args.streams <= 1}
+
+    def window_step(record):
+        # the whole window as ONE launch sequence: forward of the V views, ONE backward that sums their parameter
+        # gradients in-kernel, then the per-view densification statistics (train_gaussians.py:238-245)
+        carriers = [torch.zeros_like(means3D, requires_grad=True) for _ in views]   # render(): screenspace_points per view
+        outs = rasterize_window([rs for _, _, rs in views], means3D, carriers, colors, opac, scales=scales, rotations=rots)
+        if record:
+            for k in range(0, len(outs), 8):
+                info["R"] += [int(r) for r in outs[k][0].grad_fn.R]
+            info["V"] += [int((o[3] > 0).sum().item()) for o in outs]
+        if not args.fwd_only:
+            torch.autograd.backward([t for o in outs for t in o[:3]], [g for _, gs, _ in views for g in gs])
+            for m2, o in zip(carriers, outs):
+                add_densification_stats(m2.grad, o[3], accum, denom, max_radii)
 
     def one_view(rast, g_out, record):
         means2D = torch.zeros_like(means3D, requires_grad=True)   # per-view grad carrier (render(): screenspace_points)
@@ -590,8 +611,8 @@ def main():
             info["V"].append(int((radii > 0).sum().item()))
         if not args.fwd_only:
             torch.autograd.backward((color, depth, alpha), g_out)
-            if world > 1:   # the step's densification statistics (train_gaussians.py:238-245)
-                add_densification_stats(means2D.grad, radii, accum, denom, max_radii)
+            # the step's densification statistics (train_gaussians.py:238-245): the same per-frame work at every N
+            add_densification_stats(means2D.grad, radii, accum, denom, max_radii)
 
     def step(record=False):
         for p in params:
@@ -599,20 +620,22 @@ def main():
         if world > 1:
             accum.zero_()
             denom.zero_()
-        if side:
+        if mode["window"] and views:
+            window_step(record)
+        elif side:
             # the views of a window are independent until their gradients are summed: view j runs on HIP stream
             # j % K, so the latency-bound kernels of a small frame overlap with another view's (autograd runs
             # each backward on its forward's stream and orders the accumulation into .grad)
             main = torch.cuda.current_stream(dev)
             for st in side:
                 st.wait_stream(main)
-            for j, (rast, g_out) in enumerate(views):
+            for j, (rast, g_out, _) in enumerate(views):
                 with torch.cuda.stream(side[j % len(side)]):
                     one_view(rast, g_out, record)
             for st in side:
                 main.wait_stream(st)
         else:
-            for rast, g_out in views:   # every frame one forward + one backward, parameter gradients accumulate
+            for rast, g_out, _ in views:   # every frame one forward + one backward, parameter gradients accumulate
                 one_view(rast, g_out, record)
         if not args.fwd_only and world > 1:
             # ONE SUM all-reduce of the accumulated parameter gradients (a rank without views in strong
@@ -663,8 +686,10 @@ def main():
     # measured under overlap are not the dominant kernel's own, so the roofline stays on the serial run.
     multi_stream = []
     if world == 1 and not side and not args.fwd_only and len(views) > 1 and not args.no_multi_stream:
-        for K in (2, 4):
-            side[:] = [torch.cuda.Stream(device=dev) for _ in range(K)]
+        was_window = mode["window"]
+        mode["window"] = False
+        for K in ((1, 2, 4) if was_window else (2, 4)):      # K = 1: the reference's loop of per-view calls
+            side[:] = [torch.cuda.Stream(device=dev) for _ in range(K)] if K > 1 else []
             for _ in range(2):
                 step()
             barrier()
@@ -673,9 +698,11 @@ def main():
                 step()
             barrier()
             el = time.perf_counter() - ts
-            multi_stream.append({"streams": K, "value": round(frames_per_step * args.steps / el, 3),
+            multi_stream.append({"path": "per-view GaussianRasterizer calls", "streams": K,
+                                 "value": round(frames_per_step * args.steps / el, 3),
                                  "ms_per_step": round(1e3 * el / args.steps, 4)})
         side[:] = []
+        mode["window"] = was_window
 
     if rank == 0:
         Rs, Vs = info["R"], info["V"]
@@ -686,25 +713,45 @@ def main():
         act_bytes = actual_bytes(P, V, R, W, H, C, tiles)
         ms_per_step = 1e3 * elapsed / args.steps
         value = frames_per_step * args.steps / elapsed
+        # units per launch: a window-batched launch processes the frames of all the rank's views at once
+        vpl = max(len(views), 1) if mode["window"] else 1
         per_stage = {}
         for s, (ms, cnt) in stages.items():
             if cnt:
                 avg = ms / cnt
-                per_stage[s] = {"avg_ms": round(avg, 4), "launches": int(cnt), "lineage_bytes": int(st_bytes[s]),
-                                "actual_bytes": int(act_bytes[s]),
-                                "actual_GBps": round(act_bytes[s] / (avg * 1e-3) / 1e9, 1)}
+                per_stage[s] = {"avg_ms": round(avg, 4), "launches": int(cnt), "frames_per_launch": vpl,
+                                "lineage_bytes": int(st_bytes[s]) * vpl, "actual_bytes": int(act_bytes[s]) * vpl,
+                                "actual_GBps": round(act_bytes[s] * vpl / (avg * 1e-3) / 1e9, 1)}
         per_stage[dom]["measured"] = "live in the timed region"
         dom_avg = stages[dom][0] / max(stages[dom][1], 1)
-        ach = round(st_bytes[dom] / (dom_avg * 1e-3) / 1e9, 1)     # roofline: SURVEY §8d algorithmic bytes / duration
+        ach = round(st_bytes[dom] * vpl / (dom_avg * 1e-3) / 1e9, 1)     # roofline: SURVEY §8d algorithmic bytes / duration
+        # Counter-derived figures are REPLAYS of the builder's rocprofv3 runs (profiles/*.json), not live
+        # measurements: they are attached only when the stored run is this workload in this launch mode.
         prof = {}
         for name in ("traffic.json", "valu.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath):
                 try:
-                    prof[name] = json.load(open(tpath))
+                    j = json.load(open(tpath))
+                    if j.get("_workload", "S2") == args.workload and int(j.get("_frames_per_launch", 1)) == vpl:
+                        prof[name] = j
                 except Exception:  # noqa: BLE001
                     pass
         traffic = prof.get("traffic.json", {}).get(dom)
+        valu = prof.get("valu.json")
+        roofline_valu = None
+        if valu:
+            # the binding bound of the compositing kernels as a fraction: a wave64 VALU instruction occupies its
+            # SIMD's issue port for 4 cycles (quad-cycle), 1024 SIMDs: issue fraction = wave-instr x 4 / (1024 x cycles)
+            roofline_valu = {"source": "profiles/valu.json (builder rocprofv3 SQ-counter run, same workload and launch mode)",
+                             "bound": "valu-issue", "kernels": {}}
+            for k, c in valu.items():
+                if isinstance(c, dict) and c.get("kernel_cycles"):
+                    cyc = c["kernel_cycles"]
+                    roofline_valu["kernels"][k] = {
+                        "valu_issue_frac": round((c["valu_wave_instructions"] + c.get("mfma_wave_instructions", 0)) * 4 / (1024 * cyc), 4),
+                        "valu_busy": c.get("valu_busy"), "mfma_busy": c.get("mfma_busy"),
+                        "salu_per_valu": round(c.get("salu_wave_instructions", 0) / max(c["valu_wave_instructions"], 1), 3)}
         out = {
             "metric": "fwd+bwd frames/s @1080p, 500k Gaussians, 32 feat-ch; HBM GB/s vs roofline",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -717,18 +764,25 @@ def main():
                        "tile_instances_R": R, "visible_gaussians_V": V,
                        "frames_per_step": frames_per_step, "views_on_rank0_per_step": len(views),
                        "hip_streams_per_window": max(args.streams, 1),
+                       "launch_mode": ("window-batched: one launch sequence per window of views (splatraster_forward_window_* / "
+                                       "splatraster_backward_window)") if mode["window"] else "one launch sequence per view",
+                       "per_view_densification_stats_in_step": True,
                        "parallelism": f"frame-parallel dp{world}, scene replica per GPU"
                                       + (", one RCCL SUM all-reduce of the accumulated parameter grads + densification-"
                                          "statistics sync per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(st_bytes[dom]), "avg_ms": round(dom_avg, 4),
-                         "note": "composite kernels are VALU/LDS-bound, not HBM-bound (DESIGN.md); see frame_valu"},
+                         "traffic_source": ("profiles/traffic.json (builder rocprofv3 PMC run of this workload and launch mode; "
+                                            "a replay, not measured live)") if traffic is not None else None,
+                         "frames_per_launch": vpl,
+                         "algorithmic_bytes_per_launch": int(st_bytes[dom]) * vpl, "avg_ms": round(dom_avg, 4),
+                         "note": "composite kernels are VALU-issue-bound, not HBM-bound (DESIGN.md); see roofline_valu"},
+            "roofline_valu": roofline_valu,
             "frame_hbm": {"algorithmic_bytes_per_frame": frame_bytes, "lineage_radix_passes": n_pass,
                           "achieved_GBps": round(frame_bytes * value / world / 1e9, 1),
                           "frac_of_peak": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5),
                           "ms_per_frame": round(ms_per_step / max(len(views), 1), 4)},
-            "frame_valu": prof.get("valu.json"),
+            "frame_valu": valu,
             "multi_stream": multi_stream or None,
             "stages": per_stage,
             "stages_note": f"per-stage table from {BREAKDOWN_STEPS} untimed steps with every stage bracketed by HIP "

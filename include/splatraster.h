@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 4
+#define SPLATRASTER_ABI_VERSION 5
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
@@ -159,6 +159,71 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R,
                          float* dL_dcampos,     /* [3] or NULL (non-zero only with shs) */
                          void* stream);
 
+/* ---- a WINDOW of views in one launch sequence -------------------------------------------- */
+
+/*
+ * SplatLoc.map renders `window_size` (5) views of one Gaussian scene, sums their losses and runs ONE
+ * backward (train_gaussians.py:195-229); color_refinement and eval_rendering call the rasterizer once per
+ * view.  The reference extension has only the per-view call, so that loop is 5 x (preprocess, two sorts,
+ * compositing) + autograd's accumulation of 5 gradient sets.  These entry points take the V <= 8 views of a
+ * window at once: one preprocess over the P Gaussians for all views, ONE depth sort of the V * P (view,
+ * Gaussian) rows, ONE tile sort keyed by (view, tile), one compositing grid over V * tiles * 4 quadrant-waves —
+ * a 640x480 frame alone leaves most of an MI355X idle — and a backward that sums the V views into ONE set of
+ * parameter gradients.  Results per view are bit-identical to V calls of the functions above (both sorts are
+ * stable: every (view, tile) list is in (depth, index) order); only the float-atomic summation order of the
+ * gradients differs, as it does from run to run anyway.  All views share the settings' image size, channel
+ * count, scale modifier and background; tanfovx / tanfovy are per view (settings->tanfovx/y are ignored here).
+ * Colours must be precomputed (`colors_precomp`, SplatLoc's configuration): view-dependent SH colours and the
+ * pose-gradient extension stay on the per-view call (SPLATRASTER_ERR_UNSUPPORTED here).
+ */
+#define SPLATRASTER_MAX_WINDOW_VIEWS 8
+
+typedef struct splatraster_window_view {
+    const float* viewmatrix; /* [4,4] device memory, row-vector convention */
+    const float* projmatrix; /* [4,4] view @ proj */
+    const float* campos;     /* [3] or NULL (unused with precomputed colours) */
+    float tanfovx, tanfovy;
+    int32_t* radii;          /* [P] int32: forward output (4th member of the tuple), read again by the backward */
+    float* out_color;        /* [C,H,W] forward output; read by the backward */
+    float* out_depth;        /* [1,H,W] */
+    float* out_alpha;        /* [1,H,W] */
+    /* backward only (ignored by the forward calls) */
+    const float* dL_dout_color; /* [C,H,W] */
+    const float* dL_dout_depth; /* [1,H,W] or NULL (= zeros) */
+    const float* dL_dout_alpha; /* [1,H,W] or NULL (= zeros) */
+    float* dL_dmeans2D;         /* [P,3] output: per view, as GaussianModel.add_densification_stats reads it */
+} splatraster_window_view;
+
+size_t splatraster_window_geometry_bytes(int32_t P, int32_t n_views);
+size_t splatraster_window_binning_bytes(int32_t P, int32_t n_views, int64_t R_total, int32_t width, int32_t height,
+                                        int32_t channels);
+size_t splatraster_window_image_bytes(int32_t width, int32_t height, int32_t n_views);
+
+/* Stage 1: num_rendered[v] = tile instances of view v (one stream synchronisation for the whole window). */
+int splatraster_forward_window_geometry(const splatraster_settings* s, int32_t n_views,
+                                        const splatraster_window_view* views, int32_t P,
+                                        const float* means3D, const float* opacities, const float* scales,
+                                        const float* rotations, const float* cov3D_precomp, void* geometry,
+                                        int64_t* num_rendered /* [n_views] */, void* stream);
+/* Stage 2: `binning` holds splatraster_window_binning_bytes(P, n_views, sum(num_rendered), W, H, C) bytes. */
+int splatraster_forward_window_render(const splatraster_settings* s, int32_t n_views,
+                                      const splatraster_window_view* views, int32_t P,
+                                      const int64_t* num_rendered, const float* bg, const float* colors_precomp,
+                                      void* geometry, void* binning, void* image, void* stream);
+/* Backward of the whole window: the parameter gradients are the SUM over the views (written once, overwritten),
+ * dL_dmeans2D per view. */
+int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
+                                int32_t P, const int64_t* num_rendered, const float* means3D,
+                                const float* colors_precomp, const float* scales, const float* rotations,
+                                const float* cov3D_precomp, void* geometry, const void* binning, const void* image,
+                                float* dL_dmeans3D,   /* [P,3] */
+                                float* dL_dcolors,    /* [P,C] */
+                                float* dL_dopacities, /* [P,1] */
+                                float* dL_dscales,    /* [P,3] or NULL */
+                                float* dL_drotations, /* [P,4] or NULL */
+                                float* dL_dcov3D,     /* [P,6] or NULL */
+                                void* stream);
+
 /* ---- auxiliary entry points ---------------------------------------------------------- */
 
 /* present[i] = 1 when Gaussian i passes the near-plane test (view-space z > 0.2).
@@ -192,6 +257,13 @@ int splatraster_get_geometry_layout(int32_t P, splatraster_geometry_layout* out)
 int splatraster_get_binning_layout(int32_t P, int64_t R, int32_t width, int32_t height, int32_t channels,
                                    splatraster_binning_layout* out);
 int splatraster_get_image_layout(int32_t width, int32_t height, splatraster_image_layout* out);
+/* the same for the buffers of a window: arrays indexed by Gaussian hold n_views * P rows (row v * P + i), the
+ * instance lists hold rows and GLOBAL tile ids v * tiles + t, `ranges` has 2 * n_views * tiles entries and the
+ * per-pixel planes n_views * H * W */
+int splatraster_get_window_geometry_layout(int32_t P, int32_t n_views, splatraster_geometry_layout* out);
+int splatraster_get_window_binning_layout(int32_t P, int32_t n_views, int64_t R_total, int32_t width, int32_t height,
+                                          int32_t channels, splatraster_binning_layout* out);
+int splatraster_get_window_image_layout(int32_t width, int32_t height, int32_t n_views, splatraster_image_layout* out);
 
 /* Stable LSD radix sort of (key, value) pairs on key bits [0, key_bits); exposed so the
  * sort can be tested and timed on its own.  tmp must hold splatraster_sort_tmp_bytes(n). */
@@ -400,6 +472,9 @@ int splatraster_debug_set_spin_limit(uint32_t limit);
  * the totals are bit-reproducible; range +-8.4e6, resolution 9.1e-13), then converted back.  ~10 % slower;
  * meant for regression hunting and strict tests (tests/test_gpu_parity.py). */
 int splatraster_debug_set_deterministic(int on);
+/* A/B hook: launches of the C = 4..15 backward with at most this many quadrant-waves take the small-layout panel
+ * variant; < 0 restores the built-in default. */
+int splatraster_debug_set_small_panel_max_waves(int waves);
 int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
 
 const char* splatraster_error_string(int status);

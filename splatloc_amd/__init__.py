@@ -9,8 +9,10 @@ from .rasterizer import (  # noqa: F401
     GaussianRasterizationSettings,
     GaussianRasterizer,
     rasterize_gaussians,
+    rasterize_window,
     _RasterizeGaussians,
+    _RasterizeWindow,
 )
 from .knn import distCUDA2  # noqa: F401
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "distCUDA2"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_window", "distCUDA2"]

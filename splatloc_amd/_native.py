@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 4   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 5   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 WARN_LOOKBACK_STALL = 5   # splatraster_poll_errors() only; not an error of any frame
@@ -34,6 +34,18 @@ class Settings(C.Structure):
         ("prefiltered", C.c_int32),
         ("debug", C.c_int32),
     ]
+
+
+MAX_WINDOW_VIEWS = 8   # SPLATRASTER_MAX_WINDOW_VIEWS
+
+
+class WindowView(C.Structure):
+    """struct splatraster_window_view"""
+    _fields_ = [("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+                ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("radii", C.c_void_p), ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p),
+                ("dL_dout_color", C.c_void_p), ("dL_dout_depth", C.c_void_p), ("dL_dout_alpha", C.c_void_p),
+                ("dL_dmeans2D", C.c_void_p)]
 
 
 class GeometryLayout(C.Structure):
@@ -73,6 +85,19 @@ SYMBOLS = {
     "splatraster_forward_geometry": (C.c_int, [C.POINTER(Settings), _i32] + [_vp] * 9 + [_vp, _vp, C.POINTER(_i64), _vp]),
     "splatraster_forward_render": (C.c_int, [C.POINTER(Settings), _i32, _i64] + [_vp] * 9),
     "splatraster_backward": (C.c_int, [C.POINTER(Settings), _i32, _i64] + [_vp] * 33),
+    "splatraster_window_geometry_bytes": (_sz, [_i32, _i32]),
+    "splatraster_window_binning_bytes": (_sz, [_i32, _i32, _i64, _i32, _i32, _i32]),
+    "splatraster_window_image_bytes": (_sz, [_i32, _i32, _i32]),
+    "splatraster_forward_window_geometry": (C.c_int, [C.POINTER(Settings), _i32, C.POINTER(WindowView), _i32] + [_vp] * 6
+                                            + [C.POINTER(_i64), _vp]),
+    "splatraster_forward_window_render": (C.c_int, [C.POINTER(Settings), _i32, C.POINTER(WindowView), _i32, C.POINTER(_i64)]
+                                          + [_vp] * 6),
+    "splatraster_backward_window": (C.c_int, [C.POINTER(Settings), _i32, C.POINTER(WindowView), _i32, C.POINTER(_i64)]
+                                    + [_vp] * 15),
+    "splatraster_get_window_geometry_layout": (C.c_int, [_i32, _i32, C.POINTER(GeometryLayout)]),
+    "splatraster_get_window_binning_layout": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _i32, C.POINTER(BinningLayout)]),
+    "splatraster_get_window_image_layout": (C.c_int, [_i32, _i32, _i32, C.POINTER(ImageLayout)]),
+    "splatraster_debug_set_small_panel_max_waves": (C.c_int, [C.c_int]),
     "splatraster_mark_visible": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_get_geometry_layout": (C.c_int, [_i32, C.POINTER(GeometryLayout)]),
     "splatraster_get_binning_layout": (C.c_int, [_i32, _i64, _i32, _i32, _i32, C.POINTER(BinningLayout)]),

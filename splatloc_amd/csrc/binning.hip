@@ -30,8 +30,12 @@ constexpr int EMIT_BLOCK = 256;
 constexpr int EMIT_IPT = 4;
 static_assert(EMIT_SPAN == EMIT_BLOCK * EMIT_IPT, "common.h: EMIT_SPAN");
 
+// A window of V views: the n = V * P rows of all views are in ONE depth order; row g = v * P + i emits the
+// global tile ids v * tiles + t of its rect, so the single stable tile sort that follows leaves every
+// (view, tile) list in (depth, index) order — exactly what V separate calls produce.
 __global__ void __launch_bounds__(EMIT_BLOCK)
-emit_kernel(int64_t R, int P, int W, int H, const uint32_t* __restrict__ offsets,
+emit_kernel(int64_t R, int P /*rows: V * P*/, int Pv /*Gaussians per view*/, int tiles_per_view, int W, int H,
+            const uint32_t* __restrict__ offsets,
             const uint32_t* __restrict__ depth_order, const float4* __restrict__ rec,
             uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
             const uint32_t* __restrict__ span_owner /* first rank of span k, or NULL */,
@@ -91,7 +95,8 @@ emit_kernel(int64_t R, int P, int W, int H, const uint32_t* __restrict__ offsets
         const int rminy = min(gy, max(0, f2i_sat_b((p.y - rf) / (float)TILE)));
         const int rmaxx = min(gx, max(0, f2i_sat_b((p.x + rf + (float)(TILE - 1)) / (float)TILE)));
         s_gid[q] = g;
-        s_org[q] = (uint32_t)rminy * (uint32_t)gx + (uint32_t)rminx;  // tile id of the rect's first tile
+        const uint32_t v = (P == Pv) ? 0u : g / (uint32_t)Pv;   // once per row, not per instance
+        s_org[q] = v * (uint32_t)tiles_per_view + (uint32_t)rminy * (uint32_t)gx + (uint32_t)rminx;  // global id of the rect's first tile
         s_w[q] = (uint32_t)(rmaxx - rminx);
     }
     __syncthreads();
@@ -114,14 +119,16 @@ emit_kernel(int64_t R, int P, int W, int H, const uint32_t* __restrict__ offsets
     }
 }
 
-int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
+int launch_emit(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g, uint32_t* keys,
                 uint32_t* vals, uint32_t* ranges, uint32_t nranges, hipStream_t stream)
 {
     if (R == 0) return SPLATRASTER_OK;
     const int64_t blocks = (R + EMIT_SPAN - 1) / EMIT_SPAN;
-    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)blocks), dim3(EMIT_BLOCK), 0, stream, R, P, s.image_width,
+    const int n = P * V;
+    const int tiles = ((s.image_width + TILE - 1) / TILE) * ((s.image_height + TILE - 1) / TILE);
+    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)blocks), dim3(EMIT_BLOCK), 0, stream, R, n, P, tiles, s.image_width,
                        s.image_height, g.offsets, g.depth_order, g.rec, keys, vals,
-                       scan_state_bytes(P) ? g.span_owner : nullptr, ranges, nranges);
+                       scan_state_bytes(n) ? g.span_owner : nullptr, ranges, nranges);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
@@ -140,7 +147,7 @@ int launch_ranges_clear(int32_t tiles, uint32_t* ranges, hipStream_t stream)
 //   irec[2j] = (pixel x, y, depth, radius) of point_list[j], irec[2j+1] = its conic pre-scaled for
 //   the compositing kernels (payload_conic) and opacity;  imask[j] = reach bits.
 __global__ void __launch_bounds__(256)
-payload_kernel(int64_t R, int gx, const uint32_t* __restrict__ point_list,
+payload_kernel(int64_t R, int gx, int tiles_per_view, int V, const uint32_t* __restrict__ point_list,
                const uint32_t* __restrict__ tile_list, const float4* __restrict__ rec,
                float4* __restrict__ irec, uint8_t* __restrict__ imask, uint32_t* __restrict__ ranges)
 {
@@ -148,7 +155,10 @@ payload_kernel(int64_t R, int gx, const uint32_t* __restrict__ point_list,
     if (j >= R) return;
     const uint32_t g = point_list[j], t = tile_list[j];
     const float4 a0 = rec[2 * (size_t)g], a1 = rec[2 * (size_t)g + 1];  // one 32-byte gather
-    const uint32_t ty = t / (uint32_t)gx, tx = t - ty * (uint32_t)gx;
+    uint32_t tl = t;   // tile inside its view (V <= 8: a few compares instead of a division)
+#pragma unroll 1
+    for (int v = 1; v < V && tl >= (uint32_t)tiles_per_view; ++v) tl -= (uint32_t)tiles_per_view;
+    const uint32_t ty = tl / (uint32_t)gx, tx = tl - ty * (uint32_t)gx;
     irec[2 * j] = a0;
     irec[2 * j + 1] = payload_conic(a1);   // pre-scaled for gauss_log2 (composite_common.h)
     imask[j] = (uint8_t)quadrant_reach_mask(a0, a1, (float)(tx * TILE), (float)(ty * TILE));
@@ -157,11 +167,11 @@ payload_kernel(int64_t R, int gx, const uint32_t* __restrict__ point_list,
     if (j == R - 1 || tile_list[j + 1] != t) ranges[2 * t + 1] = (uint32_t)(j + 1);
 }
 
-int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b, hipStream_t stream)
+int launch_payload(const splatraster_settings& s, int32_t V, int64_t R, const GeomView& g, const BinView& b, hipStream_t stream)
 {
     if (R == 0) return SPLATRASTER_OK;
-    const int gx = (s.image_width + TILE - 1) / TILE;
-    hipLaunchKernelGGL(payload_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, b.point_list,
+    const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
+    hipLaunchKernelGGL(payload_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, gx * gy, V, b.point_list,
                        b.tile_list, g.rec, b.irec, b.imask, b.ranges);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;

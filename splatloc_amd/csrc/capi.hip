@@ -103,9 +103,11 @@ struct GeomLayout {
     size_t rec0, rec1, tiles_touched, depth_order, offsets, rgb, clamped, sort_keys, keys_alt, vals_alt,
         sort_tmp, scan_tmp, total, block_tiles, span_owner, bytes;
 };
-static GeomLayout geom_layout(int32_t P)
+// n = V * P rows (V views of a window; V = 1 for the plain call)
+static GeomLayout geom_layout(int32_t P, int32_t V)
 {
-    const size_t n = (size_t)(P > 0 ? P : 1);
+    const size_t p1 = (size_t)(P > 0 ? P : 1);
+    const size_t n = p1 * (size_t)(V > 0 ? V : 1);
     GeomLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
@@ -114,23 +116,23 @@ static GeomLayout geom_layout(int32_t P)
     L.tiles_touched = take(4 * n);
     L.depth_order = take(4 * n);
     L.offsets = take(4 * n);
-    L.rgb = take(12 * n);
-    L.clamped = take(3 * n);
+    L.rgb = take(12 * p1);       // SH colours: single-view calls only
+    L.clamped = take(3 * p1);
     L.sort_keys = take(4 * n);
     L.keys_alt = take(4 * n);
     L.vals_alt = take(4 * n);
     L.sort_tmp = take(sort_tmp_bytes((int64_t)n));
     L.scan_tmp = take(scan_tmp_bytes((int64_t)n));
     L.total = take(16);
-    L.block_tiles = take(4 * (size_t)preprocess_blocks((int32_t)n));
+    L.block_tiles = take(4 * (size_t)preprocess_blocks((int32_t)p1) * (size_t)(V > 0 ? V : 1));
     L.span_owner = take(4 * (size_t)SPAN_OWNER_CAP);
     L.bytes = o;
     return L;
 }
 
-GeomView geom_view(void* base, int32_t P)
+GeomView geom_view(void* base, int32_t P, int32_t V)
 {
-    const GeomLayout L = geom_layout(P);
+    const GeomLayout L = geom_layout(P, V);
     char* b = reinterpret_cast<char*>(base);
     GeomView g;
     g.rec = reinterpret_cast<float4*>(b + L.rec0);
@@ -150,10 +152,11 @@ GeomView geom_view(void* base, int32_t P)
 struct BinLayout {
     size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, bytes;
 };
-static BinLayout bin_layout(int32_t P, int64_t R, int32_t W, int32_t H, int32_t C)
+static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t H, int32_t C)
 {
     const size_t n = (size_t)(R > 0 ? R : 1);
-    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * (size_t)((H + TILE - 1) / TILE);
+    const size_t nv = (size_t)(V > 0 ? V : 1);
+    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * (size_t)((H + TILE - 1) / TILE) * nv;
     BinLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
@@ -165,18 +168,18 @@ static BinLayout bin_layout(int32_t P, int64_t R, int32_t W, int32_t H, int32_t 
     L.sort_tmp = take(sort_tmp_bytes((int64_t)n));
     L.irec = take(32 * n);
     L.imask = take(n);
-    // padded feature table only when the rows are not already 16-byte aligned
+    // padded feature table only when the rows are not already 16-byte aligned (shared by the views)
     L.featp = take((C % 4) ? (size_t)(P > 0 ? P : 1) * padded_channels(C) * sizeof(float) : 16);
-    L.gacc = take((size_t)(P > 0 ? P : 1) * gacc_row_floats(C) * sizeof(float));
+    L.gacc = take((size_t)(P > 0 ? P : 1) * nv * gacc_row_floats(C) * sizeof(float));
     // (the deterministic debug mode's 64-bit accumulator is NOT part of this buffer: it is a stream-ordered
-    //  allocation made by splatraster_backward only while that mode is on)
+    //  allocation made by the backward only while that mode is on)
     L.bytes = o;
     return L;
 }
 
-BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H, int32_t C)
+BinView bin_view(void* base, int32_t P, int32_t V, int64_t R, int32_t W, int32_t H, int32_t C)
 {
-    const BinLayout L = bin_layout(P, R, W, H, C);
+    const BinLayout L = bin_layout(P, V, R, W, H, C);
     char* b = reinterpret_cast<char*>(base);
     BinView v;
     v.point_list = reinterpret_cast<uint32_t*>(b + L.valsA);
@@ -192,22 +195,28 @@ BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H, int32_t
     return v;
 }
 
-ImgView img_view(void* base, int32_t W, int32_t H)
+static size_t img_plane_bytes(int32_t W, int32_t H, int32_t V)
+{
+    return align_up((size_t)W * H * 4 * (size_t)(V > 0 ? V : 1), 256);
+}
+
+ImgView img_view(void* base, int32_t W, int32_t H, int32_t V)
 {
     char* b = reinterpret_cast<char*>(base);
     ImgView v;
     v.final_T = reinterpret_cast<float*>(b);
-    v.n_contrib = reinterpret_cast<uint32_t*>(b + align_up((size_t)W * H * 4, 256));
+    v.n_contrib = reinterpret_cast<uint32_t*>(b + img_plane_bytes(W, H, V));
     return v;
 }
 
 // The compositing kernels index feature / accumulator rows with 24-bit x 24-bit multiplies (one
 // full-rate instruction instead of a 64-bit multiply-add pair per address): Gaussian ids must fit 24
 // bits and a row's float offset 32 bits.  16.7 M Gaussians per scene — SplatLoc maps hold < 1 M.
-static int check_row_index_range(int32_t P, int32_t C)
+static int check_row_index_range(int32_t P, int32_t V, int32_t C)
 {
     const uint64_t row = (uint64_t)(gacc_row_floats(C) > padded_channels(C) ? gacc_row_floats(C) : padded_channels(C));
-    if ((uint64_t)P > (1ull << 24) || (uint64_t)P * row >= (1ull << 32)) return SPLATRASTER_ERR_UNSUPPORTED;
+    const uint64_t n = (uint64_t)P * (uint64_t)V;   // rows of the window
+    if (n > (1ull << 24) || n * row >= (1ull << 32)) return SPLATRASTER_ERR_UNSUPPORTED;
     return SPLATRASTER_OK;
 }
 
@@ -242,20 +251,32 @@ const char* splatraster_error_string(int status)
 
 const char* splatraster_last_hip_error(void) { return g_last_error.c_str(); }
 
-size_t splatraster_geometry_bytes(int32_t P) { return geom_layout(P).bytes; }
+size_t splatraster_geometry_bytes(int32_t P) { return geom_layout(P, 1).bytes; }
 size_t splatraster_binning_bytes(int32_t P, int64_t R, int32_t width, int32_t height, int32_t channels)
 {
-    return bin_layout(P, R, width, height, channels).bytes;
+    return bin_layout(P, 1, R, width, height, channels).bytes;
 }
-size_t splatraster_image_bytes(int32_t width, int32_t height)
+size_t splatraster_image_bytes(int32_t width, int32_t height) { return 2 * img_plane_bytes(width, height, 1); }
+
+size_t splatraster_window_geometry_bytes(int32_t P, int32_t n_views) { return geom_layout(P, n_views).bytes; }
+size_t splatraster_window_binning_bytes(int32_t P, int32_t n_views, int64_t R_total, int32_t width, int32_t height,
+                                        int32_t channels)
 {
-    return 2 * align_up((size_t)width * height * 4, 256);
+    return bin_layout(P, n_views, R_total, width, height, channels).bytes;
+}
+size_t splatraster_window_image_bytes(int32_t width, int32_t height, int32_t n_views)
+{
+    return 2 * img_plane_bytes(width, height, n_views);
 }
 
 int splatraster_get_geometry_layout(int32_t P, splatraster_geometry_layout* out)
 {
-    if (!out) return SPLATRASTER_ERR_BAD_ARG;
-    const GeomLayout L = geom_layout(P);
+    return splatraster_get_window_geometry_layout(P, 1, out);
+}
+int splatraster_get_window_geometry_layout(int32_t P, int32_t n_views, splatraster_geometry_layout* out)
+{
+    if (!out || n_views < 1 || n_views > MAX_VIEWS) return SPLATRASTER_ERR_BAD_ARG;
+    const GeomLayout L = geom_layout(P, n_views);
     out->rec0 = L.rec0; out->rec1 = L.rec1; out->tiles_touched = L.tiles_touched;
     out->depth_order = L.depth_order; out->offsets = L.offsets; out->rgb = L.rgb;
     out->clamped = L.clamped; out->total = L.bytes;
@@ -264,107 +285,155 @@ int splatraster_get_geometry_layout(int32_t P, splatraster_geometry_layout* out)
 int splatraster_get_binning_layout(int32_t P, int64_t R, int32_t width, int32_t height, int32_t channels,
                                    splatraster_binning_layout* out)
 {
-    if (!out) return SPLATRASTER_ERR_BAD_ARG;
-    const BinLayout L = bin_layout(P, R, width, height, channels);
+    return splatraster_get_window_binning_layout(P, 1, R, width, height, channels, out);
+}
+int splatraster_get_window_binning_layout(int32_t P, int32_t n_views, int64_t R_total, int32_t width, int32_t height,
+                                          int32_t channels, splatraster_binning_layout* out)
+{
+    if (!out || n_views < 1 || n_views > MAX_VIEWS) return SPLATRASTER_ERR_BAD_ARG;
+    const BinLayout L = bin_layout(P, n_views, R_total, width, height, channels);
     out->point_list = L.valsA; out->tile_list = L.keysA; out->ranges = L.ranges; out->total = L.bytes;
     return SPLATRASTER_OK;
 }
 int splatraster_get_image_layout(int32_t width, int32_t height, splatraster_image_layout* out)
 {
-    if (!out) return SPLATRASTER_ERR_BAD_ARG;
+    return splatraster_get_window_image_layout(width, height, 1, out);
+}
+int splatraster_get_window_image_layout(int32_t width, int32_t height, int32_t n_views, splatraster_image_layout* out)
+{
+    if (!out || n_views < 1 || n_views > MAX_VIEWS) return SPLATRASTER_ERR_BAD_ARG;
     out->final_T = 0;
-    out->n_contrib = align_up((size_t)width * height * 4, 256);
-    out->total = splatraster_image_bytes(width, height);
+    out->n_contrib = img_plane_bytes(width, height, n_views);
+    out->total = 2 * img_plane_bytes(width, height, n_views);
     return SPLATRASTER_OK;
 }
 
-int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const float* means3D,
-                                 const float* shs, const float* opacities, const float* scales,
-                                 const float* rotations, const float* cov3D_precomp,
-                                 const float* viewmatrix, const float* projmatrix, const float* campos,
-                                 void* geometry, int32_t* radii, int64_t* num_rendered, void* stream_)
+}  // extern "C"
+
+namespace sr {
+
+static int check_window(const splatraster_settings* s, int32_t V, const splatraster_window_view* views)
 {
     int st = check_settings(s);
     if (st) return st;
+    if (V < 1 || V > MAX_VIEWS || !views) return SPLATRASTER_ERR_BAD_ARG;
+    return SPLATRASTER_OK;
+}
+
+static WinCams make_cams(int32_t V, const splatraster_window_view* views)
+{
+    WinCams c{};
+    for (int v = 0; v < V; ++v) {
+        c.view[v] = views[v].viewmatrix;
+        c.proj[v] = views[v].projmatrix;
+        c.campos[v] = views[v].campos;
+        c.tanfovx[v] = views[v].tanfovx;
+        c.tanfovy[v] = views[v].tanfovy;
+        c.radii[v] = views[v].radii;
+    }
+    return c;
+}
+
+// Stage 1 of the forward over a window of V views (V = 1: the plain call): one preprocess, ONE depth sort of the
+// V * P rows, one scan; the per-view instance counts are read back under the sort.
+static int window_geometry(const splatraster_settings* s, int32_t V, const splatraster_window_view* views, int32_t P,
+                           const float* means3D, const float* shs, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, void* geometry, int64_t* num_rendered,
+                           hipStream_t stream)
+{
+    int st = check_window(s, V, views);
+    if (st) return st;
     if (P < 0 || !num_rendered) return SPLATRASTER_ERR_BAD_ARG;
-    *num_rendered = 0;
+    for (int v = 0; v < V; ++v) num_rendered[v] = 0;
     if (P == 0) return SPLATRASTER_OK;
-    if (!means3D || !opacities || !viewmatrix || !projmatrix || !geometry || !radii) return SPLATRASTER_ERR_BAD_ARG;
+    if (!means3D || !opacities || !geometry) return SPLATRASTER_ERR_BAD_ARG;
+    for (int v = 0; v < V; ++v)
+        if (!views[v].viewmatrix || !views[v].projmatrix || !views[v].radii) return SPLATRASTER_ERR_BAD_ARG;
     const bool have_sr = scales && rotations;
     if (have_sr == (cov3D_precomp != nullptr)) return SPLATRASTER_ERR_BAD_ARG;
     if ((scales == nullptr) != (rotations == nullptr)) return SPLATRASTER_ERR_BAD_ARG;
     if (shs) {
-        if (s->channels != 3 || !campos) return SPLATRASTER_ERR_BAD_ARG;
+        if (V != 1) return SPLATRASTER_ERR_UNSUPPORTED;   // view-dependent colours: one table per view
+        if (s->channels != 3 || !views[0].campos) return SPLATRASTER_ERR_BAD_ARG;
         if (s->sh_degree < 0 || s->sh_degree > 3) return SPLATRASTER_ERR_UNSUPPORTED;
         if (s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1)) return SPLATRASTER_ERR_BAD_ARG;
     }
+    if ((int64_t)P * V >= ((int64_t)1 << 31)) return SPLATRASTER_ERR_OVERFLOW;
     st = lookback_error_init();
     if (st) return st;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    const GeomLayout L = geom_layout(P);
-    GeomView g = geom_view(geometry, P);
+    const int32_t n = P * V;
+    const GeomLayout L = geom_layout(P, V);
+    GeomView g = geom_view(geometry, P, V);
     char* base = reinterpret_cast<char*>(geometry);
+    const WinCams cams = make_cams(V, views);
     {
         StageTimer t(SPLATRASTER_STAGE_PREPROCESS, stream);
         // the look-back state of the depth sort and of the scan is cleared by preprocess_kernel
-        st = launch_preprocess(*s, P, means3D, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix,
-                               projmatrix, campos, g, radii, g.sort_tmp, (uint32_t)(sort_zero_bytes(P, 32) / 4),
-                               reinterpret_cast<uint32_t*>(base + L.scan_tmp), (uint32_t)(scan_state_bytes(P) / 4),
-                               stream);
+        st = launch_preprocess(*s, P, V, cams, means3D, shs, opacities, scales, rotations, cov3D_precomp, g,
+                               g.sort_tmp, (uint32_t)(sort_zero_bytes(n, 32) / 4),
+                               reinterpret_cast<uint32_t*>(base + L.scan_tmp), (uint32_t)(scan_state_bytes(n) / 4), stream);
     }
     if (st) return st;
     HostSlot* slot = nullptr;
     const size_t nblk = (size_t)preprocess_blocks(P);
-    st = host_slot(nblk, &slot);
+    st = host_slot(nblk * (size_t)V, &slot);
     if (st) return st;
-    SR_HIP_CHECK(hipMemcpyAsync(slot->p, g.block_tiles, sizeof(uint32_t) * nblk, hipMemcpyDeviceToHost, stream));
+    SR_HIP_CHECK(hipMemcpyAsync(slot->p, g.block_tiles, sizeof(uint32_t) * nblk * (size_t)V, hipMemcpyDeviceToHost, stream));
     SR_HIP_CHECK(hipEventRecord(slot->ev, stream));
     {
         StageTimer t(SPLATRASTER_STAGE_DEPTH_SORT, stream);
         bool in_alt = false;
         uint32_t* keys_alt = reinterpret_cast<uint32_t*>(base + L.keys_alt);
         uint32_t* vals_alt = reinterpret_cast<uint32_t*>(base + L.vals_alt);
-        st = sort_pairs_u32(P, g.sort_keys, g.depth_order, keys_alt, vals_alt, 32, g.sort_tmp, stream, &in_alt, true);
+        st = sort_pairs_u32(n, g.sort_keys, g.depth_order, keys_alt, vals_alt, 32, g.sort_tmp, stream, &in_alt, true);
         if (st) return st;
         if (in_alt) return SPLATRASTER_ERR_UNSUPPORTED;  // 4 passes: never
     }
     {
         StageTimer t(SPLATRASTER_STAGE_SCAN, stream);
-        st = inclusive_scan_u32(P, g.tiles_touched, g.depth_order, g.offsets, g.total, base + L.scan_tmp, stream, true,
+        st = inclusive_scan_u32(n, g.tiles_touched, g.depth_order, g.offsets, g.total, base + L.scan_tmp, stream, true,
                                 g.span_owner, (uint32_t)EMIT_SPAN, SPAN_OWNER_CAP);
     }
     if (st) return st;
     SR_HIP_CHECK(hipEventSynchronize(slot->ev));  // the copy only: sort and scan may still be running
     uint64_t total = 0;
-    for (size_t k = 0; k < nblk; ++k) total += slot->p[k];
+    for (int v = 0; v < V; ++v) {
+        uint64_t tv = 0;
+        for (size_t k = 0; k < nblk; ++k) tv += slot->p[(size_t)v * nblk + k];
+        num_rendered[v] = (int64_t)tv;
+        total += tv;
+    }
     if (total >= ((uint64_t)1 << 31)) return SPLATRASTER_ERR_OVERFLOW;
-    *num_rendered = (int64_t)total;
     return SPLATRASTER_OK;
 }
 
-int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t R, const float* bg,
-                               const float* colors_precomp, void* geometry, void* binning, void* image,
-                               float* out_color, float* out_depth, float* out_alpha, void* stream_)
+// Stage 2: ONE emission, ONE tile sort keyed by (view, tile), one payload pass, one compositing grid over the V views.
+static int window_render(const splatraster_settings* s, int32_t V, const splatraster_window_view* views, int32_t P,
+                         int64_t R, const float* bg, const float* colors_precomp, void* geometry, void* binning,
+                         void* image, hipStream_t stream)
 {
-    int st = check_settings(s);
+    int st = check_window(s, V, views);
     if (st) return st;
-    if (P < 0 || R < 0 || !image || !out_color || !out_depth || !out_alpha) return SPLATRASTER_ERR_BAD_ARG;
+    if (P < 0 || R < 0 || !image) return SPLATRASTER_ERR_BAD_ARG;
+    for (int v = 0; v < V; ++v)
+        if (!views[v].out_color || !views[v].out_depth || !views[v].out_alpha) return SPLATRASTER_ERR_BAD_ARG;
     if (s->bg_channels > 0 && !bg) return SPLATRASTER_ERR_BAD_ARG;
     if (P > 0 && (!geometry || !binning)) return SPLATRASTER_ERR_BAD_ARG;
-    st = check_row_index_range(P, s->channels);
+    if (V > 1 && !colors_precomp && P > 0) return SPLATRASTER_ERR_UNSUPPORTED;
+    st = check_row_index_range(P, V, s->channels);
     if (st) return st;
-    if (R > 0 && !binning) return SPLATRASTER_ERR_BAD_ARG;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!binning) return SPLATRASTER_ERR_BAD_ARG;
     const int W = s->image_width, H = s->image_height;
     const int tiles = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    ImgView im = img_view(image, W, H);
+    const int64_t gtiles = (int64_t)tiles * V;
+    if (gtiles >= ((int64_t)1 << 31)) return SPLATRASTER_ERR_OVERFLOW;
+    ImgView im = img_view(image, W, H, V);
     GeomView g{};
-    if (geometry) g = geom_view(geometry, P);
-    if (!binning) return SPLATRASTER_ERR_BAD_ARG;
-    BinView b = bin_view(binning, P, R, W, H, s->channels);
+    if (geometry) g = geom_view(geometry, P, V);
+    BinView b = bin_view(binning, P, V, R, W, H, s->channels);
     const float* feat = colors_precomp ? colors_precomp : g.rgb;
     if (R > 0 && !feat) return SPLATRASTER_ERR_BAD_ARG;
-    const int bits = tile_bits(tiles);
+    const int bits = tile_bits((int)gtiles);
     const int passes = (bits + 7) / 8;
     // emit into the buffer pair from which `passes` ping-pongs end in (tile_list, point_list)
     uint32_t* k0 = (passes & 1) ? b.keys_tmp : b.tile_list;
@@ -374,7 +443,7 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
     if (R > 0) {
         {
             StageTimer t(SPLATRASTER_STAGE_EMIT, stream);
-            st = launch_emit(*s, P, R, g, k0, v0, b.ranges, 2u * (uint32_t)tiles, stream);  // also clears the range table
+            st = launch_emit(*s, P, V, R, g, k0, v0, b.ranges, 2u * (uint32_t)gtiles, stream);  // also clears the range table
         }
         if (st) return st;
         bool in_alt = false;
@@ -386,13 +455,13 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
     }
     if (R == 0) {   // nothing was emitted: the table is cleared here instead
         StageTimer t(SPLATRASTER_STAGE_RANGES, stream);
-        st = launch_ranges_clear(tiles, b.ranges, stream);
+        st = launch_ranges_clear((int32_t)gtiles, b.ranges, stream);
     }
     if (st) return st;
     const float* featp = feat;  // 16-byte aligned rows for the compositing kernels
     if (R > 0) {
         StageTimer t(SPLATRASTER_STAGE_PAYLOAD, stream);
-        st = launch_payload(*s, R, g, b, stream);
+        st = launch_payload(*s, V, R, g, b, stream);
         if (st) return st;
         if (s->channels % 4) {
             st = launch_pad_features(P, s->channels, feat, b.featp, stream);
@@ -400,8 +469,120 @@ int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t
         }
     }
     if (st) return st;
+    WinOut outs{};
+    for (int v = 0; v < V; ++v) {
+        outs.color[v] = views[v].out_color;
+        outs.depth[v] = views[v].out_depth;
+        outs.alpha[v] = views[v].out_alpha;
+    }
     StageTimer t(SPLATRASTER_STAGE_COMPOSITE_FWD, stream);
-    return launch_composite_fwd(*s, R, g, b, im, featp, bg, out_color, out_depth, out_alpha, stream);
+    return launch_composite_fwd(*s, P, V, R, g, b, im, featp, bg, outs, stream);
+}
+
+// Backward of the window: one compositing grid over the V views into per-(view, Gaussian) accumulator rows, then
+// ONE per-Gaussian pass that sums the views into a single set of parameter gradients.
+static int window_backward(const splatraster_settings* s, int32_t V, const splatraster_window_view* views, int32_t P,
+                           int64_t R, const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* scales, const float* rotations, const float* cov3D_precomp, void* geometry,
+                           const void* binning, const void* image, float* dL_dmeans3D, float* dL_dcolors,
+                           float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                           float* dL_dshs, float* dL_dviewmatrix, float* dL_dprojmatrix, float* dL_dcampos,
+                           hipStream_t stream)
+{
+    int st = check_window(s, V, views);
+    if (st) return st;
+    if (P < 0 || R < 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (V > 1 && (shs || dL_dviewmatrix || dL_dprojmatrix || dL_dcampos)) return SPLATRASTER_ERR_UNSUPPORTED;
+    if (P == 0) {   // nothing to differentiate: the camera gradients are still defined (zero)
+        if (dL_dviewmatrix) SR_HIP_CHECK(hipMemsetAsync(dL_dviewmatrix, 0, 16 * sizeof(float), stream));
+        if (dL_dprojmatrix) SR_HIP_CHECK(hipMemsetAsync(dL_dprojmatrix, 0, 16 * sizeof(float), stream));
+        if (dL_dcampos) SR_HIP_CHECK(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), stream));
+        return SPLATRASTER_OK;
+    }
+    if (!means3D || !geometry || !binning || !image || !dL_dmeans3D || !dL_dopacities) return SPLATRASTER_ERR_BAD_ARG;
+    for (int v = 0; v < V; ++v)
+        if (!views[v].viewmatrix || !views[v].projmatrix || !views[v].radii || !views[v].out_color || !views[v].out_depth ||
+            !views[v].dL_dout_color || !views[v].dL_dmeans2D)
+            return SPLATRASTER_ERR_BAD_ARG;
+    if (shs && (!dL_dshs || !views[0].campos)) return SPLATRASTER_ERR_BAD_ARG;
+    if (!shs && (!colors_precomp || !dL_dcolors)) return SPLATRASTER_ERR_BAD_ARG;
+    if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
+        return SPLATRASTER_ERR_BAD_ARG;
+    st = check_row_index_range(P, V, s->channels);
+    if (st) return st;
+    const int W = s->image_width, H = s->image_height;
+    GeomView g = geom_view(geometry, P, V);
+    BinView b = bin_view(const_cast<void*>(binning), P, V, R, W, H, s->channels);
+    ImgView im = img_view(const_cast<void*>(image), W, H, V);
+    const int C = s->channels;
+    const float* feat = shs ? g.rgb : colors_precomp;
+    const WinCams cams = make_cams(V, views);
+    WinGrad grads{};
+    for (int v = 0; v < V; ++v) {
+        grads.out_color[v] = views[v].out_color;
+        grads.out_depth[v] = views[v].out_depth;
+        grads.dL_dcolor[v] = views[v].dL_dout_color;
+        grads.dL_ddepth[v] = views[v].dL_dout_depth;
+        grads.dL_dalpha[v] = views[v].dL_dout_alpha;
+        grads.dL_dmeans2D[v] = views[v].dL_dmeans2D;
+    }
+    // zero the accumulator rows (outside the stage bracket: the stage is the kernel alone, so its
+    // figure can be held against the per-kernel rocprofv3 average)
+    const size_t gacc_n = (size_t)gacc_row_floats(C) * (size_t)P * (size_t)V;
+    const bool det = g_deterministic != 0;
+    long long* gacc64 = nullptr;   // debug mode only: stream-ordered scratch, freed below (never part of `binning`)
+    if (det) {
+        SR_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&gacc64), sizeof(long long) * gacc_n, stream));
+        SR_HIP_CHECK(hipMemsetAsync(gacc64, 0, sizeof(long long) * gacc_n, stream));
+    } else {
+        SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * gacc_n, stream));
+    }
+    {
+        StageTimer t(SPLATRASTER_STAGE_COMPOSITE_BWD, stream);
+        st = launch_composite_bwd(*s, P, V, R, g, b, im, (C % 4) ? b.featp : feat, C, grads, b.gacc, gacc64, stream);
+    }
+    if (det) {
+        if (!st) st = launch_fixed_to_float((int64_t)gacc_n, gacc64, b.gacc, stream);
+        (void)hipFreeAsync(gacc64, stream);
+    }
+    if (st) return st;
+    StageTimer t(SPLATRASTER_STAGE_PREPROCESS_BWD, stream);
+    return launch_preprocess_bwd(*s, P, V, cams, grads, means3D, shs, scales, rotations, cov3D_precomp, g.clamped, g.rec,
+                                 b.gacc, C, shs ? nullptr : dL_dcolors, dL_dmeans3D, dL_dopacities,
+                                 cov3D_precomp ? nullptr : dL_dscales, cov3D_precomp ? nullptr : dL_drotations,
+                                 cov3D_precomp ? dL_dcov3D : nullptr, dL_dshs, dL_dviewmatrix, dL_dprojmatrix, dL_dcampos,
+                                 stream);
+}
+
+}  // namespace sr
+
+extern "C" {
+
+int splatraster_forward_geometry(const splatraster_settings* s, int32_t P, const float* means3D,
+                                 const float* shs, const float* opacities, const float* scales,
+                                 const float* rotations, const float* cov3D_precomp,
+                                 const float* viewmatrix, const float* projmatrix, const float* campos,
+                                 void* geometry, int32_t* radii, int64_t* num_rendered, void* stream_)
+{
+    if (!s) return SPLATRASTER_ERR_BAD_ARG;
+    splatraster_window_view w{};
+    w.viewmatrix = viewmatrix; w.projmatrix = projmatrix; w.campos = campos;
+    w.tanfovx = s->tanfovx; w.tanfovy = s->tanfovy; w.radii = radii;
+    if (num_rendered) *num_rendered = 0;
+    if (P > 0 && !radii) return SPLATRASTER_ERR_BAD_ARG;
+    return window_geometry(s, 1, &w, P, means3D, shs, opacities, scales, rotations, cov3D_precomp, geometry, num_rendered,
+                           reinterpret_cast<hipStream_t>(stream_));
+}
+
+int splatraster_forward_render(const splatraster_settings* s, int32_t P, int64_t R, const float* bg,
+                               const float* colors_precomp, void* geometry, void* binning, void* image,
+                               float* out_color, float* out_depth, float* out_alpha, void* stream_)
+{
+    if (!s) return SPLATRASTER_ERR_BAD_ARG;
+    splatraster_window_view w{};
+    w.tanfovx = s->tanfovx; w.tanfovy = s->tanfovy;
+    w.out_color = out_color; w.out_depth = out_depth; w.out_alpha = out_alpha;
+    return window_render(s, 1, &w, P, R, bg, colors_precomp, geometry, binning, image, reinterpret_cast<hipStream_t>(stream_));
 }
 
 int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, const float* bg,
@@ -417,59 +598,62 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
                          float* dL_dprojmatrix, float* dL_dcampos, void* stream_)
 {
     (void)bg; (void)opacities; (void)out_alpha;
-    int st = check_settings(s);
-    if (st) return st;
-    if (P < 0 || R < 0) return SPLATRASTER_ERR_BAD_ARG;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (P == 0) {   // nothing to differentiate: the camera gradients are still defined (zero)
-        if (dL_dviewmatrix) SR_HIP_CHECK(hipMemsetAsync(dL_dviewmatrix, 0, 16 * sizeof(float), stream));
-        if (dL_dprojmatrix) SR_HIP_CHECK(hipMemsetAsync(dL_dprojmatrix, 0, 16 * sizeof(float), stream));
-        if (dL_dcampos) SR_HIP_CHECK(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), stream));
-        return SPLATRASTER_OK;
+    if (!s) return SPLATRASTER_ERR_BAD_ARG;
+    splatraster_window_view w{};
+    w.viewmatrix = viewmatrix; w.projmatrix = projmatrix; w.campos = campos;
+    w.tanfovx = s->tanfovx; w.tanfovy = s->tanfovy; w.radii = const_cast<int32_t*>(radii);
+    w.out_color = const_cast<float*>(out_color); w.out_depth = const_cast<float*>(out_depth);
+    w.dL_dout_color = dL_dout_color; w.dL_dout_depth = dL_dout_depth; w.dL_dout_alpha = dL_dout_alpha;
+    w.dL_dmeans2D = dL_dmeans2D;
+    return window_backward(s, 1, &w, P, R, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, geometry, binning,
+                           image, dL_dmeans3D, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, dL_dshs,
+                           dL_dviewmatrix, dL_dprojmatrix, dL_dcampos, reinterpret_cast<hipStream_t>(stream_));
+}
+
+int splatraster_forward_window_geometry(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
+                                        int32_t P, const float* means3D, const float* opacities, const float* scales,
+                                        const float* rotations, const float* cov3D_precomp, void* geometry,
+                                        int64_t* num_rendered, void* stream)
+{
+    return window_geometry(s, n_views, views, P, means3D, nullptr, opacities, scales, rotations, cov3D_precomp, geometry,
+                           num_rendered, reinterpret_cast<hipStream_t>(stream));
+}
+
+int splatraster_forward_window_render(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
+                                      int32_t P, const int64_t* num_rendered, const float* bg, const float* colors_precomp,
+                                      void* geometry, void* binning, void* image, void* stream)
+{
+    if (!num_rendered || n_views < 1 || n_views > MAX_VIEWS) return SPLATRASTER_ERR_BAD_ARG;
+    int64_t R = 0;
+    for (int v = 0; v < n_views; ++v) {
+        if (num_rendered[v] < 0) return SPLATRASTER_ERR_BAD_ARG;
+        R += num_rendered[v];
     }
-    if (!means3D || !viewmatrix || !projmatrix || !radii || !geometry || !binning || !image || !out_color ||
-        !out_depth || !dL_dout_color || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacities)
-        return SPLATRASTER_ERR_BAD_ARG;
-    if (shs && (!dL_dshs || !campos)) return SPLATRASTER_ERR_BAD_ARG;
-    if (!shs && (!colors_precomp || !dL_dcolors)) return SPLATRASTER_ERR_BAD_ARG;
-    if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
-        return SPLATRASTER_ERR_BAD_ARG;
-    st = check_row_index_range(P, s->channels);
-    if (st) return st;
-    const int W = s->image_width, H = s->image_height;
-    GeomView g = geom_view(geometry, P);
-    BinView b = bin_view(const_cast<void*>(binning), P, R, W, H, s->channels);
-    ImgView im = img_view(const_cast<void*>(image), W, H);
-    const int C = s->channels;
-    const float* feat = shs ? g.rgb : colors_precomp;
-    // zero the accumulator rows (outside the stage bracket: the stage is the kernel alone, so its
-    // figure can be held against the per-kernel rocprofv3 average)
-    const size_t gacc_n = (size_t)gacc_row_floats(C) * (size_t)P;
-    const bool det = g_deterministic != 0;
-    long long* gacc64 = nullptr;   // debug mode only: stream-ordered scratch, freed below (never part of `binning`)
-    if (det) {
-        SR_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&gacc64), sizeof(long long) * gacc_n, stream));
-        SR_HIP_CHECK(hipMemsetAsync(gacc64, 0, sizeof(long long) * gacc_n, stream));
-    } else {
-        SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * gacc_n, stream));
+    return window_render(s, n_views, views, P, R, bg, colors_precomp, geometry, binning, image,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
+int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
+                                int32_t P, const int64_t* num_rendered, const float* means3D, const float* colors_precomp,
+                                const float* scales, const float* rotations, const float* cov3D_precomp, void* geometry,
+                                const void* binning, const void* image, float* dL_dmeans3D, float* dL_dcolors,
+                                float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream)
+{
+    if (!num_rendered || n_views < 1 || n_views > MAX_VIEWS) return SPLATRASTER_ERR_BAD_ARG;
+    int64_t R = 0;
+    for (int v = 0; v < n_views; ++v) {
+        if (num_rendered[v] < 0) return SPLATRASTER_ERR_BAD_ARG;
+        R += num_rendered[v];
     }
-    {
-        StageTimer t(SPLATRASTER_STAGE_COMPOSITE_BWD, stream);
-        st = launch_composite_bwd(*s, P, R, g, b, im, (C % 4) ? b.featp : feat, C, out_color, out_depth, dL_dout_color,
-                                  dL_dout_depth, dL_dout_alpha, b.gacc, gacc64, stream);
-    }
-    if (det) {
-        if (!st) st = launch_fixed_to_float((int64_t)gacc_n, gacc64, b.gacc, stream);
-        (void)hipFreeAsync(gacc64, stream);
-    }
-    if (st) return st;
-    StageTimer t(SPLATRASTER_STAGE_PREPROCESS_BWD, stream);
-    return launch_preprocess_bwd(*s, P, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
-                                 campos, radii, g.clamped, g.rec, b.gacc, C, shs ? nullptr : dL_dcolors, dL_dmeans3D,
-                                 dL_dmeans2D,
-                                 dL_dopacities, cov3D_precomp ? nullptr : dL_dscales,
-                                 cov3D_precomp ? nullptr : dL_drotations, cov3D_precomp ? dL_dcov3D : nullptr,
-                                 dL_dshs, dL_dviewmatrix, dL_dprojmatrix, dL_dcampos, stream);
+    return window_backward(s, n_views, views, P, R, means3D, nullptr, colors_precomp, scales, rotations, cov3D_precomp,
+                           geometry, binning, image, dL_dmeans3D, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations,
+                           dL_dcov3D, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int splatraster_debug_set_small_panel_max_waves(int waves)
+{
+    set_small_panel_max_waves(waves);
+    return SPLATRASTER_OK;
 }
 
 int splatraster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,

@@ -50,56 +50,88 @@ int launch_debug_exp2(int64_t n, const float* x, float* y, hipStream_t stream);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// ---- opaque buffer views -------------------------------------------------------------
+// ---- a window of views ------------------------------------------------------------------
+// SplatLoc.map renders `window_size` views of ONE Gaussian scene before a single backward
+// (train_gaussians.py:195-229).  Every stage of the pipeline therefore works on a WINDOW of V views at once
+// (V = 1: the plain GaussianRasterizer call): "row" g = v * P + i is Gaussian i as seen from view v, "global tile"
+// v * tiles + t is tile t of view v.  One preprocess, ONE depth sort over the V * P rows, one emission, ONE
+// tile sort keyed by the global tile, one compositing grid over V * tiles * 4 quadrant-waves; the per-view
+// results are bit-identical to V separate calls (both sorts are stable, so every (view, tile) list is in
+// (depth, index) order).  Per-view pointers travel as kernel arguments (the camera tensors stay on the device:
+// reading them on the host would cost a synchronisation).
+constexpr int MAX_VIEWS = SPLATRASTER_MAX_WINDOW_VIEWS;
+struct WinCams {
+    const float* view[MAX_VIEWS];    // [4,4] row-vector convention
+    const float* proj[MAX_VIEWS];    // [4,4] view @ proj
+    const float* campos[MAX_VIEWS];  // [3] or null
+    float tanfovx[MAX_VIEWS], tanfovy[MAX_VIEWS];
+    int32_t* radii[MAX_VIEWS];       // [P] per view (forward: written; backward: read)
+};
+struct WinOut {                      // forward outputs
+    float* color[MAX_VIEWS];         // [C,H,W]
+    float* depth[MAX_VIEWS];         // [1,H,W]
+    float* alpha[MAX_VIEWS];         // [1,H,W]
+};
+struct WinGrad {                     // backward inputs per view
+    const float* out_color[MAX_VIEWS];
+    const float* out_depth[MAX_VIEWS];
+    const float* dL_dcolor[MAX_VIEWS];
+    const float* dL_ddepth[MAX_VIEWS];   // null = zeros
+    const float* dL_dalpha[MAX_VIEWS];   // null = zeros
+    float* dL_dmeans2D[MAX_VIEWS];       // [P,3] output
+};
+
+// ---- opaque buffer views (n = V * P rows) -------------------------------------------------
 struct GeomView {
-    float4* rec;             // [2P] 32-byte records: rec[2i] = px, py, depth, radius (float; 0 = culled),
-                             //                       rec[2i+1] = conic a, b, c, opacity
-    uint32_t* tiles_touched; // [P] original order
-    uint32_t* depth_order;   // [P] gaussian ids sorted by depth
-    uint32_t* offsets;       // [P] inclusive scan of tiles_touched in depth order
-    float* rgb;              // [3P]
+    float4* rec;             // [2n] 32-byte records: rec[2g] = px, py, depth, radius (float; 0 = culled),
+                             //                       rec[2g+1] = conic a, b, c, opacity
+    uint32_t* tiles_touched; // [n] row order
+    uint32_t* depth_order;   // [n] rows sorted by depth (all views together; culled rows last)
+    uint32_t* offsets;       // [n] inclusive scan of tiles_touched in depth order
+    float* rgb;              // [3P]   (SH colours: single-view calls only)
     uint8_t* clamped;        // [3P]
-    uint32_t* sort_keys;     // [P] scratch (depth bits)
-    uint32_t* sort_tmp;      // scratch for the P-sized sort + scan partials
+    uint32_t* sort_keys;     // [n] scratch (depth bits)
+    uint32_t* sort_tmp;      // scratch for the n-sized sort + scan partials
     uint32_t* total;         // [2] device-side R (uint64 as two words), written by the scan
-    uint32_t* block_tiles;   // [preprocess_blocks(P)] per-block sums of tiles_touched, written by preprocess
+    uint32_t* block_tiles;   // [V * preprocess_blocks(P)] per-(view, block) sums of tiles_touched, written by preprocess
     uint32_t* span_owner;    // [SPAN_OWNER_CAP] depth rank owning instance k * EMIT_SPAN, written by the one-pass scan
 };
 struct BinView {
-    uint32_t* point_list; // [R] sorted gaussian ids
-    uint32_t* tile_list;  // [R] sorted tile ids
-    uint32_t* ranges;     // [2*tiles]
-    uint32_t* keys_tmp;   // [R] unsorted tile ids
-    uint32_t* vals_tmp;   // [R] unsorted gaussian ids
+    uint32_t* point_list; // [R] sorted rows (v * P + i)
+    uint32_t* tile_list;  // [R] sorted global tile ids (v * tiles + t)
+    uint32_t* ranges;     // [2 * V * tiles]
+    uint32_t* keys_tmp;   // [R] unsorted global tile ids
+    uint32_t* vals_tmp;   // [R] unsorted rows
     void* sort_tmp;       // radix sort scratch
     float4* irec;         // [2R] per-instance copy of the 32-byte record, in sorted order
     uint8_t* imask;       // [R] bit q: the Gaussian may reach quadrant q of its tile
-    float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows)
-    float* gacc;          // [P * gacc_row_floats(C)] backward gradient accumulator rows
+    float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows); shared by the views
+    float* gacc;          // [V * P * gacc_row_floats(C)] backward gradient accumulator rows (one per row)
 };
 struct ImgView {
-    float* final_T;
-    uint32_t* n_contrib;
+    float* final_T;       // [V][H * W]
+    uint32_t* n_contrib;  // [V][H * W]
 };
 
-GeomView geom_view(void* base, int32_t P);
-BinView bin_view(void* base, int32_t P, int64_t R, int32_t W, int32_t H, int32_t C);
-ImgView img_view(void* base, int32_t W, int32_t H);
+GeomView geom_view(void* base, int32_t P, int32_t V);
+BinView bin_view(void* base, int32_t P, int32_t V, int64_t R, int32_t W, int32_t H, int32_t C);
+ImgView img_view(void* base, int32_t W, int32_t H, int32_t V);
 
 // ---- stage launchers (each returns a SPLATRASTER_* status) -----------------------------
-int launch_preprocess(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
-                      const float* opacities, const float* scales, const float* rotations,
-                      const float* cov3D_precomp, const float* view, const float* proj,
-                      const float* campos, GeomView g, int32_t* radii, uint32_t* zero0, uint32_t nzero0, uint32_t* zero1, uint32_t nzero1,
+int launch_preprocess(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const float* means3D,
+                      const float* shs /*V == 1 only*/, const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp, GeomView g, uint32_t* zero0, uint32_t nzero0, uint32_t* zero1, uint32_t nzero1,
                       hipStream_t stream);
-int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
+// sums the gradient contributions of the V views of a window into ONE set of parameter gradients (written once,
+// in view order: deterministic given the accumulator rows); dL/dmeans2D is per view
+int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const WinGrad& grads,
+                          const float* means3D, const float* shs /*V == 1 only*/,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
-                          const float* view, const float* proj, const float* campos, const int32_t* radii,
                           const uint8_t* clamped, const float4* rec, const float* gacc, int C,
                           float* dL_dcolors,
-                          float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
+                          float* dL_dmeans3D, float* dL_dopacities, float* dL_dscales,
                           float* dL_drotations, float* dL_dcov3D, float* dL_dshs,
-                          float* dL_dview /*[16] or null*/, float* dL_dproj, float* dL_dcampos,
+                          float* dL_dview /*[16] or null; V == 1 only*/, float* dL_dproj, float* dL_dcampos,
                           hipStream_t stream);
 int launch_mark_visible(int32_t P, const float* means3D, const float* view, uint8_t* present,
                         hipStream_t stream);
@@ -117,10 +149,10 @@ int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint
 constexpr int EMIT_SPAN = 1024;  // instances emitted per workgroup (binning.hip)
 constexpr uint32_t SPAN_OWNER_CAP = 1u << 16;  // emit workgroups that get their first rank from the scan (R <= 64 M)
 
-int launch_emit(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g, uint32_t* keys,
+int launch_emit(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g, uint32_t* keys,
                 uint32_t* vals, uint32_t* ranges, uint32_t nranges, hipStream_t stream);
 int launch_ranges_clear(int32_t tiles, uint32_t* ranges, hipStream_t stream);
-int launch_payload(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b, hipStream_t stream);
+int launch_payload(const splatraster_settings& s, int32_t V, int64_t R, const GeomView& g, const BinView& b, hipStream_t stream);
 // 16-byte aligned copy of the [P, C] feature rows (returns feat itself when C % 4 == 0)
 int launch_pad_features(int32_t P, int C, const float* feat, float* featp, hipStream_t stream);
 static inline int padded_channels(int C) { return (C + 3) & ~3; }
@@ -131,17 +163,19 @@ static inline int padded_channels(int C) { return (C + 3) & ~3; }
 __host__ __device__ static inline int gacc_moment_offset(int C) { return ((C & 15) + 7 <= 16) ? C : ((C + 15) & ~15); }
 __host__ __device__ static inline int gacc_row_floats(int C) { return (gacc_moment_offset(C) + 7 + 15) & ~15; }
 
-int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b,
-                         const ImgView& im, const float* featp /*padded rows*/, const float* bg, float* out_color,
-                         float* out_depth, float* out_alpha, hipStream_t stream);
-int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g,
+int launch_composite_fwd(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g, const BinView& b,
+                         const ImgView& im, const float* featp /*padded rows, shared by the views*/, const float* bg,
+                         const WinOut& out, hipStream_t stream);
+int launch_composite_bwd(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g,
                          const BinView& b, const ImgView& im, const float* feat, int feat_stride,
-                         const float* out_color, const float* out_depth, const float* dL_dcolor,
-                         const float* dL_ddepth, const float* dL_dalpha,
-                         float* gacc /*[P, gacc_row_floats(C)]: dL/dfeature | moments sum E dx, E dy, E dx^2,
+                         const WinGrad& grads,
+                         float* gacc /*[V * P, gacc_row_floats(C)]: dL/dfeature | moments sum E dx, E dy, E dx^2,
                                       E dx dy, E dy^2, E, w g_D*/,
                          long long* gacc64 /*non-NULL: deterministic fixed-point accumulation into this buffer*/,
                          hipStream_t stream);
+// test / A-B hook: frames with at most this many quadrant-waves take the small-layout panel variant of the backward
+// (< 0: the built-in default)
+void set_small_panel_max_waves(int waves);
 int launch_fixed_to_float(int64_t n, const long long* src, float* dst, hipStream_t stream);
 
 int launch_activate_fwd(int32_t P, int32_t K, int32_t deg, int32_t SC, int32_t E, const float* xyz,

@@ -126,15 +126,15 @@ __device__ __forceinline__ void acc_add(float* gacc, long long* gacc64, size_t i
 
 template <int NC, bool DET, bool SP>
 __global__ void __launch_bounds__(WAVE, SR_BWD_MINW)
-composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass, int tiles,
+composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass, int tiles /*per view*/, int V,
+                     int P /*rows per view*/,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                      const float4* __restrict__ irec,
                      const uint8_t* __restrict__ imask, const float4* __restrict__ featp4,
-                     const float* __restrict__ out_color, const float* __restrict__ out_depth,
-                     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                     const float* __restrict__ dL_dalpha, float* __restrict__ gacc /*[P, GROW]*/, int GROW,
-                     int MO, long long* __restrict__ gacc64 /*[P, GROW] fixed point, DET only*/)
+                     WinGrad grads,
+                     const float* __restrict__ final_T_all, const uint32_t* __restrict__ n_contrib_all,
+                     float* __restrict__ gacc /*[V * P, GROW]*/, int GROW,
+                     int MO, long long* __restrict__ gacc64 /*[V * P, GROW] fixed point, DET only*/)
 {
     using Cfg = BwdCfg<NC, SP>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
@@ -166,10 +166,20 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         }
     } trace_end{__builtin_amdgcn_s_memrealtime(), g_trace_bwd};
 #endif
-    int tile, quad;
+    int gtile, quad;   // global tile = view * tiles + tile: the grid covers the V views of the window
     const int gx = (W + TILE - 1) / TILE;
-    quadrant_of_block(blockIdx.x, tiles, gx, tile, quad);
-    if (tile >= tiles) return;
+    quadrant_of_block(blockIdx.x, V * tiles, gx, gtile, quad);
+    if (gtile >= V * tiles) return;
+    const int view = (V == 1) ? 0 : gtile / tiles;      // wave-uniform (scalar)
+    const int tile = gtile - view * tiles;
+    const uint32_t row0 = (uint32_t)view * (uint32_t)P;  // accumulator rows are per (view, Gaussian), feature rows shared
+    const float* __restrict__ out_color = grads.out_color[view];
+    const float* __restrict__ out_depth = grads.out_depth[view];
+    const float* __restrict__ dL_dcolor = grads.dL_dcolor[view];
+    const float* __restrict__ dL_ddepth = grads.dL_ddepth[view];
+    const float* __restrict__ dL_dalpha = grads.dL_dalpha[view];
+    const float* __restrict__ final_T = final_T_all + (size_t)view * H * W;
+    const uint32_t* __restrict__ n_contrib = n_contrib_all + (size_t)view * H * W;
     const int lane = threadIdx.x;
     const int qx = (tile % gx) * TILE + (quad & 1) * 8, qy = (tile / gx) * TILE + (quad >> 1) * 8;
     const int px = qx + (lane & 7), py = qy + (lane >> 3);
@@ -177,7 +187,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     const float fx = (float)px, fy = (float)py;
     const size_t plane = (size_t)H * W;
     const size_t pix = inside ? (size_t)py * W + px : 0;
-    const uint32_t beg = ranges[2 * tile], end0 = ranges[2 * tile + 1];
+    const uint32_t beg = ranges[2 * gtile], end0 = ranges[2 * gtile + 1];
 
     // per-pixel constants
     float g[NC];
@@ -344,7 +354,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 const int e = k * WAVE + lane;
                 if (k * WAVE < ncand * PPR && e < ncand * PPR) {
                     const int row = e / PPR, pc = e - row * PPR;
-                    __builtin_amdgcn_global_load_lds(&featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))],
+                    __builtin_amdgcn_global_load_lds(&featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row] - row0), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))],
                                                      reinterpret_cast<float4*>(s_feat) + k * WAVE, 16, 0, 0);
                 }
             }
@@ -354,7 +364,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #pragma unroll SR_BWD_STAGE_UNROLL
             for (int e = lane; e < SR_ABLATE_STAGE_N(ncand * PPR); e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
-                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];
+                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row] - row0), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];
             }
             __builtin_amdgcn_wave_barrier();
 #endif
@@ -562,25 +572,31 @@ extern "C" int splatraster_debug_bwd_prof(unsigned long long* out, int reset)
 #endif
 
 
+static int g_small_panel_max_waves = SR_BWD_SMALL_PANEL_MAX_WAVES;
+void set_small_panel_max_waves(int waves) { g_small_panel_max_waves = waves < 0 ? SR_BWD_SMALL_PANEL_MAX_WAVES : waves; }
+
+struct BwdLaunch {
+    int P, V;
+    const WinGrad* grads;
+};
+
 template <int NC, bool DET>
 static int launch_one_bwd(const splatraster_settings& s, int c0, int first, const GeomView& g,
                           const BinView& b, const ImgView& im, const float* feat, int feat_stride,
-                          const float* out_color, const float* out_depth, const float* dL_dcolor,
-                          const float* dL_ddepth, const float* dL_dalpha, float* gacc, long long* gacc64,
-                          hipStream_t stream)
+                          const BwdLaunch& L, float* gacc, long long* gacc64, hipStream_t stream)
 {
     (void)g;
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
     const int tiles = gx * gy;
-    const unsigned blocks = quadrant_blocks(tiles, gx);  // 4 quadrants per tile (+ padding of the id space)
+    const unsigned blocks = quadrant_blocks(L.V * tiles, gx);  // 4 quadrants per (view, tile) (+ padding of the id space)
 #define SR_BWD_LAUNCH(SPV)                                                                                          \
     hipLaunchKernelGGL((composite_bwd_kernel<NC, DET, SPV>), dim3(blocks), dim3(WAVE), 0, stream, s.image_width,        \
-                       s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, b.ranges,      \
-                       b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), out_color, out_depth,     \
-                       im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, gacc, gacc_row_floats(s.channels),   \
+                       s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, L.V, L.P,      \
+                       b.ranges, b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), *L.grads,       \
+                       im.final_T, im.n_contrib, gacc, gacc_row_floats(s.channels),                                    \
                        gacc_moment_offset(s.channels), gacc64)
     if constexpr (NC >= 4 && NC <= 15) {   // C = 3 and below: the flush costs what the 8 saved butterfly values gain (A/B: S0 0.036 vs 0.041 ms)
-        if (4 * tiles <= SR_BWD_SMALL_PANEL_MAX_WAVES)
+        if (4 * L.V * tiles <= g_small_panel_max_waves)   // every quadrant-wave of the launch resident at once
             SR_BWD_LAUNCH(true);
         else
             SR_BWD_LAUNCH(false);
@@ -592,17 +608,15 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
     return SPLATRASTER_OK;
 }
 
-int launch_composite_bwd(const splatraster_settings& s, int32_t P, int64_t R, const GeomView& g,
+int launch_composite_bwd(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g,
                          const BinView& b, const ImgView& im, const float* feat, int feat_stride,
-                         const float* out_color, const float* out_depth, const float* dL_dcolor,
-                         const float* dL_ddepth, const float* dL_dalpha, float* gacc, long long* gacc64,
-                         hipStream_t stream)
+                         const WinGrad& grads, float* gacc, long long* gacc64, hipStream_t stream)
 {
-    (void)P;
     if (R == 0) return SPLATRASTER_OK;
     const bool det = gacc64 != nullptr;
     const int C = s.channels;
-#define SR_BWD_ARGS g, b, im, feat, feat_stride, out_color, out_depth, dL_dcolor, dL_ddepth, dL_dalpha, gacc, gacc64, stream
+    const BwdLaunch L{P, V, &grads};
+#define SR_BWD_ARGS g, b, im, feat, feat_stride, L, gacc, gacc64, stream
 #define SR_BWD_ONE(N, c0_, first_) (det ? launch_one_bwd<N, true>(s, c0_, first_, SR_BWD_ARGS) : launch_one_bwd<N, false>(s, c0_, first_, SR_BWD_ARGS))
 #define SR_BWD_CASE(N) \
     case N: return SR_BWD_ONE(N, 0, 1);

@@ -94,13 +94,13 @@ struct FwdCfg {
 
 template <int NC>
 __global__ void __launch_bounds__(WAVE, SR_FWD_MINW)
-composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_aux, int tiles,
+composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_aux, int tiles /*per view*/, int V,
+                     int P /*rows per view*/,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                      const float4* __restrict__ irec,
                      const uint8_t* __restrict__ imask, const float4* __restrict__ featp4,
-                     const float* __restrict__ bg, float* __restrict__ out_color,
-                     float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+                     const float* __restrict__ bg, WinOut outs,
+                     float* __restrict__ final_T_all, uint32_t* __restrict__ n_contrib_all)
 {
     using Cfg = FwdCfg<NC>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, FS = Cfg::FS;
@@ -124,16 +124,24 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
         }
     } trace_end{__builtin_amdgcn_s_memrealtime(), g_trace_fwd};
 #endif
-    int tile, quad;
+    int gtile, quad;   // global tile = view * tiles + tile: the grid covers the V views of the window
     const int gx = (W + TILE - 1) / TILE;
-    quadrant_of_block(blockIdx.x, tiles, gx, tile, quad);
-    if (tile >= tiles) return;
+    quadrant_of_block(blockIdx.x, V * tiles, gx, gtile, quad);
+    if (gtile >= V * tiles) return;
+    const int view = (V == 1) ? 0 : gtile / tiles;      // wave-uniform (scalar)
+    const int tile = gtile - view * tiles;
+    const uint32_t row0 = (uint32_t)view * (uint32_t)P;  // the view's first row: feature row of row g is g - row0
+    float* __restrict__ out_color = outs.color[view];
+    float* __restrict__ out_depth = outs.depth[view];
+    float* __restrict__ out_alpha = outs.alpha[view];
+    float* __restrict__ final_T = final_T_all + (size_t)view * H * W;
+    uint32_t* __restrict__ n_contrib = n_contrib_all + (size_t)view * H * W;
     const int lane = threadIdx.x;
     const int qx = (tile % gx) * TILE + (quad & 1) * 8, qy = (tile / gx) * TILE + (quad >> 1) * 8;
     const int px = qx + (lane & 7), py = qy + (lane >> 3);
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
-    const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+    const uint32_t beg = ranges[2 * gtile], end = ranges[2 * gtile + 1];
 
     bool active = inside;  // pixel still accumulating
     float T = 1.0f, D = 0.0f;
@@ -182,7 +190,7 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
             const int rank = __popcll(cand & lt_mask);
             const int ncand = min(FS, (int)__popcll(cand));
             __builtin_amdgcn_wave_barrier();
-            if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid;
+            if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid - row0;   // feature row (shared by the views)
             __builtin_amdgcn_wave_barrier();
             // 16-byte pieces of the 16-byte-aligned padded rows
 #if SR_FWD_LDSDMA
@@ -303,34 +311,38 @@ int launch_debug_exp2(int64_t n, const float* x, float* y, hipStream_t stream)
     return SPLATRASTER_OK;
 }
 
+struct FwdLaunch {
+    int P, V;
+    const WinOut* outs;
+};
+
 template <int NC>
 static int launch_one(const splatraster_settings& s, int c0, int write_aux, const GeomView& g,
                       const BinView& b, const ImgView& im, const float* featp, int feat_stride,
-                      const float* bg, float* out_color, float* out_depth, float* out_alpha,
-                      hipStream_t stream)
+                      const float* bg, const FwdLaunch& L, hipStream_t stream)
 {
     (void)g;
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
     const int tiles = gx * gy;
-    const unsigned blocks = quadrant_blocks(tiles, gx);  // 4 quadrants per tile (+ padding of the id space)
+    const unsigned blocks = quadrant_blocks(L.V * tiles, gx);  // 4 quadrants per (view, tile) (+ padding of the id space)
     hipLaunchKernelGGL(composite_fwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
-                       s.image_height, padded_channels(feat_stride) / 4, c0, s.bg_channels, write_aux, tiles, b.ranges,
-                       b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(featp), bg, out_color, out_depth, out_alpha, im.final_T,
+                       s.image_height, padded_channels(feat_stride) / 4, c0, s.bg_channels, write_aux, tiles, L.V, L.P, b.ranges,
+                       b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(featp), bg, *L.outs, im.final_T,
                        im.n_contrib);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
 
-int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomView& g, const BinView& b,
-                         const ImgView& im, const float* featp, const float* bg, float* out_color,
-                         float* out_depth, float* out_alpha, hipStream_t stream)
+int launch_composite_fwd(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g, const BinView& b,
+                         const ImgView& im, const float* featp, const float* bg, const WinOut& outs, hipStream_t stream)
 {
     (void)R;
     const int C = s.channels;
+    const FwdLaunch L{P, V, &outs};
     int c0 = 0, aux = 1, st = SPLATRASTER_OK;
 #define SR_FWD_CASE(N)                                                                              \
     case N:                                                                                         \
-        return launch_one<N>(s, 0, 1, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream);
+        return launch_one<N>(s, 0, 1, g, b, im, featp, C, bg, L, stream);
     switch (C) {
         SR_FWD_CASE(1) SR_FWD_CASE(2) SR_FWD_CASE(3) SR_FWD_CASE(4) SR_FWD_CASE(8) SR_FWD_CASE(16)
         SR_FWD_CASE(32) SR_FWD_CASE(35)
@@ -340,13 +352,13 @@ int launch_composite_fwd(const splatraster_settings& s, int64_t R, const GeomVie
     // generic channel count: chunked passes (alpha is re-evaluated per chunk)
     while (c0 < C && st == SPLATRASTER_OK) {
         const int left = C - c0;
-        if (left >= 32) { st = launch_one<32>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 32; }
-        else if (left >= 16) { st = launch_one<16>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 16; }
-        else if (left >= 8) { st = launch_one<8>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 8; }
-        else if (left >= 4) { st = launch_one<4>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 4; }
-        else if (left == 3) { st = launch_one<3>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 3; }
-        else if (left == 2) { st = launch_one<2>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 2; }
-        else { st = launch_one<1>(s, c0, aux, g, b, im, featp, C, bg, out_color, out_depth, out_alpha, stream); c0 += 1; }
+        if (left >= 32) { st = launch_one<32>(s, c0, aux, g, b, im, featp, C, bg, L, stream); c0 += 32; }
+        else if (left >= 16) { st = launch_one<16>(s, c0, aux, g, b, im, featp, C, bg, L, stream); c0 += 16; }
+        else if (left >= 8) { st = launch_one<8>(s, c0, aux, g, b, im, featp, C, bg, L, stream); c0 += 8; }
+        else if (left >= 4) { st = launch_one<4>(s, c0, aux, g, b, im, featp, C, bg, L, stream); c0 += 4; }
+        else if (left == 3) { st = launch_one<3>(s, c0, aux, g, b, im, featp, C, bg, L, stream); c0 += 3; }
+        else if (left == 2) { st = launch_one<2>(s, c0, aux, g, b, im, featp, C, bg, L, stream); c0 += 2; }
+        else { st = launch_one<1>(s, c0, aux, g, b, im, featp, C, bg, L, stream); c0 += 1; }
         aux = 0;
     }
     return st;

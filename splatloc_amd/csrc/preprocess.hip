@@ -86,16 +86,17 @@ __device__ void sh_to_rgb(int deg, const float* sh, float px, float py, float pz
     }
 }
 
+// One thread per Gaussian, looping over the V views of the window: the view-independent work (loading the
+// parameters, the 3D covariance) is done once, then every view projects it with its own camera.  Row
+// g = v * P + i of the geometry buffer is Gaussian i seen from view v.
 __global__ void __launch_bounds__(PREPROCESS_BLOCK)
-preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale_modifier, int sh_degree,
-                  int sh_coeffs, const float* __restrict__ means3D, const float* __restrict__ shs,
+preprocess_kernel(int P, int V, int W, int H, float scale_modifier, int sh_degree, int sh_coeffs, WinCams cams,
+                  const float* __restrict__ means3D, const float* __restrict__ shs,
                   const float* __restrict__ opacities, const float* __restrict__ scales,
                   const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
-                  const float* __restrict__ view, const float* __restrict__ proj,
-                  const float* __restrict__ campos_p,
                   float4* __restrict__ rec, uint32_t* __restrict__ tiles_touched,
-                  float* __restrict__ rgb, uint8_t* __restrict__ clamped, int32_t* __restrict__ radii,
-                  uint32_t* __restrict__ block_tiles /*[gridDim.x] per-block sums of tiles_touched*/,
+                  float* __restrict__ rgb, uint8_t* __restrict__ clamped,
+                  uint32_t* __restrict__ block_tiles /*[V][gridDim.x] per-(view, block) sums of tiles_touched*/,
                   uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals /*depth-sort input*/,
                   uint32_t* __restrict__ zero0, uint32_t nzero0, uint32_t* __restrict__ zero1, uint32_t nzero1)
 {
@@ -106,128 +107,137 @@ preprocess_kernel(int P, int W, int H, float tanfovx, float tanfovy, float scale
     for (uint32_t w = (uint32_t)gi; w < nzero1; w += gridDim.x * blockDim.x) zero1[w] = 0u;
     const bool live = gi < P;
     const int i = live ? gi : P - 1;  // padding lanes recompute the last Gaussian and store nothing
-    // camera tensors: wave-uniform addresses -> scalar loads, SGPR-resident
-    float V[16], PM[16], campos[3];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { V[k] = view[k]; PM[k] = proj[k]; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) campos[k] = campos_p ? campos_p[k] : 0.f;
-    int32_t out_radius = 0;
-    uint32_t out_tiles = 0;
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-
     const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
-    const float tx0 = ((V[0] * px + V[4] * py) + V[8] * pz) + V[12];
-    const float ty0 = ((V[1] * px + V[5] * py) + V[9] * pz) + V[13];
-    const float tz = ((V[2] * px + V[6] * py) + V[10] * pz) + V[14];
-    if (live && tz > NEAR_Z) {
-        const float hx = ((PM[0] * px + PM[4] * py) + PM[8] * pz) + PM[12];
-        const float hy = ((PM[1] * px + PM[5] * py) + PM[9] * pz) + PM[13];
-        const float hw = ((PM[3] * px + PM[7] * py) + PM[11] * pz) + PM[15];
-        const float p_w = 1.0f / (hw + 0.0000001f);
-        const float ndc_x = hx * p_w, ndc_y = hy * p_w;
-        float c6[6];
-        if (cov3D_precomp) {
+    const float opacity = opacities[i];
+    float c6[6];
+    if (cov3D_precomp) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
-        } else {
-            const float s3[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
-            const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
-            const float q[4] = {qv.x, qv.y, qv.z, qv.w};
-            cov3d_from_scale_rot(s3, scale_modifier, q, c6);
-        }
-        const float focal_x = (float)W / (2.0f * tanfovx);
-        const float focal_y = (float)H / (2.0f * tanfovy);
-        const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
-        const float txtz = tx0 / tz, tytz = ty0 / tz;
-        const float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
-        const float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
-        const float j00 = focal_x / tz, j02 = -(focal_x * tx) / (tz * tz);
-        const float j11 = focal_y / tz, j12 = -(focal_y * ty) / (tz * tz);
-        float A0[3], A1[3];
+        for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+    } else {
+        const float s3[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
+        const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        cov3d_from_scale_rot(s3, scale_modifier, q, c6);
+    }
+    const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    __shared__ uint32_t s_part[MAX_VIEWS][PREPROCESS_BLOCK / WAVE];
+
+#pragma unroll 1
+    for (int v = 0; v < V; ++v) {
+        // camera tensors: wave-uniform addresses -> scalar loads, SGPR-resident
+        const float* __restrict__ view = cams.view[v];
+        const float* __restrict__ proj = cams.proj[v];
+        const float* __restrict__ campos_p = cams.campos[v];
+        const float tanfovx = cams.tanfovx[v], tanfovy = cams.tanfovy[v];
+        float Vm[16], PM[16], campos[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            A0[c] = j00 * V[4 * c + 0] + j02 * V[4 * c + 2];
-            A1[c] = j11 * V[4 * c + 1] + j12 * V[4 * c + 2];
-        }
-        const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
-        float SA0[3], SA1[3];
+        for (int k = 0; k < 16; ++k) { Vm[k] = view[k]; PM[k] = proj[k]; }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            SA0[j] = (S[j][0] * A0[0] + S[j][1] * A0[1]) + S[j][2] * A0[2];
-            SA1[j] = (S[j][0] * A1[0] + S[j][1] * A1[1]) + S[j][2] * A1[2];
-        }
-        const float a = ((A0[0] * SA0[0] + A0[1] * SA0[1]) + A0[2] * SA0[2]) + DILATION;
-        const float b = (A0[0] * SA1[0] + A0[1] * SA1[1]) + A0[2] * SA1[2];
-        const float c = ((A1[0] * SA1[0] + A1[1] * SA1[1]) + A1[2] * SA1[2]) + DILATION;
-        const float det = a * c - b * b;
-        if (det != 0.0f) {
-            const float det_inv = 1.0f / det;
-            const float mid = 0.5f * (a + c);
-            const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
-            const float lambda1 = mid + disc, lambda2 = mid - disc;
-            const float rad_f = ceilf(3.0f * sqrtf(fmaxf(lambda1, lambda2)));
-            const int my_radius = f2i_sat(rad_f);
-            const float pixx = ((ndc_x + 1.0f) * (float)W - 1.0f) * 0.5f;
-            const float pixy = ((ndc_y + 1.0f) * (float)H - 1.0f) * 0.5f;
-            const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-            const float rf = (float)my_radius;
-            const int rminx = min(gx, max(0, f2i_sat((pixx - rf) / (float)TILE)));
-            const int rminy = min(gy, max(0, f2i_sat((pixy - rf) / (float)TILE)));
-            const int rmaxx = min(gx, max(0, f2i_sat((pixx + rf + (float)(TILE - 1)) / (float)TILE)));
-            const int rmaxy = min(gy, max(0, f2i_sat((pixy + rf + (float)(TILE - 1)) / (float)TILE)));
-            const int area = (rmaxx - rminx) * (rmaxy - rminy);
-            if (area > 0) {
-                if (shs) {
-                    sh_to_rgb(sh_degree, shs + (size_t)i * sh_coeffs * 3, px, py, pz, campos,
-                              rgb + 3 * (size_t)i, clamped + 3 * (size_t)i);
+        for (int k = 0; k < 3; ++k) campos[k] = campos_p ? campos_p[k] : 0.f;
+        int32_t out_radius = 0;
+        uint32_t out_tiles = 0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        const float tx0 = ((Vm[0] * px + Vm[4] * py) + Vm[8] * pz) + Vm[12];
+        const float ty0 = ((Vm[1] * px + Vm[5] * py) + Vm[9] * pz) + Vm[13];
+        const float tz = ((Vm[2] * px + Vm[6] * py) + Vm[10] * pz) + Vm[14];
+        if (live && tz > NEAR_Z) {
+            const float hx = ((PM[0] * px + PM[4] * py) + PM[8] * pz) + PM[12];
+            const float hy = ((PM[1] * px + PM[5] * py) + PM[9] * pz) + PM[13];
+            const float hw = ((PM[3] * px + PM[7] * py) + PM[11] * pz) + PM[15];
+            const float p_w = 1.0f / (hw + 0.0000001f);
+            const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+            const float focal_x = (float)W / (2.0f * tanfovx);
+            const float focal_y = (float)H / (2.0f * tanfovy);
+            const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+            const float txtz = tx0 / tz, tytz = ty0 / tz;
+            const float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+            const float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+            const float j00 = focal_x / tz, j02 = -(focal_x * tx) / (tz * tz);
+            const float j11 = focal_y / tz, j12 = -(focal_y * ty) / (tz * tz);
+            float A0[3], A1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                A0[c] = j00 * Vm[4 * c + 0] + j02 * Vm[4 * c + 2];
+                A1[c] = j11 * Vm[4 * c + 1] + j12 * Vm[4 * c + 2];
+            }
+            float SA0[3], SA1[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                SA0[j] = (S[j][0] * A0[0] + S[j][1] * A0[1]) + S[j][2] * A0[2];
+                SA1[j] = (S[j][0] * A1[0] + S[j][1] * A1[1]) + S[j][2] * A1[2];
+            }
+            const float a = ((A0[0] * SA0[0] + A0[1] * SA0[1]) + A0[2] * SA0[2]) + DILATION;
+            const float b = (A0[0] * SA1[0] + A0[1] * SA1[1]) + A0[2] * SA1[2];
+            const float c = ((A1[0] * SA1[0] + A1[1] * SA1[1]) + A1[2] * SA1[2]) + DILATION;
+            const float det = a * c - b * b;
+            if (det != 0.0f) {
+                const float det_inv = 1.0f / det;
+                const float mid = 0.5f * (a + c);
+                const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lambda1 = mid + disc, lambda2 = mid - disc;
+                const float rad_f = ceilf(3.0f * sqrtf(fmaxf(lambda1, lambda2)));
+                const int my_radius = f2i_sat(rad_f);
+                const float pixx = ((ndc_x + 1.0f) * (float)W - 1.0f) * 0.5f;
+                const float pixy = ((ndc_y + 1.0f) * (float)H - 1.0f) * 0.5f;
+                const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+                const float rf = (float)my_radius;
+                const int rminx = min(gx, max(0, f2i_sat((pixx - rf) / (float)TILE)));
+                const int rminy = min(gy, max(0, f2i_sat((pixy - rf) / (float)TILE)));
+                const int rmaxx = min(gx, max(0, f2i_sat((pixx + rf + (float)(TILE - 1)) / (float)TILE)));
+                const int rmaxy = min(gy, max(0, f2i_sat((pixy + rf + (float)(TILE - 1)) / (float)TILE)));
+                const int area = (rmaxx - rminx) * (rmaxy - rminy);
+                if (area > 0) {
+                    if (shs) {   // single-view calls only (V == 1: row == i)
+                        sh_to_rgb(sh_degree, shs + (size_t)i * sh_coeffs * 3, px, py, pz, campos,
+                                  rgb + 3 * (size_t)i, clamped + 3 * (size_t)i);
+                    }
+                    out_radius = my_radius;
+                    out_tiles = (uint32_t)area;
+                    r0 = make_float4(pixx, pixy, tz, (float)my_radius);
+                    r1 = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacity);
                 }
-                out_radius = my_radius;
-                out_tiles = (uint32_t)area;
-                r0 = make_float4(pixx, pixy, tz, (float)my_radius);
-                r1 = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacities[i]);
             }
         }
-    }
-    if (live) {
-        radii[i] = out_radius;
-        tiles_touched[i] = out_tiles;
-        rec[2 * i] = r0;
-        rec[2 * i + 1] = r1;
-        // input of the depth sort: view depth > 0.2 for every visible Gaussian, so its IEEE bits
-        // order like the value; culled Gaussians sort to the end
-        sort_keys[i] = out_radius > 0 ? __float_as_uint(tz) : 0xFFFFFFFFu;
-        sort_vals[i] = (uint32_t)i;
+        if (live) {
+            const size_t g = (size_t)v * P + i;
+            cams.radii[v][i] = out_radius;
+            tiles_touched[g] = out_tiles;
+            rec[2 * g] = r0;
+            rec[2 * g + 1] = r1;
+            // input of the depth sort: view depth > 0.2 for every visible Gaussian, so its IEEE bits
+            // order like the value; culled rows sort to the end
+            sort_keys[g] = out_radius > 0 ? __float_as_uint(tz) : 0xFFFFFFFFu;
+            sort_vals[g] = (uint32_t)g;
+        }
+        uint32_t t = out_tiles;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) t += (uint32_t)__shfl_xor((int)t, d, WAVE);
+        if ((threadIdx.x & (WAVE - 1)) == 0) s_part[v][threadIdx.x / WAVE] = t;
     }
     // The instance count R = sum of tiles_touched is needed on the HOST (it sizes the binning
-    // buffer).  Per-block sums written here (no atomics, nothing to zero) are copied out and
+    // buffer).  Per-(view, block) sums written here (no atomics, nothing to zero) are copied out and
     // added up by the host while the depth sort and the scan are still executing (capi.hip).
-    __shared__ uint32_t s_part[PREPROCESS_BLOCK / WAVE];
-    uint32_t t = out_tiles;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) t += (uint32_t)__shfl_xor((int)t, d, WAVE);
-    if ((threadIdx.x & (WAVE - 1)) == 0) s_part[threadIdx.x / WAVE] = t;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x < V) {
         uint32_t sum = 0;
 #pragma unroll
-        for (int k = 0; k < PREPROCESS_BLOCK / WAVE; ++k) sum += s_part[k];
-        block_tiles[blockIdx.x] = sum;
+        for (int k = 0; k < PREPROCESS_BLOCK / WAVE; ++k) sum += s_part[threadIdx.x][k];
+        block_tiles[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sum;
     }
 }
 
-int launch_preprocess(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
-                      const float* opacities, const float* scales, const float* rotations,
-                      const float* cov3D_precomp, const float* view, const float* proj,
-                      const float* campos, GeomView g, int32_t* radii, uint32_t* zero0, uint32_t nzero0,
+int launch_preprocess(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const float* means3D,
+                      const float* shs, const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp, GeomView g, uint32_t* zero0, uint32_t nzero0,
                       uint32_t* zero1, uint32_t nzero1, hipStream_t stream)
 {
     if (P == 0) return SPLATRASTER_OK;
     const int blocks = preprocess_blocks(P);
-    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(PREPROCESS_BLOCK), 0, stream, P, s.image_width,
-                       s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs,
-                       means3D, shs, opacities, scales, rotations, cov3D_precomp, view, proj, campos, g.rec,
-                       g.tiles_touched, g.rgb, g.clamped, radii, g.block_tiles, g.sort_keys, g.depth_order, zero0, nzero0, zero1, nzero1);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(PREPROCESS_BLOCK), 0, stream, P, V, s.image_width,
+                       s.image_height, s.scale_modifier, s.sh_degree, s.sh_coeffs, cams,
+                       means3D, shs, opacities, scales, rotations, cov3D_precomp, g.rec,
+                       g.tiles_touched, g.rgb, g.clamped, g.block_tiles, g.sort_keys, g.depth_order, zero0, nzero0, zero1, nzero1);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

@@ -82,53 +82,93 @@ __device__ void sh_backward(int deg, int M, const float* sh, float* dsh, const u
     dmean[2] += (ddir[2] - z * dot) / len;
 }
 
+// One thread per Gaussian, looping over the V views of the window: the contributions of every view (accumulator
+// row g = v * P + i, forward record rec[g], the view's camera) are summed in view order into ONE set of parameter
+// gradients, written once — no per-view gradient tensors, no accumulation kernels, a deterministic sum.
+// dL/dmeans2D stays per view (GaussianModel.add_densification_stats reads it per view).
 template <bool POSE>
 __global__ void __launch_bounds__(256)
-preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float mod, int sh_degree, int M,
+preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int M, WinCams cams, WinGrad grads,
                       const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
-                      const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
-                      const float* __restrict__ proj, const float* __restrict__ campos_p,
-                      const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+                      const float* __restrict__ cov3D_precomp,
+                      const uint8_t* __restrict__ clamped,
                       const float4* __restrict__ rec, const float* __restrict__ gacc, int C, int GROW, int MO,
-                      float* __restrict__ dL_dcolors,
-                      float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+                      float* __restrict__ dL_dmeans3D,
                       float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dshs, float* __restrict__ dL_dview, float* __restrict__ dL_dproj,
                       float* __restrict__ dL_dcampos)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    // pose partials of this Gaussian: dV[4c + r] (r < 3), dPM[4c + k] (k = 0, 1, 3), dcampos
+    // pose partials of this Gaussian: dV[4c + r] (r < 3), dPM[4c + k] (k = 0, 1, 3), dcampos   (V == 1 only)
     float pose[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) pose[k] = 0.f;
     if (i < P) {
-    float V[16], PM[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { V[k] = view[k]; PM[k] = proj[k]; }
-
     float dmean[3] = {0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float dm2x = 0.f, dm2y = 0.f, dop = 0.f;
-    const bool visible = radii[i] > 0;
+    float dop = 0.f;
+    bool any_visible = false;
+    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    // 3D covariance (recomputed; same formula as the forward) — view independent
+    float c6[6];
+    float Rm[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, sc[3] = {0.f, 0.f, 0.f};
+    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+    } else {
+        qv = reinterpret_cast<const float4*>(rotations)[i];
+        const float r = qv.x, x = qv.y, y = qv.z, z = qv.w;
+        Rm[0][0] = 1.f - 2.f * (y * y + z * z); Rm[0][1] = 2.f * (x * y - r * z); Rm[0][2] = 2.f * (x * z + r * y);
+        Rm[1][0] = 2.f * (x * y + r * z); Rm[1][1] = 1.f - 2.f * (x * x + z * z); Rm[1][2] = 2.f * (y * z - r * x);
+        Rm[2][0] = 2.f * (x * z - r * y); Rm[2][1] = 2.f * (y * z + r * x); Rm[2][2] = 1.f - 2.f * (x * x + y * y);
+        sc[0] = mod * scales[3 * i]; sc[1] = mod * scales[3 * i + 1]; sc[2] = mod * scales[3 * i + 2];
+        float L[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) L[j][k] = Rm[j][k] * sc[k];
+        c6[0] = L[0][0] * L[0][0] + L[0][1] * L[0][1] + L[0][2] * L[0][2];
+        c6[1] = L[0][0] * L[1][0] + L[0][1] * L[1][1] + L[0][2] * L[1][2];
+        c6[2] = L[0][0] * L[2][0] + L[0][1] * L[2][1] + L[0][2] * L[2][2];
+        c6[3] = L[1][0] * L[1][0] + L[1][1] * L[1][1] + L[1][2] * L[1][2];
+        c6[4] = L[1][0] * L[2][0] + L[1][1] * L[2][1] + L[1][2] * L[2][2];
+        c6[5] = L[2][0] * L[2][0] + L[2][1] * L[2][1] + L[2][2] * L[2][2];
+    }
+    const float S3[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float G3s[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // dL/dSigma3 summed over the views
+
+#pragma unroll 1
+    for (int v = 0; v < V; ++v) {
+    const float* __restrict__ view = cams.view[v];
+    const float* __restrict__ proj = cams.proj[v];
+    const float* __restrict__ campos_p = cams.campos[v];
+    const float tanfovx = cams.tanfovx[v], tanfovy = cams.tanfovy[v];
+    float Vm[16], PM[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { Vm[k] = view[k]; PM[k] = proj[k]; }
+    const size_t gr = (size_t)v * P + i;   // row of (view, Gaussian)
+    float dm2x = 0.f, dm2y = 0.f;
+    const bool visible = cams.radii[v][i] > 0;
     if (visible) {
-        const float* mrow = gacc + (size_t)i * GROW + MO;  // moment record of this Gaussian
+        any_visible = true;
+        const float* mrow = gacc + gr * GROW + MO;  // moment record of this row
         const float4 g0 = make_float4(mrow[0], mrow[1], mrow[2], mrow[3]);
         const float4 g1 = make_float4(mrow[4], mrow[5], mrow[6], 0.f);
-        const float4 con = rec[2 * (size_t)i + 1];  // conic a, b, c, opacity of the forward
+        const float4 con = rec[2 * gr + 1];  // conic a, b, c, opacity of the forward
         // power = -1/2 (A dx^2 + C dy^2) - B dx dy, alpha = o G:
         dm2x = -0.5f * (float)W * con.w * (con.x * g0.x + con.y * g0.y);
         dm2y = -0.5f * (float)H * con.w * (con.z * g0.y + con.y * g0.x);
         const float gA = -0.5f * con.w * g0.z, gB = -con.w * g0.w, gC = -0.5f * con.w * g1.x;
-        dop = g1.y;
+        dop += g1.y;
         const float gdepth = g1.z;
-        const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
-        const float tx0 = V[0] * px + V[4] * py + V[8] * pz + V[12];
-        const float ty0 = V[1] * px + V[5] * py + V[9] * pz + V[13];
-        const float tz = V[2] * px + V[6] * py + V[10] * pz + V[14];
+        const float tx0 = Vm[0] * px + Vm[4] * py + Vm[8] * pz + Vm[12];
+        const float ty0 = Vm[1] * px + Vm[5] * py + Vm[9] * pz + Vm[13];
+        const float tz = Vm[2] * px + Vm[6] * py + Vm[10] * pz + Vm[14];
         const float focal_x = (float)W / (2.0f * tanfovx), focal_y = (float)H / (2.0f * tanfovy);
         const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
         const float txtz = tx0 / tz, tytz = ty0 / tz;
@@ -143,35 +183,9 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
         float A0[3], A1[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            A0[c] = J00 * V[4 * c + 0] + J02 * V[4 * c + 2];
-            A1[c] = J11 * V[4 * c + 1] + J12 * V[4 * c + 2];
+            A0[c] = J00 * Vm[4 * c + 0] + J02 * Vm[4 * c + 2];
+            A1[c] = J11 * Vm[4 * c + 1] + J12 * Vm[4 * c + 2];
         }
-        // 3D covariance (recomputed; same formula as the forward)
-        float c6[6];
-        float Rm[3][3], sc[3] = {0.f, 0.f, 0.f};
-        if (cov3D_precomp) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
-        } else {
-            const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
-            const float r = qv.x, x = qv.y, y = qv.z, z = qv.w;
-            Rm[0][0] = 1.f - 2.f * (y * y + z * z); Rm[0][1] = 2.f * (x * y - r * z); Rm[0][2] = 2.f * (x * z + r * y);
-            Rm[1][0] = 2.f * (x * y + r * z); Rm[1][1] = 1.f - 2.f * (x * x + z * z); Rm[1][2] = 2.f * (y * z - r * x);
-            Rm[2][0] = 2.f * (x * z - r * y); Rm[2][1] = 2.f * (y * z + r * x); Rm[2][2] = 1.f - 2.f * (x * x + y * y);
-            sc[0] = mod * scales[3 * i]; sc[1] = mod * scales[3 * i + 1]; sc[2] = mod * scales[3 * i + 2];
-            float L[3][3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) L[j][k] = Rm[j][k] * sc[k];
-            c6[0] = L[0][0] * L[0][0] + L[0][1] * L[0][1] + L[0][2] * L[0][2];
-            c6[1] = L[0][0] * L[1][0] + L[0][1] * L[1][1] + L[0][2] * L[1][2];
-            c6[2] = L[0][0] * L[2][0] + L[0][1] * L[2][1] + L[0][2] * L[2][2];
-            c6[3] = L[1][0] * L[1][0] + L[1][1] * L[1][1] + L[1][2] * L[1][2];
-            c6[4] = L[1][0] * L[2][0] + L[1][1] * L[2][1] + L[1][2] * L[2][2];
-            c6[5] = L[2][0] * L[2][0] + L[2][1] * L[2][1] + L[2][2] * L[2][2];
-        }
-        const float S3[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
         float SA0[3], SA1[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -190,48 +204,24 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
             dL_dc = (-b * b * gA + a * b * gB - a * a * gC) * d2;
         }
         const float G2[2][2] = {{dL_da, 0.5f * dL_db}, {0.5f * dL_db, dL_dc}};
-        // dL/dSigma3 (full symmetric) = A^T G2 A
+        // dL/dSigma3 (full symmetric) = A^T G2 A — linear in the view's contribution, chained to scale / quaternion
+        // once after the loop
         float GA0[3], GA1[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             GA0[k] = G2[0][0] * A0[k] + G2[0][1] * A1[k];
             GA1[k] = G2[1][0] * A0[k] + G2[1][1] * A1[k];
         }
-        float G3[3][3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) G3[j][k] = A0[j] * GA0[k] + A1[j] * GA1[k];
-        if (cov3D_precomp) {
-            dcov[0] = G3[0][0]; dcov[1] = 2.f * G3[0][1]; dcov[2] = 2.f * G3[0][2];
-            dcov[3] = G3[1][1]; dcov[4] = 2.f * G3[1][2]; dcov[5] = G3[2][2];
-        } else {
-            // Sigma3 = L L^T, L = R diag(s)  =>  dL/dL = 2 G3 L
-            float dR[3][3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float ds = 0.f;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float dLjk = 2.f * (G3[j][0] * Rm[0][k] + G3[j][1] * Rm[1][k] + G3[j][2] * Rm[2][k]) * sc[k];
-                    ds += dLjk * Rm[j][k];
-                    dR[j][k] = dLjk * sc[k];
-                }
-                dscale[k] = ds * mod;
-            }
-            const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
-            const float r = qv.x, x = qv.y, y = qv.z, z = qv.w;
-            drot[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
-            drot[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
-            drot[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
-            drot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
-        }
+            for (int k = 0; k < 3; ++k) G3s[j][k] += A0[j] * GA0[k] + A1[j] * GA1[k];
         // dL/dJ = 2 G2 J Sigma_v with J Sigma_v = (A Sigma3) Wv^T ; (A Sigma3)[r][k] = SA_r[k]
         float JS0[3], JS1[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {  // column k of Sigma_v side: sum_c SA[c] * Wv[k][c]
-            JS0[k] = SA0[0] * V[0 + k] + SA0[1] * V[4 + k] + SA0[2] * V[8 + k];
-            JS1[k] = SA1[0] * V[0 + k] + SA1[1] * V[4 + k] + SA1[2] * V[8 + k];
+            JS0[k] = SA0[0] * Vm[0 + k] + SA0[1] * Vm[4 + k] + SA0[2] * Vm[8 + k];
+            JS1[k] = SA1[0] * Vm[0 + k] + SA1[1] * Vm[4 + k] + SA1[2] * Vm[8 + k];
         }
         const float dJ00 = 2.f * (G2[0][0] * JS0[0] + G2[0][1] * JS1[0]);
         const float dJ02 = 2.f * (G2[0][0] * JS0[2] + G2[0][1] * JS1[2]);
@@ -243,7 +233,7 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
                           2.f * focal_y * ty * itz3 * dJ12;
 #pragma unroll
         for (int k = 0; k < 3; ++k)  // Wv^T [dtx dty dtz]: Wv[r][k] = V[4k + r]
-            dmean[k] += V[4 * k + 0] * dtx + V[4 * k + 1] * dty + V[4 * k + 2] * (dtz + gdepth);
+            dmean[k] += Vm[4 * k + 0] * dtx + Vm[4 * k + 1] * dty + Vm[4 * k + 2] * (dtz + gdepth);
         if (POSE) {
             // t = Wv p + trans (V[4c + r] multiplies p[c] into t[r]); cov2D = A Sigma3 A^T with
             // A = J Wv: dL/dA = 2 G2 A Sigma3, dL/dWv = J^T dL/dA
@@ -283,10 +273,10 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
 #pragma unroll
                 for (int j = 0; j < 3; ++j) pose[12 + 3 * c + j] = dh[j] * p4[c];
         }
-        if (shs) {
+        if (shs) {   // single-view calls only
             const float sm0 = dmean[0], sm1 = dmean[1], sm2 = dmean[2];
             sh_backward(sh_degree, M, shs + (size_t)i * 3 * M, dL_dshs + (size_t)i * 3 * M, clamped + 3 * (size_t)i,
-                        gacc + (size_t)i * GROW, px - campos_p[0], py - campos_p[1], pz - campos_p[2], dmean);
+                        gacc + gr * GROW, px - campos_p[0], py - campos_p[1], pz - campos_p[2], dmean);
             if (POSE) {  // direction = normalize(p - campos)
                 pose[24] = -(dmean[0] - sm0);
                 pose[25] = -(dmean[1] - sm1);
@@ -296,11 +286,39 @@ preprocess_bwd_kernel(int P, int W, int H, float tanfovx, float tanfovy, float m
     } else if (shs && dL_dshs) {
         for (int k = 0; k < 3 * M; ++k) dL_dshs[(size_t)i * 3 * M + k] = 0.f;
     }
+    float* __restrict__ dm2 = grads.dL_dmeans2D[v];
+    dm2[3 * i] = dm2x;
+    dm2[3 * i + 1] = dm2y;
+    dm2[3 * i + 2] = 0.f;
+    }  // views
+
+    if (any_visible) {
+        if (cov3D_precomp) {
+            dcov[0] = G3s[0][0]; dcov[1] = 2.f * G3s[0][1]; dcov[2] = 2.f * G3s[0][2];
+            dcov[3] = G3s[1][1]; dcov[4] = 2.f * G3s[1][2]; dcov[5] = G3s[2][2];
+        } else {
+            // Sigma3 = L L^T, L = R diag(s)  =>  dL/dL = 2 G3 L
+            float dR[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float ds = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float dLjk = 2.f * (G3s[j][0] * Rm[0][k] + G3s[j][1] * Rm[1][k] + G3s[j][2] * Rm[2][k]) * sc[k];
+                    ds += dLjk * Rm[j][k];
+                    dR[j][k] = dLjk * sc[k];
+                }
+                dscale[k] = ds * mod;
+            }
+            const float r = qv.x, x = qv.y, y = qv.z, z = qv.w;
+            drot[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            drot[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+            drot[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+            drot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = dmean[k];
-    dL_dmeans2D[3 * i] = dm2x;
-    dL_dmeans2D[3 * i + 1] = dm2y;
-    dL_dmeans2D[3 * i + 2] = 0.f;
     dL_dopacities[i] = dop;
     if (dL_dscales) {
 #pragma unroll
@@ -355,21 +373,22 @@ int launch_fixed_to_float(int64_t n, const long long* src, float* dst, hipStream
 }
 
 __global__ void __launch_bounds__(256)
-gather_dcolors_kernel(int64_t n, int C, int GROW, const float* __restrict__ gacc, float* __restrict__ dL_dcolors)
+gather_dcolors_kernel(int64_t n, int C, int GROW, int V, int64_t P, const float* __restrict__ gacc,
+                      float* __restrict__ dL_dcolors)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const int64_t i = e / C;
     const int ch = (int)(e - i * C);
-    dL_dcolors[e] = gacc[i * GROW + ch];
+    float sum = gacc[i * GROW + ch];
+    for (int v = 1; v < V; ++v) sum += gacc[(v * P + i) * GROW + ch];   // the feature table is shared by the views
+    dL_dcolors[e] = sum;
 }
 
-int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float* means3D, const float* shs,
-                          const float* scales, const float* rotations, const float* cov3D_precomp,
-                          const float* view, const float* proj, const float* campos, const int32_t* radii,
-                          const uint8_t* clamped, const float4* rec, const float* gacc, int C,
-                          float* dL_dcolors,
-                          float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
+int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const WinGrad& grads,
+                          const float* means3D, const float* shs, const float* scales, const float* rotations,
+                          const float* cov3D_precomp, const uint8_t* clamped, const float4* rec, const float* gacc, int C,
+                          float* dL_dcolors, float* dL_dmeans3D, float* dL_dopacities, float* dL_dscales,
                           float* dL_drotations, float* dL_dcov3D, float* dL_dshs, float* dL_dview,
                           float* dL_dproj, float* dL_dcampos, hipStream_t stream)
 {
@@ -377,7 +396,7 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float*
     if (dL_dcolors) {
         const int64_t n = (int64_t)P * C;
         hipLaunchKernelGGL(gather_dcolors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, C,
-                           gacc_row_floats(C), gacc, dL_dcolors);
+                           gacc_row_floats(C), V, (int64_t)P, gacc, dL_dcolors);
         SR_LAUNCH_CHECK();
     }
     const bool pose = dL_dview && dL_dproj;
@@ -387,9 +406,9 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, const float*
         if (dL_dcampos) SR_HIP_CHECK(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), stream));
     }
 #define SR_PBWD_ARGS                                                                                              \
-    P, s.image_width, s.image_height, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.sh_coeffs, means3D,   \
-        shs, scales, rotations, cov3D_precomp, view, proj, campos, radii, clamped, rec, gacc, C, gacc_row_floats(C), \
-        gacc_moment_offset(C), dL_dcolors, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscales, dL_drotations,       \
+    P, V, s.image_width, s.image_height, s.scale_modifier, s.sh_degree, s.sh_coeffs, cams, grads, means3D,         \
+        shs, scales, rotations, cov3D_precomp, clamped, rec, gacc, C, gacc_row_floats(C),                          \
+        gacc_moment_offset(C), dL_dmeans3D, dL_dopacities, dL_dscales, dL_drotations,                              \
         dL_dcov3D, dL_dshs, dL_dview, dL_dproj, dL_dcampos
     if (pose)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, SR_PBWD_ARGS);

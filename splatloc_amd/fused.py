@@ -24,7 +24,8 @@ from typing import Optional
 import torch
 
 from . import _native
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, _prep, _ptr, _require_gpu, _stream, _on_device
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _on_device, _prep, _ptr, _require_gpu, _stream,
+                         _window_compatible, rasterize_window)
 
 
 class _ActivatePack(torch.autograd.Function):
@@ -206,8 +207,16 @@ def window_streams(device, n: int):
     return _WINDOW_STREAMS[key]
 
 
-def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, streams: int = 2, per_view=None,
-                  share_activations: bool = True):
+def _view_settings(vp, pc, bg_color, scaling_modifier) -> GaussianRasterizationSettings:
+    return GaussianRasterizationSettings(
+        image_height=int(vp.image_height), image_width=int(vp.image_width), tanfovx=math.tan(vp.FoVx * 0.5),
+        tanfovy=math.tan(vp.FoVy * 0.5), bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=vp.world_view_transform, projmatrix=vp.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=vp.camera_center, prefiltered=False, debug=False)
+
+
+def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, streams: int = 1, per_view=None,
+                  share_activations: bool = True, batched: bool = True):
     """The render loop of one optimisation window (`for cam_idx in ...: render_pkg = render(viewpoint, ...)`,
     train_gaussians.py:195-219) with view k enqueued on HIP stream k % `streams`.
 
@@ -221,12 +230,37 @@ def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier
     `share_activations`: at SH degree 0 the activated scales / rotations / opacities and the `[rgb | kp_score]` table are
     the same for every view, so they are produced by ONE `activate_pack` per window (and differentiated once: autograd sums
     the views' gradients at its outputs) instead of one per view.
-    Returns (pkgs, per_view results).  streams <= 1 is the reference's serial loop."""
+    `batched` (default): when the rasterizer arguments are the same for every view (SH degree 0 — SplatLoc's
+    configuration — so `shared_activations` applies) and the views share one image size, the whole window goes through
+    `rasterize_window`: ONE launch sequence for the V views (one preprocess, one depth sort, one tile sort keyed by
+    (view, tile), one compositing grid) and ONE backward that sums the views' parameter gradients in-kernel.  Per-view
+    results are bit-identical to the loop; `streams` is ignored on this path (there is nothing left to overlap).
+    Returns (pkgs, per_view results).  batched=False, streams <= 1 is the reference's serial loop."""
     viewpoints = list(viewpoints)
     pkgs, extra = [], []
     dev = pc._xyz.device
     # view-independent activations once per window (on the caller's stream, before the fork)
     shared = shared_activations(pc, pipe) if (share_activations and len(viewpoints) > 1 and pc._xyz.shape[0] > 0) else None
+    if batched and shared is not None:
+        settings = [_view_settings(vp, pc, bg_color, scaling_modifier) for vp in viewpoints]
+        if _window_compatible(settings):
+            scales, rotations, opacity, colors = shared
+            xyz = pc._xyz
+            carriers = []
+            for _ in viewpoints:   # render(): screenspace_points, the per-view gradient carrier
+                sp = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+                try:
+                    sp.retain_grad()
+                except Exception:  # noqa: BLE001
+                    pass
+                carriers.append(sp)
+            outs = rasterize_window(settings, xyz, carriers, colors, opacity, scales=scales, rotations=rotations)
+            for k, (vp, (img, depth, alpha, radii)) in enumerate(zip(viewpoints, outs)):
+                pkg = {"render": img[:3, :, :], "kp_prob": img[-1, :, :], "viewspace_points": carriers[k],
+                       "visibility_filter": radii > 0, "radii": radii, "depth": depth, "opacity": alpha}
+                pkgs.append(pkg)
+                extra.append(per_view(k, vp, pkg) if per_view is not None else None)
+            return pkgs, extra
     if streams <= 1 or len(viewpoints) <= 1:
         for k, vp in enumerate(viewpoints):
             pkg = render(vp, pc, pipe, bg_color, scaling_modifier, _shared=shared)

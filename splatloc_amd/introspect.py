@@ -63,3 +63,35 @@ def forward_state(fn_ctx_tensors, P: int, W: int, H: int, R: int) -> dict:
     out.update(binning_views(binning, P, R, W, H))
     out.update(image_views(img, W, H))
     return out
+
+
+def window_state(fn_ctx_tensors, P: int, V: int, W: int, H: int, R_per_view) -> list:
+    """Per-view views into the (geom, binning, img) buffers of a _RasterizeWindow forward, translated to what the
+    per-view call exposes: rows -> Gaussian indices, global tiles -> the view's tiles, ranges relative to the view's
+    own (contiguous) segment of the instance list."""
+    lib = _native.load()
+    geom, binning, img = fn_ctx_tensors
+    Rt = int(sum(R_per_view))
+    GL, BL, IL = _native.GeometryLayout(), _native.BinningLayout(), _native.ImageLayout()
+    _native.check(lib.splatraster_get_window_geometry_layout(P, V, C.byref(GL)), "window_geometry_layout")
+    _native.check(lib.splatraster_get_window_binning_layout(P, V, Rt, W, H, 4, C.byref(BL)), "window_binning_layout")
+    _native.check(lib.splatraster_get_window_image_layout(W, H, V, C.byref(IL)), "window_image_layout")
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    n = P * V
+    rec = _view(geom, GL.rec0, 8 * n, torch.float32).view(V, P, 8)
+    tt = _view(geom, GL.tiles_touched, n, torch.int32).view(V, P)
+    pl = _view(binning, BL.point_list, Rt, torch.int32)
+    tl = _view(binning, BL.tile_list, Rt, torch.int32)
+    rng = _view(binning, BL.ranges, 2 * V * tiles, torch.int32).view(V, tiles, 2)
+    fT = _view(img, IL.final_T, V * W * H, torch.float32).view(V, H, W)
+    nc = _view(img, IL.n_contrib, V * W * H, torch.int32).view(V, H, W)
+    out, start = [], 0
+    for v in range(V):
+        Rv = int(R_per_view[v])
+        r = rng[v].clone()
+        nz = r[:, 1] > r[:, 0]
+        r[nz] -= start
+        out.append(dict(rec0=rec[v, :, :4], rec1=rec[v, :, 4:], tiles_touched=tt[v], point_list=pl[start:start + Rv] - v * P,
+                        tile_list=tl[start:start + Rv] - v * tiles, ranges=r, final_T=fT[v], n_contrib=nc[v]))
+        start += Rv
+    return out

@@ -237,6 +237,176 @@ class _RasterizeGaussians(torch.autograd.Function):
         return d_m3, d_m2, d_sh, d_col, d_op, d_sca, d_rot, d_cov, None, d_view, d_proj, d_cam
 
 
+def _window_compatible(settings) -> bool:
+    """One launch sequence needs one image size, channel layout, scale modifier and background for all views."""
+    a = settings[0]
+    for b in settings[1:]:
+        if (int(b.image_height), int(b.image_width)) != (int(a.image_height), int(a.image_width)):
+            return False
+        if float(b.scale_modifier) != float(a.scale_modifier):
+            return False
+        if b.bg is not a.bg and b.bg.data_ptr() != a.bg.data_ptr() and not torch.equal(b.bg, a.bg):   # (the last test reads the device: only for distinct tensors)
+            return False
+    return True
+
+
+class _RasterizeWindow(torch.autograd.Function):
+    """The V views of one optimisation window (train_gaussians.py:195-229) as ONE launch sequence:
+    splatraster_forward_window_* / splatraster_backward_window (include/splatraster.h).  Inputs: the shared
+    rasterizer arguments, the list of per-view settings, then one `means2D` gradient carrier per view.  Outputs:
+    (color_0, depth_0, alpha_0, radii_0, color_1, ...).  The backward runs once, when autograd has the output
+    gradients of every view, and returns parameter gradients already summed over the views."""
+
+    @staticmethod
+    def forward(ctx, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, *means2D):
+        lib = _native.load()
+        _require_gpu(means3D, "means3D")
+        dev = means3D.device
+        V = len(settings)
+        assert 1 <= V <= _native.MAX_WINDOW_VIEWS and len(means2D) == V
+        rs0 = settings[0]
+        P = int(means3D.shape[0])
+        H, W = int(rs0.image_height), int(rs0.image_width)
+        m3, col, opa = _prep(means3D, dev), _prep(colors_precomp, dev), _prep(opacities, dev)
+        sca, rot, cov = _prep(scales, dev), _prep(rotations, dev), _prep(cov3Ds_precomp, dev)
+        bg = _prep(rs0.bg, dev)
+        Cn = int(colors_precomp.shape[1])
+        st = _native.Settings(H, W, float(rs0.tanfovx), float(rs0.tanfovy), float(rs0.scale_modifier), 0, 0, Cn,
+                              0 if bg is None else int(bg.numel()), 0, 0)
+        f32 = dict(dtype=torch.float32, device=dev)
+        cams = [(_prep(rs.viewmatrix, dev), _prep(rs.projmatrix, dev), _prep(rs.campos, dev)) for rs in settings]
+        # one allocation per kind; the per-view outputs are its slices (plain tensors for autograd: they do not
+        # alias any input)
+        color = torch.empty((V, Cn, H, W), **f32)
+        depth = torch.empty((V, 1, H, W), **f32)
+        alpha = torch.empty((V, 1, H, W), **f32)
+        radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+        views = (_native.WindowView * V)()
+        for v, rs in enumerate(settings):
+            w = views[v]
+            w.viewmatrix, w.projmatrix = cams[v][0].data_ptr(), cams[v][1].data_ptr()
+            w.campos = None if cams[v][2] is None else cams[v][2].data_ptr()
+            w.tanfovx, w.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+            w.radii = radii[v].data_ptr() if P else None
+            w.out_color, w.out_depth, w.out_alpha = color[v].data_ptr(), depth[v].data_ptr(), alpha[v].data_ptr()
+        geom = torch.empty((lib.splatraster_window_geometry_bytes(P, V),), dtype=torch.uint8, device=dev)
+        img = torch.empty((lib.splatraster_window_image_bytes(W, H, V),), dtype=torch.uint8, device=dev)
+        stream = _stream(dev)
+        R = (C.c_int64 * V)()
+        with _on_device(dev):
+            _native.check(lib.splatraster_forward_window_geometry(
+                C.byref(st), V, views, P, _ptr(m3), _ptr(opa), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(geom), R, stream),
+                "forward_window_geometry")
+            Rt = sum(int(r) for r in R)
+            binning = torch.empty((lib.splatraster_window_binning_bytes(P, V, Rt, W, H, Cn),), dtype=torch.uint8,
+                                  device=dev)
+            _native.check(lib.splatraster_forward_window_render(
+                C.byref(st), V, views, P, R, _ptr(bg), _ptr(col), _ptr(geom), _ptr(binning), _ptr(img), stream),
+                "forward_window_render")
+        ctx.st, ctx.V, ctx.R = st, V, [int(r) for r in R]
+        ctx.tanfov = [(float(rs.tanfovx), float(rs.tanfovy)) for rs in settings]
+        ctx.have = (sca is not None, cov is not None)
+        none = _empty(dev)
+        flat_cams = [t if t is not None else none for cam in cams for t in cam]
+        ctx.save_for_backward(*[t if t is not None else none for t in (m3, col, opa, sca, rot, cov)], radii, geom, binning,
+                              img, color, depth, alpha, *flat_cams)
+        outs, rad = [], []
+        for v in range(V):
+            rv = radii[v]
+            rad.append(rv)
+            outs += [color[v], depth[v], alpha[v], rv]
+        ctx.mark_non_differentiable(*rad)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        lib = _native.load()
+        saved = ctx.saved_tensors
+        m3, col, opa, sca, rot, cov, radii, geom, binning, img, color, depth, alpha = saved[:13]
+        flat_cams = saved[13:]
+        dev = m3.device
+        V, st = ctx.V, ctx.st
+        opt = lambda t: t if t.numel() else None  # noqa: E731
+        sca, rot, cov = map(opt, (sca, rot, cov))
+        P, Cn = int(m3.shape[0]), st.channels
+        f32 = dict(dtype=torch.float32, device=dev)
+        # the summed parameter gradients of the window: 16-byte aligned pieces of ONE allocation, like the per-view
+        # call, so a frame-parallel replica all-reduces them in place as a single RCCL call
+        shapes = {"m3": (P, 3), "op": (P, 1), "col": (P, Cn)}
+        if sca is not None:
+            shapes["sca"], shapes["rot"] = (P, 3), (P, 4)
+        if cov is not None:
+            shapes["cov"] = (P, 6)
+        offs, total = {}, 0
+        for k, shp in shapes.items():
+            offs[k] = total
+            total += (shp[0] * shp[1] + 3) & ~3
+        flat = torch.empty((total,), **f32)
+        piece = lambda k: flat[offs[k]:offs[k] + shapes[k][0] * shapes[k][1]].view(shapes[k]) if k in shapes else None  # noqa: E731
+        d_m3, d_op, d_col, d_sca, d_rot, d_cov = (piece(k) for k in ("m3", "op", "col", "sca", "rot", "cov"))
+        d_m2 = torch.empty((V, P, 3), **f32)
+        views = (_native.WindowView * V)()
+        keep = []
+        zeros_color = None
+        for v in range(V):
+            g_color, g_depth, g_alpha = gouts[4 * v], gouts[4 * v + 1], gouts[4 * v + 2]
+            g_color = _prep(g_color, dev) if g_color is not None else None
+            if g_color is None:     # this view's colour buffer did not reach the loss
+                if zeros_color is None:
+                    zeros_color = torch.zeros((Cn, st.image_height, st.image_width), **f32)
+                g_color = zeros_color
+            g_depth = _prep(g_depth, dev) if g_depth is not None else None
+            g_alpha = _prep(g_alpha, dev) if g_alpha is not None else None
+            keep += [g_color, g_depth, g_alpha]
+            w = views[v]
+            cv, cp, cc = flat_cams[3 * v], flat_cams[3 * v + 1], flat_cams[3 * v + 2]
+            w.viewmatrix, w.projmatrix = cv.data_ptr(), cp.data_ptr()
+            w.campos = cc.data_ptr() if cc.numel() else None
+            w.tanfovx, w.tanfovy = ctx.tanfov[v]
+            w.radii = radii[v].data_ptr() if P else None
+            w.out_color, w.out_depth, w.out_alpha = color[v].data_ptr(), depth[v].data_ptr(), alpha[v].data_ptr()
+            w.dL_dout_color = g_color.data_ptr()
+            w.dL_dout_depth = None if g_depth is None else g_depth.data_ptr()
+            w.dL_dout_alpha = None if g_alpha is None else g_alpha.data_ptr()
+            w.dL_dmeans2D = d_m2[v].data_ptr() if P else None
+        R = (C.c_int64 * V)(*ctx.R)
+        with _on_device(dev):
+            _native.check(lib.splatraster_backward_window(
+                C.byref(st), V, views, P, R, _ptr(m3), _ptr(col), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(geom),
+                _ptr(binning), _ptr(img), _ptr(d_m3), _ptr(d_col), _ptr(d_op), _ptr(d_sca), _ptr(d_rot), _ptr(d_cov),
+                _stream(dev)), "backward_window")
+        del keep
+        # (means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, *means2D)
+        return (d_m3, d_col, d_op, d_sca, d_rot, d_cov, None) + tuple(d_m2[v] for v in range(V))
+
+
+def rasterize_window(settings, means3D, means2D, colors_precomp, opacities, scales=None, rotations=None,
+                     cov3D_precomp=None):
+    """`[GaussianRasterizer(s)(means3D, m2, opacities, colors_precomp=..., ...) for s, m2 in zip(settings, means2D)]`
+    as one launch sequence per chunk of <= 8 views.  `settings`: GaussianRasterizationSettings per view (same
+    image size / scale modifier / background); `means2D`: one gradient carrier per view.  Returns a list of
+    (color, depth, alpha, radii) per view — bit-identical to the per-view calls; the backward sums the views'
+    parameter gradients in-kernel (one gradient set per window instead of V sets + V accumulation passes)."""
+    settings, means2D = list(settings), list(means2D)
+    if colors_precomp is None:
+        raise Exception("rasterize_window needs precomputed colors (view-dependent SH colours: per-view calls)")
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+            (scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    if len(settings) != len(means2D) or not settings:
+        raise Exception("rasterize_window: one means2D tensor per view")
+    if not _window_compatible(settings):
+        raise Exception("rasterize_window: the views of a window share image size, scale modifier and background")
+    out = []
+    K = _native.MAX_WINDOW_VIEWS
+    for a in range(0, len(settings), K):
+        flat = _RasterizeWindow.apply(means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                      tuple(settings[a:a + K]), *means2D[a:a + K])
+        out += [tuple(flat[4 * v:4 * v + 4]) for v in range(len(flat) // 4)]
+    return out
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()

@@ -249,7 +249,7 @@ def test_render_window_streams_match_serial_loop(golden_dir):
     cfg = {"Training": {"primitive_reg": True, "rgb_boundary_threshold": 0.01}}
     bg = torch.zeros(3, device=dev)
     results = {}
-    for streams in (0, 1, 2, 3):          # 0: the serial loop with one activate_pack per view (the baseline)
+    for streams in (0, 1, 2, 3, "batched"):   # 0: the serial loop with one activate_pack per view (the baseline); "batched": one launch sequence per window
         pc = types.SimpleNamespace(active_sh_degree=0, max_sh_degree=0)
         for k, a in names.items():
             setattr(pc, a, torch.from_numpy(d["raw_" + k]).to(dev).requires_grad_(True))
@@ -266,14 +266,16 @@ def test_render_window_streams_match_serial_loop(golden_dir):
         for rep in range(3):      # several windows back to back: stream reuse across windows
             for a in names.values():
                 getattr(pc, a).grad = None
-            pkgs, losses = render_window(cams, pc, pipe, bg, streams=max(streams, 1), share_activations=streams > 0,
+            batched = streams == "batched"
+            pkgs, losses = render_window(cams, pc, pipe, bg, streams=1 if batched else max(streams, 1),
+                                         share_activations=batched or streams > 0, batched=batched,
                                          per_view=lambda k, vp, pkg: mapping_loss(cfg, pkg["render"], pkg["depth"], pkg["kp_prob"], vp))
             sum(losses).backward()
         torch.cuda.synchronize()
         results[streams] = (torch.stack([p["render"] for p in pkgs]).cpu(), [p["radii"].cpu() for p in pkgs],
                             {a: getattr(pc, a).grad.cpu().numpy() for a in names.values() if getattr(pc, a).grad is not None
                              and getattr(pc, a).grad.numel()})
-    for streams in (1, 2, 3):
+    for streams in (1, 2, 3, "batched"):
         assert torch.equal(results[streams][0], results[0][0])               # forward: bit-identical
         assert all(torch.equal(a, b) for a, b in zip(results[streams][1], results[0][1]))
         assert set(results[streams][2]) == set(results[0][2])
