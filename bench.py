@@ -341,7 +341,7 @@ def bench_map_step(args, dev):
     import types
     from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer
     from splatloc_amd.camera import PinholeCamera
-    from splatloc_amd.densify import add_densification_stats, densify_and_prune
+    from splatloc_amd.densify import add_densification_stats_window, densify_and_prune
     from splatloc_amd.fused import render as fused_render, render_window
     from splatloc_amd.losses import isotropic_loss, mapping_loss
     from splatloc_amd.optim import Adam as FusedAdam
@@ -441,11 +441,10 @@ def bench_map_step(args, dev):
             else:
                 key_mask = pc._marker.detach().cpu().squeeze() > 0.005
                 pc._xyz.grad[key_mask] = 0
-            for pkg in pkgs:
-                if fused:
-                    add_densification_stats(pkg["viewspace_points"].grad, pkg["radii"], pc.xyz_gradient_accum, pc.denom,
-                                            pc.max_radii2D)
-                    continue
+            if fused:   # the 5 views in one launch
+                add_densification_stats_window([pkg["viewspace_points"].grad for pkg in pkgs], [pkg["radii"] for pkg in pkgs],
+                                               pc.xyz_gradient_accum, pc.denom, pc.max_radii2D)
+            for pkg in ([] if fused else pkgs):
                 vis = pkg["visibility_filter"]
                 pc.max_radii2D[vis] = torch.max(pc.max_radii2D[vis], pkg["radii"][vis].float())
                 pc.xyz_gradient_accum[vis] += torch.norm(pkg["viewspace_points"].grad[vis, :2], dim=-1, keepdim=True)
@@ -495,6 +494,113 @@ def bench_map_step(args, dev):
     }), flush=True)
 
 
+def bench_refine_step(args, dev):
+    """--stage refine_step: iterations of SplatLoc.color_refinement (train_gaussians.py:269-297; 26 000 of the ~35 000
+    rasterizer calls of a scene): ONE view per iteration — render, 0.8 L1 + 0.2 (1 - SSIM) on RGB, backward, key-primitive
+    gate, max_radii2D update, Adam over the 8 groups, lr schedule — with splatloc_amd.training.color_refinement_step
+    (window-of-one launch sequence, RGB-only backward, fused loss / Adam) and, for comparison, with the reference's chain
+    of torch ops around the same per-view rasterizer call.  Default workload: the reference's own layout (S2-ref-layout:
+    500k Gaussians, 640x480, C = 4).  Secondary figure, not the BASELINE metric."""
+    import types
+    from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from splatloc_amd.camera import PinholeCamera
+    from splatloc_amd.optim import Adam as FusedAdam
+    from splatloc_amd.synthetic import WORKLOADS, make_workload
+    from splatloc_amd.training import color_refinement_step
+    wl = WORKLOADS[args.workload]
+    sc = make_workload(args.workload)
+    P0, W, H, C = wl["P"], wl["W"], wl["H"], wl["C"]
+    E = max(C - 3, 1)
+    inv_sig = lambda p: torch.log(p / (1 - p))  # noqa: E731
+    NAMES = ("xyz", "f_dc", "f_rest", "opacity", "marker", "kp_score", "scaling", "rotation")
+    ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+            "marker": "_marker", "kp_score": "_kp_score", "scaling": "_scaling", "rotation": "_rotation"}
+    LR = {"xyz": 1.6e-4 * 6.0, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 5e-2, "marker": 5e-2, "kp_score": 5e-2,
+          "scaling": 1e-3 * 6.0, "rotation": 1e-3}
+
+    def make_model(adam_cls, **adam_kw):
+        g = torch.Generator().manual_seed(11)
+        par = lambda t: torch.nn.Parameter(t.to(dev).contiguous().requires_grad_(True))  # noqa: E731
+        pc = types.SimpleNamespace(
+            _xyz=par(sc.means3D.clone()),
+            _features_dc=par(((sc.features[:, :3] - 0.5) / 0.28209479177387814)[:, None, :].contiguous()),
+            _features_rest=par(torch.zeros(P0, 0, 3)), _opacity=par(inv_sig(sc.opacities.clamp(1e-4, 1 - 1e-4))),
+            _marker=par((torch.rand(P0, 1, generator=g) < 0.05).float() * torch.rand(P0, 1, generator=g) * 0.9),
+            _kp_score=par(torch.rand(P0, E, generator=g)), _scaling=par(torch.log(sc.scales)),
+            _rotation=par(sc.rotations.clone()), active_sh_degree=0, max_sh_degree=0,
+            lr_init=1.6e-4 * 6.0, lr_final=1.6e-6 * 6.0, lr_delay_mult=0.01, max_steps=30000)
+        pc.optimizer = adam_cls([{"params": [getattr(pc, ATTR[k])], "lr": LR[k], "name": k} for k in NAMES], lr=0.0,
+                                eps=1e-15, **adam_kw)
+        pc.max_radii2D = torch.zeros(P0, device=dev)
+        return pc
+
+    g = torch.Generator().manual_seed(12)
+    views = []
+    for k in range(8):
+        ang = torch.tensor(0.02 * (k - 4))
+        R = torch.tensor([[torch.cos(ang), 0, torch.sin(ang)], [0, 1, 0], [-torch.sin(ang), 0, torch.cos(ang)]])
+        cam = PinholeCamera(W, H, W / 2.0, W / 2.0, (W - 1) / 2.0, (H - 1) / 2.0, R, torch.tensor([0.01 * k, 0.0, 0.0])).to(dev)
+        cam.original_image = torch.rand(3, H, W, generator=g).to(dev)
+        views.append(cam)
+    bg = torch.zeros(3, device=dev)
+    pipe = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
+    win = torch.tensor([math.exp(-((x - 5) ** 2) / 4.5) for x in range(11)])
+    win = (win / win.sum()).to(dev)
+    win2d = (win[:, None] @ win[None, :]).expand(3, 1, 11, 11).contiguous()
+
+    def ssim_torch(a_, b_):   # loss_utils.py:72-102
+        conv = lambda t: torch.nn.functional.conv2d(t, win2d, padding=5, groups=3)  # noqa: E731
+        mu1, mu2 = conv(a_), conv(b_)
+        s1, s2, s12 = conv(a_ * a_) - mu1 * mu1, conv(b_ * b_) - mu2 * mu2, conv(a_ * b_) - mu1 * mu2
+        return (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+
+    def composed_step(pc, cam, it):   # train_gaussians.py:275-297 with the reference's torch ops around the per-view rasterizer
+        rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
+                                           cam.world_view_transform, cam.full_proj_transform, 0, cam.camera_center,
+                                           False, False)
+        m2 = torch.zeros_like(pc._xyz, requires_grad=True) + 0
+        feats = torch.cat((pc._features_dc, pc._features_rest), dim=1)
+        rgb = torch.clamp_min(0.28209479177387814 * feats.transpose(1, 2).view(-1, 3, 1)[..., 0] + 0.5, 0.0)
+        img, depth, alpha, radii = GaussianRasterizer(raster_settings=rs)(
+            means3D=pc._xyz, means2D=m2, shs=None, colors_precomp=torch.cat((rgb, pc._kp_score), dim=1),
+            opacities=torch.sigmoid(pc._opacity), scales=torch.exp(pc._scaling),
+            rotations=torch.nn.functional.normalize(pc._rotation), cov3D_precomp=None)
+        image, vis = img[:3], radii > 0
+        gt = cam.original_image
+        loss = 0.8 * torch.abs(image - gt).mean() + 0.2 * (1.0 - ssim_torch(image[None], gt[None]))
+        loss.backward()
+        key_mask = pc._marker.detach().squeeze() > 0.005
+        pc._xyz.grad[key_mask] = 0
+        with torch.no_grad():
+            pc.max_radii2D[vis] = torch.max(pc.max_radii2D[vis], radii[vis].float())
+            pc.optimizer.step()
+            pc.optimizer.zero_grad(set_to_none=True)
+
+    def time_it(fused):
+        pc = make_model(FusedAdam) if fused else make_model(torch.optim.Adam, fused=True)
+        for it in range(args.warmup):
+            (color_refinement_step(views[it % 8], pc, pipe, bg, 0.2, it + 1) if fused else composed_step(pc, views[it % 8], it + 1))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for it in range(args.steps):
+            (color_refinement_step(views[it % 8], pc, pipe, bg, 0.2, it + 1) if fused else composed_step(pc, views[it % 8], it + 1))
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / args.steps * 1e3
+
+    ms_f = time_it(True)
+    ms_c = time_it(False)
+    print(json.dumps({
+        "metric": "SplatLoc.color_refinement iterations/s (1 view/iteration; secondary figure, NOT the BASELINE metric)",
+        "value": round(1e3 / ms_f, 2), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_f, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: P={P0}, {W}x{H}, C={3 + E} ([rgb | kp_score]); per iteration: render, "
+                               "0.8 L1 + 0.2 (1 - SSIM) on RGB, backward (3 colour channels, no depth / alpha terms), key gate, "
+                               "max_radii2D, fused Adam over 8 groups, lr schedule; 8 different cameras in rotation"},
+        "scene_of_26000_iterations_s": round(26000 * ms_f / 1e3, 1),
+        "torch_front_end_loss_adam_same_rasterizer": {"ms_per_step": round(ms_c, 4), "speedup": round(ms_c / ms_f, 3)},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -515,7 +621,7 @@ def main():
     ap.add_argument("--no-multi-stream", action="store_true", help="skip the secondary legs (per-view loop, multi-stream) (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
-    ap.add_argument("--stage", default="raster", choices=["raster", "activations", "loss", "map_step"],
+    ap.add_argument("--stage", default="raster", choices=["raster", "activations", "loss", "map_step", "refine_step"],
                     help="raster = the BASELINE metric (default); activations = the fused front-end stage alone")
     args = ap.parse_args()
 
@@ -538,9 +644,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.stage in ("activations", "loss", "map_step"):
+    if args.stage in ("activations", "loss", "map_step", "refine_step"):
         if rank == 0:
-            {"activations": bench_activations, "loss": bench_loss, "map_step": bench_map_step}[args.stage](args, dev)
+            {"activations": bench_activations, "loss": bench_loss, "map_step": bench_map_step,
+             "refine_step": bench_refine_step}[args.stage](args, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -548,7 +655,7 @@ def main():
 
     from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer, _native, rasterize_window
     from splatloc_amd.camera import PinholeCamera
-    from splatloc_amd.densify import add_densification_stats
+    from splatloc_amd.densify import add_densification_stats, add_densification_stats_window
     from splatloc_amd.frame_parallel import allreduce_grads, shard_views, sync_densification_stats
     from splatloc_amd.synthetic import WORKLOADS, make_workload
 
@@ -599,8 +706,7 @@ def main():
             info["V"] += [int((o[3] > 0).sum().item()) for o in outs]
         if not args.fwd_only:
             torch.autograd.backward([t for o in outs for t in o[:3]], [g for _, gs, _ in views for g in gs])
-            for m2, o in zip(carriers, outs):
-                add_densification_stats(m2.grad, o[3], accum, denom, max_radii)
+            add_densification_stats_window([m2.grad for m2 in carriers], [o[3] for o in outs], accum, denom, max_radii)
 
     def one_view(rast, g_out, record):
         means2D = torch.zeros_like(means3D, requires_grad=True)   # per-view grad carrier (render(): screenspace_points)

@@ -188,10 +188,19 @@ typedef struct splatraster_window_view {
     float* out_depth;        /* [1,H,W] */
     float* out_alpha;        /* [1,H,W] */
     /* backward only (ignored by the forward calls) */
-    const float* dL_dout_color; /* [C,H,W] */
+    const float* dL_dout_color; /* [C,H,W]; or [C-1,H,W] when color_grad_channels == C - 1 */
     const float* dL_dout_depth; /* [1,H,W] or NULL (= zeros) */
     const float* dL_dout_alpha; /* [1,H,W] or NULL (= zeros) */
     float* dL_dmeans2D;         /* [P,3] output: per view, as GaussianModel.add_densification_stats reads it */
+    /* SplatLoc's render() hands the colour buffer out as TWO tensors, render = image[:3] and kp_prob = image[-1]
+     * (gaussian_renderer/__init__.py:133-135), and the losses produce their gradients separately — through autograd
+     * each arrives zero-padded to [C,H,W] and the two are added (five elementwise kernels per view).  A caller that
+     * has the two gradients apart passes them apart: color_grad_channels = C - 1 planes behind dL_dout_color and the
+     * last channel's plane behind dL_dout_last, or NULL when that channel did not reach the loss (color_refinement:
+     * RGB only, train_gaussians.py:283-285) — the backward then skips the channel altogether.  0 = all C planes are
+     * behind dL_dout_color (the plain call). */
+    const float* dL_dout_last;  /* [1,H,W] or NULL */
+    int32_t color_grad_channels; /* 0 (= C) or C - 1 */
 } splatraster_window_view;
 
 size_t splatraster_window_geometry_bytes(int32_t P, int32_t n_views);
@@ -314,6 +323,12 @@ int splatraster_activate_backward(int32_t P, int32_t sh_coeffs, int32_t active_s
 int splatraster_densification_stats(int32_t P, const float* viewspace_grad /* [P,3] */, const int32_t* radii,
                                     float* xyz_gradient_accum /* [P,1] */, float* denom /* [P,1] */,
                                     float* max_radii2D /* [P] */, void* stream);
+/* The same for the n_views <= SPLATRASTER_MAX_WINDOW_VIEWS views of a window in ONE launch, in view order (host arrays
+ * of device pointers).  xyz_gradient_accum == denom == NULL: only max_radii2D is updated — the statistics line of
+ * SplatLoc.color_refinement (train_gaussians.py:293-294); viewspace_grads may then be NULL. */
+int splatraster_densification_stats_window(int32_t P, int32_t n_views, const float* const* viewspace_grads,
+                                           const int32_t* const* radii, float* xyz_gradient_accum, float* denom,
+                                           float* max_radii2D, void* stream);
 
 /* ---- densify / clone / split / prune + Adam over the parameter groups -------- */
 
@@ -364,6 +379,17 @@ int splatraster_densify_apply(const splatraster_model* model, const splatraster_
                               splatraster_model* out_exp_avg_sq, int32_t* source_row /* [new_P] or NULL */,
                               int32_t* source_kind /* [new_P] or NULL: 0 original, 1 clone, 2 / 3 split child */,
                               void* stream);
+
+/* Key-frame insertion, GaussianModel.extend_from_pcd -> densification_postfix -> cat_tensors_to_optimizer
+ * (gaussian_model.py:222-241, :528-587; once per key-frame, train_gaussians.py:173-177): the `extra->P` new rows are
+ * appended to the 8 parameter tensors and ZERO rows to the Adam moments of every group that has state — ONE launch
+ * instead of 24 torch.cat + 16 zeros_like.  out_* hold model->P + extra->P rows; exp_avg / exp_avg_sq (and their
+ * outputs) may be NULL, or carry NULL members for groups without state.  The caller resets the densification
+ * statistics, as densification_postfix does (:585-587). */
+int splatraster_model_append(const splatraster_model* model, const splatraster_model* exp_avg /* or NULL */,
+                             const splatraster_model* exp_avg_sq /* or NULL */, const splatraster_model* extra,
+                             splatraster_model* out_model, splatraster_model* out_exp_avg,
+                             splatraster_model* out_exp_avg_sq, void* stream);
 
 /* One torch.optim.Adam step (no weight decay, no amsgrad: gaussian_model.py:287) over up to 16 parameter
  * groups in ONE launch.  `step` is the group's step count AFTER this step (>= 1): the bias corrections

@@ -45,7 +45,7 @@ class WindowView(C.Structure):
                 ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("radii", C.c_void_p), ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p),
                 ("dL_dout_color", C.c_void_p), ("dL_dout_depth", C.c_void_p), ("dL_dout_alpha", C.c_void_p),
-                ("dL_dmeans2D", C.c_void_p)]
+                ("dL_dmeans2D", C.c_void_p), ("dL_dout_last", C.c_void_p), ("color_grad_channels", C.c_int32)]
 
 
 class GeometryLayout(C.Structure):
@@ -112,12 +112,14 @@ SYMBOLS = {
     "splatraster_activate_forward": (C.c_int, [_i32] * 5 + [_vp] * 13),
     "splatraster_activate_backward": (C.c_int, [_i32] * 5 + [_vp] * 19),
     "splatraster_densification_stats": (C.c_int, [_i32] + [_vp] * 6),
+    "splatraster_densification_stats_window": (C.c_int, [_i32, _i32] + [_vp] * 6),
     "splatraster_densify_workspace_bytes": (_sz, [_i32]),
     "splatraster_densify_plan": (C.c_int, [C.POINTER(Model), _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i32,
                                            _i32, _vp, C.POINTER(_i32), _vp]),
     "splatraster_densify_apply": (C.c_int, [C.POINTER(Model), C.POINTER(Model), C.POINTER(Model), _vp, C.c_uint64,
                                             C.c_uint64, _vp, _i32, C.POINTER(Model), C.POINTER(Model), C.POINTER(Model),
                                             _vp, _vp, _vp]),
+    "splatraster_model_append": (C.c_int, [C.POINTER(Model)] * 7 + [_vp]),
     "splatraster_adam_step": (C.c_int, [_i32, C.POINTER(AdamGroup), C.c_double, C.c_double, C.c_double, C.c_float, _vp]),
     "splatraster_isotropic_loss_workspace_bytes": (_sz, [_i32]),
     "splatraster_isotropic_loss": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -273,24 +273,38 @@ activate_bwd_kernel(int P, int K, int deg, int SC, int E, const float* __restric
 //   max_radii2D[vis] = max(max_radii2D[vis], radii[vis])                 train_gaussians.py:240-244
 //   xyz_gradient_accum[vis] += ||viewspace_grad[vis, :2]||;  denom[vis] += 1   gaussian_model.py:677-679
 __global__ void __launch_bounds__(256)
-densification_stats_kernel(int P, const float* __restrict__ vs_grad /*[P,3]*/, const int32_t* __restrict__ radii,
-                           float* __restrict__ accum, float* __restrict__ denom, float* __restrict__ max_radii)
+densification_stats_kernel(int P, int V, StatsViews views, float* __restrict__ accum, float* __restrict__ denom,
+                           float* __restrict__ max_radii)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const int r = radii[i];
-    if (r <= 0) return;
-    const float gx = vs_grad[3 * (size_t)i], gy = vs_grad[3 * (size_t)i + 1];
-    accum[i] += sqrtf(gx * gx + gy * gy);
-    denom[i] += 1.0f;
-    max_radii[i] = fmaxf(max_radii[i], (float)r);
+    // the views of a window in view order (the reference's loop order, train_gaussians.py:238-245): one
+    // read-modify-write of the three statistics per Gaussian instead of one per (view, Gaussian)
+    float a = 0.0f, n = 0.0f, m = 0.0f;
+    bool any = false;
+#pragma unroll 1
+    for (int v = 0; v < V; ++v) {
+        const int r = views.radii[v][i];
+        if (r <= 0) continue;
+        if (!any) { any = true; m = max_radii[i]; if (accum) { a = accum[i]; n = denom[i]; } }
+        if (accum) {    // color_refinement updates max_radii2D only (train_gaussians.py:293-294)
+            const float gx = views.vs_grad[v][3 * (size_t)i], gy = views.vs_grad[v][3 * (size_t)i + 1];
+            a += sqrtf(gx * gx + gy * gy);
+            n += 1.0f;
+        }
+        m = fmaxf(m, (float)r);
+    }
+    if (any) {
+        max_radii[i] = m;
+        if (accum) { accum[i] = a; denom[i] = n; }
+    }
 }
 
-int launch_densification_stats(int32_t P, const float* vs_grad, const int32_t* radii, float* accum, float* denom,
+int launch_densification_stats(int32_t P, int32_t V, const StatsViews& views, float* accum, float* denom,
                                float* max_radii, hipStream_t stream)
 {
-    if (P == 0) return SPLATRASTER_OK;
-    hipLaunchKernelGGL(densification_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, vs_grad, radii,
+    if (P == 0 || V == 0) return SPLATRASTER_OK;
+    hipLaunchKernelGGL(densification_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, V, views,
                        accum, denom, max_radii);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;

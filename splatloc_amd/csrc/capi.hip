@@ -518,6 +518,17 @@ static int window_backward(const splatraster_settings* s, int32_t V, const splat
     const float* feat = shs ? g.rgb : colors_precomp;
     const WinCams cams = make_cams(V, views);
     WinGrad grads{};
+    grads.gc = C;
+    for (int v = 0; v < V; ++v) {
+        const int gcv = views[v].color_grad_channels;
+        if (gcv != 0 && gcv != C && gcv != C - 1) return SPLATRASTER_ERR_BAD_ARG;
+        if (gcv == C - 1 && C >= 2) grads.gc = C - 1;
+    }
+    for (int v = 0; v < V; ++v) {   // one convention per launch: all views split the last channel off, or none does
+        const int gcv = views[v].color_grad_channels ? views[v].color_grad_channels : C;
+        if (gcv != grads.gc) return SPLATRASTER_ERR_BAD_ARG;
+        grads.dL_dlast[v] = grads.gc < C ? views[v].dL_dout_last : nullptr;
+    }
     for (int v = 0; v < V; ++v) {
         grads.out_color[v] = views[v].out_color;
         grads.out_depth[v] = views[v].out_depth;
@@ -806,10 +817,26 @@ int splatraster_activate_backward(int32_t P, int32_t sh_coeffs, int32_t active_s
 int splatraster_densification_stats(int32_t P, const float* viewspace_grad, const int32_t* radii,
                                     float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream)
 {
-    if (P < 0) return SPLATRASTER_ERR_BAD_ARG;
-    if (P == 0) return SPLATRASTER_OK;
-    if (!viewspace_grad || !radii || !xyz_gradient_accum || !denom || !max_radii2D) return SPLATRASTER_ERR_BAD_ARG;
-    return launch_densification_stats(P, viewspace_grad, radii, xyz_gradient_accum, denom, max_radii2D,
+    const float* g[1] = {viewspace_grad};
+    const int32_t* r[1] = {radii};
+    return splatraster_densification_stats_window(P, 1, g, r, xyz_gradient_accum, denom, max_radii2D, stream);
+}
+
+int splatraster_densification_stats_window(int32_t P, int32_t n_views, const float* const* viewspace_grads,
+                                           const int32_t* const* radii, float* xyz_gradient_accum, float* denom,
+                                           float* max_radii2D, void* stream)
+{
+    if (P < 0 || n_views < 0 || n_views > MAX_VIEWS) return SPLATRASTER_ERR_BAD_ARG;
+    if (P == 0 || n_views == 0) return SPLATRASTER_OK;
+    if (!radii || !max_radii2D || (xyz_gradient_accum == nullptr) != (denom == nullptr)) return SPLATRASTER_ERR_BAD_ARG;
+    if (xyz_gradient_accum && !viewspace_grads) return SPLATRASTER_ERR_BAD_ARG;
+    StatsViews sv{};
+    for (int v = 0; v < n_views; ++v) {
+        if (!radii[v] || (xyz_gradient_accum && !viewspace_grads[v])) return SPLATRASTER_ERR_BAD_ARG;
+        sv.radii[v] = radii[v];
+        sv.vs_grad[v] = viewspace_grads ? viewspace_grads[v] : nullptr;
+    }
+    return launch_densification_stats(P, n_views, sv, xyz_gradient_accum, denom, max_radii2D,
                                       reinterpret_cast<hipStream_t>(stream));
 }
 

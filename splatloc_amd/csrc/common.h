@@ -78,7 +78,9 @@ struct WinGrad {                     // backward inputs per view
     const float* dL_dcolor[MAX_VIEWS];
     const float* dL_ddepth[MAX_VIEWS];   // null = zeros
     const float* dL_dalpha[MAX_VIEWS];   // null = zeros
+    const float* dL_dlast[MAX_VIEWS];    // gradient plane of channel C - 1 when it travels apart (null = zeros); see gc
     float* dL_dmeans2D[MAX_VIEWS];       // [P,3] output
+    int gc;                              // channel planes behind dL_dcolor: C, or C - 1 (then channel C - 1 reads dL_dlast)
 };
 
 // ---- opaque buffer views (n = V * P rows) -------------------------------------------------
@@ -189,8 +191,12 @@ int launch_activate_bwd(int32_t P, int32_t K, int32_t deg, int32_t SC, int32_t E
                         float* d_f_dc, float* d_f_rest, float* d_scaling, float* d_rotation, float* d_opacity,
                         float* d_extra, hipStream_t stream);
 
-int launch_densification_stats(int32_t P, const float* vs_grad, const int32_t* radii, float* accum, float* denom,
-                               float* max_radii, hipStream_t stream);
+struct StatsViews {
+    const float* vs_grad[MAX_VIEWS];   // [P,3] per view (unused when accum == null)
+    const int32_t* radii[MAX_VIEWS];   // [P] per view
+};
+int launch_densification_stats(int32_t P, int32_t V, const StatsViews& views, float* accum /*or null*/,
+                               float* denom /*or null*/, float* max_radii, hipStream_t stream);
 size_t mapping_loss_workspace_bytes(int32_t HW);
 int launch_mapping_loss(int32_t HW, const float* image, const float* depth, const float* marker,
                         const float* gt_image, const float* gt_depth, const float* kp, float threshold,

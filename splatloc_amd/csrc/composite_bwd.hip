@@ -87,7 +87,7 @@ __device__ unsigned long long g_bwd_prof[12];
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NC, bool SP>
+template <int NC, bool SP, bool AUX = true>
 struct BwdCfg {
     // Small layouts (NC <= 15: SplatLoc's own C = 4, and 1 / 2 / 3 / 8), variant SP: ALL channels and the depth
     // weight w g_D are ONE 16-column block of the flush contraction, so only the six geometric moments go
@@ -102,7 +102,9 @@ struct BwdCfg {
     static constexpr int NB = NC >= 32 ? 2 : 1;                    // 16-column blocks of the contraction
     static constexpr bool XD = SMALLP;                             // column NC of the block = the depth weight
     static constexpr int NV = NC - NM;         // channels reduced with the packed butterfly
-    static constexpr int KV = NV + (XD ? 6 : 7);   // butterfly values per Gaussian
+    // AUX = false: no view of the launch has a depth / alpha gradient (color_refinement, train_gaussians.py:283-285):
+    // the depth weight w g_D is identically zero and leaves the reduction
+    static constexpr int KV = NV + ((XD || !AUX) ? 6 : 7);   // butterfly values per Gaussian
     static constexpr int NCP = (NC + 3) & ~3;
     static constexpr int FS = SR_BWD_FS;             // feature rows staged per round
     static constexpr int GROUP = 16;           // Gaussians per MFMA flush (M of v_mfma_f32_16x16x4_f32)
@@ -124,7 +126,7 @@ __device__ __forceinline__ void acc_add(float* gacc, long long* gacc64, size_t i
         atomicAdd(gacc + idx, v);
 }
 
-template <int NC, bool DET, bool SP>
+template <int NC, bool DET, bool SP, bool AUX>
 __global__ void __launch_bounds__(WAVE, SR_BWD_MINW)
 composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass, int tiles /*per view*/, int V,
                      int P /*rows per view*/,
@@ -136,7 +138,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      float* __restrict__ gacc /*[V * P, GROW]*/, int GROW,
                      int MO, long long* __restrict__ gacc64 /*[V * P, GROW] fixed point, DET only*/)
 {
-    using Cfg = BwdCfg<NC, SP>;
+    using Cfg = BwdCfg<NC, SP, AUX>;
+    static_assert(AUX || !SP, "the no-aux variant exists for the butterfly kernels only");
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
     constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
     constexpr bool MFMA = Cfg::MFMA, XD = Cfg::XD;
@@ -178,6 +181,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     const float* __restrict__ dL_dcolor = grads.dL_dcolor[view];
     const float* __restrict__ dL_ddepth = grads.dL_ddepth[view];
     const float* __restrict__ dL_dalpha = grads.dL_dalpha[view];
+    const float* __restrict__ dL_dlast = grads.dL_dlast[view];
+    const int gc = grads.gc;   // channel planes behind dL_dcolor; channel >= gc (only C - 1) reads dL_dlast
     const float* __restrict__ final_T = final_T_all + (size_t)view * H * W;
     const uint32_t* __restrict__ n_contrib = n_contrib_all + (size_t)view * H * W;
     const int lane = threadIdx.x;
@@ -198,10 +203,11 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         last = n_contrib[pix];
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
-            g[ch] = dL_dcolor[(size_t)(c0 + ch) * plane + pix];
-            S += out_color[(size_t)(c0 + ch) * plane + pix] * g[ch];
+            const int c = c0 + ch;
+            g[ch] = c < gc ? dL_dcolor[(size_t)c * plane + pix] : (dL_dlast ? dL_dlast[pix] : 0.0f);
+            S += out_color[(size_t)c * plane + pix] * g[ch];
         }
-        if (first_pass) {
+        if (AUX && first_pass) {
             gD = dL_ddepth ? dL_ddepth[pix] : 0.0f;
             const float gA = dL_dalpha ? dL_dalpha[pix] : 0.0f;
             S += out_depth[pix] * gD - final_T[pix] * gA;
@@ -397,8 +403,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 if (!DOTM) {
                     const float* f0 = &s_feat[r0 * NCP];
                     const float* f1 = &s_feat[r1 * NCP];
-                    qd0 = p0.z * gD;
-                    qd1 = p1.z * gD;
+                    qd0 = AUX ? p0.z * gD : 0.0f;
+                    qd1 = AUX ? p1.z * gD : 0.0f;
 #pragma unroll
                     for (int ch = 0; ch < NC; ++ch) {
                         qd0 += f0[ch] * g[ch];
@@ -435,7 +441,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     red[NV + 3] = Ex * dy0;
                     red[NV + 4] = Ey * dy0;
                     red[NV + 5] = E;
-                    if (!XD) red[NV + (XD ? 5 : 6)] = w0 * gD;
+                    if (!XD && AUX) red[NV + ((XD || !AUX) ? 5 : 6)] = w0 * gD;
                 }
                 {
                     const float E = G1 * dA1, Ex = E * dx1, Ey = E * dy1;
@@ -445,7 +451,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     red[KV + NV + 3] = Ex * dy1;
                     red[KV + NV + 4] = Ey * dy1;
                     red[KV + NV + 5] = E;
-                    if (!XD) red[KV + NV + (XD ? 5 : 6)] = w1 * gD;
+                    if (!XD && AUX) red[KV + NV + ((XD || !AUX) ? 5 : 6)] = w1 * gD;
                 }
                 BP_T(tp2);
                 BP_ADD(3, tp2 - tp1);
@@ -580,7 +586,7 @@ struct BwdLaunch {
     const WinGrad* grads;
 };
 
-template <int NC, bool DET>
+template <int NC, bool DET, bool AUX = true>
 static int launch_one_bwd(const splatraster_settings& s, int c0, int first, const GeomView& g,
                           const BinView& b, const ImgView& im, const float* feat, int feat_stride,
                           const BwdLaunch& L, float* gacc, long long* gacc64, hipStream_t stream)
@@ -590,12 +596,12 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
     const int tiles = gx * gy;
     const unsigned blocks = quadrant_blocks(L.V * tiles, gx);  // 4 quadrants per (view, tile) (+ padding of the id space)
 #define SR_BWD_LAUNCH(SPV)                                                                                          \
-    hipLaunchKernelGGL((composite_bwd_kernel<NC, DET, SPV>), dim3(blocks), dim3(WAVE), 0, stream, s.image_width,        \
+    hipLaunchKernelGGL((composite_bwd_kernel<NC, DET, SPV, AUX>), dim3(blocks), dim3(WAVE), 0, stream, s.image_width,   \
                        s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, L.V, L.P,      \
                        b.ranges, b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), *L.grads,       \
                        im.final_T, im.n_contrib, gacc, gacc_row_floats(s.channels),                                    \
                        gacc_moment_offset(s.channels), gacc64)
-    if constexpr (NC >= 4 && NC <= 15) {   // C = 3 and below: the flush costs what the 8 saved butterfly values gain (A/B: S0 0.036 vs 0.041 ms)
+    if constexpr (NC >= 4 && NC <= 15 && AUX) {   // C = 3 and below: the flush costs what the 8 saved butterfly values gain (A/B: S0 0.036 vs 0.041 ms)
         if (4 * L.V * tiles <= g_small_panel_max_waves)   // every quadrant-wave of the launch resident at once
             SR_BWD_LAUNCH(true);
         else
@@ -614,8 +620,20 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int32_t V, in
 {
     if (R == 0) return SPLATRASTER_OK;
     const bool det = gacc64 != nullptr;
-    const int C = s.channels;
+    int C = s.channels;
     const BwdLaunch L{P, V, &grads};
+    // Channels and auxiliary planes that did not reach the loss are not computed: when the last channel's gradient
+    // travels apart (grads.gc = C - 1) and NO view has one, the launch covers channels [0, C - 1) only — its dL/dfeature
+    // column stays at the zero the accumulator rows were cleared to; without any depth / alpha gradient the RGB kernel
+    // drops the depth weight from the dot product and the reduction (color_refinement: train_gaussians.py:283-285).
+    bool any_last = false, any_aux = false;
+    for (int v = 0; v < V; ++v) {
+        any_last = any_last || grads.dL_dlast[v] != nullptr;
+        any_aux = any_aux || grads.dL_ddepth[v] != nullptr || grads.dL_dalpha[v] != nullptr;
+    }
+    if (grads.gc < C && !any_last) C = grads.gc;
+    if (C == 3 && !any_aux && !det)
+        return launch_one_bwd<3, false, false>(s, 0, 1, g, b, im, feat, feat_stride, L, gacc, gacc64, stream);
 #define SR_BWD_ARGS g, b, im, feat, feat_stride, L, gacc, gacc64, stream
 #define SR_BWD_ONE(N, c0_, first_) (det ? launch_one_bwd<N, true>(s, c0_, first_, SR_BWD_ARGS) : launch_one_bwd<N, false>(s, c0_, first_, SR_BWD_ARGS))
 #define SR_BWD_CASE(N) \

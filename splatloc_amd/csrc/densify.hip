@@ -222,6 +222,45 @@ int densify_apply(int32_t P, const DensifyGroups& G, const float* unit_noise, ui
     return SPLATRASTER_OK;
 }
 
+// ---- key-frame insertion: rows appended to every group, zero Adam moments for the new rows ---------------------
+// GaussianModel.extend_from_pcd -> densification_postfix -> cat_tensors_to_optimizer (gaussian_model.py:222-241,
+// :528-587): torch.cat per parameter tensor and per Adam moment (24 cat launches + 16 zeros_like) as ONE launch.
+// G.in = the model (P rows), G.m_in / G.v_in its moments, `extra` = the N new rows; outputs hold P + N rows.
+struct AppendRows { const float* extra[8]; };
+__global__ void __launch_bounds__(DN_BLOCK)
+model_append_kernel(int P, int N, DensifyGroups G, AppendRows X)
+{
+    const size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= (size_t)P + (size_t)N) return;
+    const bool old = d < (size_t)P;
+    const size_t r = old ? d : d - (size_t)P;
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+        const int w = G.width[gq];
+        if (w == 0 || !G.out[gq]) continue;
+        const float* src = (old ? G.in[gq] : X.extra[gq]) + (size_t)w * r;
+        float* dst = G.out[gq] + (size_t)w * d;
+        for (int k = 0; k < w; ++k) dst[k] = src[k];
+        if (G.m_out[gq]) {
+            float* md = G.m_out[gq] + (size_t)w * d;
+            float* vd = G.v_out[gq] + (size_t)w * d;
+            for (int k = 0; k < w; ++k) {
+                md[k] = old ? G.m_in[gq][(size_t)w * r + k] : 0.0f;
+                vd[k] = old ? G.v_in[gq][(size_t)w * r + k] : 0.0f;
+            }
+        }
+    }
+}
+
+int model_append(int32_t P, int32_t N, const DensifyGroups& G, const AppendRows& X, hipStream_t stream)
+{
+    const size_t n = (size_t)P + (size_t)N;
+    if (n == 0) return SPLATRASTER_OK;
+    hipLaunchKernelGGL(model_append_kernel, dim3((unsigned)((n + DN_BLOCK - 1) / DN_BLOCK)), dim3(DN_BLOCK), 0, stream, P, N, G, X);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
 // ---- Adam over all groups, one launch --------------------------------------------------------------
 constexpr int ADAM_MAX_GROUPS = 16;
 struct AdamTable {
@@ -432,6 +471,50 @@ int splatraster_densify_apply(const splatraster_model* model, const splatraster_
     }
     return densify_apply(model->P, G, unit_noise, seed, draw_id, workspace, source_row, source_kind,
                          reinterpret_cast<hipStream_t>(stream));
+}
+
+int splatraster_model_append(const splatraster_model* model, const splatraster_model* exp_avg,
+                             const splatraster_model* exp_avg_sq, const splatraster_model* extra,
+                             splatraster_model* out_model, splatraster_model* out_exp_avg,
+                             splatraster_model* out_exp_avg_sq, void* stream)
+{
+    int st = check_model(model, 1);
+    if (st) return st;
+    st = check_model(extra, 1);
+    if (st) return st;
+    if (!out_model || (exp_avg == nullptr) != (exp_avg_sq == nullptr)) return SPLATRASTER_ERR_BAD_ARG;
+    if (exp_avg && (!out_exp_avg || !out_exp_avg_sq)) return SPLATRASTER_ERR_BAD_ARG;
+    if (model->f_rest_width != extra->f_rest_width || model->marker_width != extra->marker_width ||
+        model->kp_width != extra->kp_width || model->scaling_width != extra->scaling_width)
+        return SPLATRASTER_ERR_BAD_ARG;
+    if ((int64_t)model->P + (int64_t)extra->P >= ((int64_t)1 << 31)) return SPLATRASTER_ERR_OVERFLOW;
+    const int widths[8] = {3, 3, model->f_rest_width, 1, model->marker_width, model->kp_width, model->scaling_width, 4};
+    auto ptrs = [](const splatraster_model* m, const float* (&p)[8]) {
+        p[0] = m->xyz; p[1] = m->f_dc; p[2] = m->f_rest; p[3] = m->opacity; p[4] = m->marker; p[5] = m->kp_score;
+        p[6] = m->scaling; p[7] = m->rotation;
+    };
+    DensifyGroups G{};
+    AppendRows X{};
+    const float *in[8], *ex[8], *out[8], *mi[8] = {}, *vi[8] = {}, *mo[8] = {}, *vo[8] = {};
+    ptrs(model, in);
+    ptrs(extra, ex);
+    ptrs(out_model, out);
+    if (exp_avg) { ptrs(exp_avg, mi); ptrs(exp_avg_sq, vi); ptrs(out_exp_avg, mo); ptrs(out_exp_avg_sq, vo); }
+    for (int k = 0; k < 8; ++k) {
+        G.width[k] = widths[k];
+        G.in[k] = in[k];
+        X.extra[k] = ex[k];
+        G.out[k] = const_cast<float*>(out[k]);
+        if (widths[k] > 0 && !out[k]) return SPLATRASTER_ERR_BAD_ARG;
+        // a group carries Adam state only when BOTH moments are given (the marker never has any in map())
+        const bool has = mi[k] && vi[k];
+        if (has && (!mo[k] || !vo[k])) return SPLATRASTER_ERR_BAD_ARG;
+        G.m_in[k] = has ? mi[k] : nullptr;
+        G.v_in[k] = has ? vi[k] : nullptr;
+        G.m_out[k] = has ? const_cast<float*>(mo[k]) : nullptr;
+        G.v_out[k] = has ? const_cast<float*>(vo[k]) : nullptr;
+    }
+    return model_append(model->P, extra->P, G, X, reinterpret_cast<hipStream_t>(stream));
 }
 
 int splatraster_adam_step(int32_t n_groups, const splatraster_adam_group* groups, double beta1, double beta2, double eps,

@@ -34,6 +34,45 @@ def add_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, x
             _stream(dev)), "densification_stats")
 
 
+def add_densification_stats_window(viewspace_grads, radii, xyz_gradient_accum, denom, max_radii2D) -> None:
+    """`add_densification_stats` for the views of a window in ONE launch (view order = the reference's loop order,
+    train_gaussians.py:238-245).  `xyz_gradient_accum = denom = None`: only `max_radii2D` is updated — the statistics
+    line of SplatLoc.color_refinement (train_gaussians.py:293-294); `viewspace_grads` may then be None."""
+    import ctypes as C
+    radii = list(radii)
+    V = len(radii)
+    if V == 0:
+        return
+    dev = radii[0].device
+    _require_gpu(radii[0], "radii")
+    P = int(radii[0].numel())
+    only_max = xyz_gradient_accum is None
+    state = ((max_radii2D, "max_radii2D"),) if only_max else ((xyz_gradient_accum, "xyz_gradient_accum"), (denom, "denom"),
+                                                             (max_radii2D, "max_radii2D"))
+    for t, name in state:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != P or t.device != dev:
+            raise RuntimeError(f"add_densification_stats: `{name}` must be a contiguous float32 tensor of {P} elements on {dev}")
+    lib = _native.load()
+    K = _native.MAX_WINDOW_VIEWS
+    for a in range(0, V, K):
+        rs = [r.contiguous() for r in radii[a:a + K]]
+        gs = None
+        if not only_max:
+            gs = []
+            for g in viewspace_grads[a:a + K]:
+                g = g.detach()
+                if g.dtype != torch.float32 or not g.is_contiguous() or tuple(g.shape) != (P, 3):
+                    g = g.to(torch.float32).reshape(P, 3).contiguous()
+                gs.append(g)
+        n = len(rs)
+        rp = (C.c_void_p * n)(*[r.data_ptr() for r in rs])
+        gp = None if gs is None else (C.c_void_p * n)(*[g.data_ptr() for g in gs])
+        with _on_device(dev):
+            _native.check(lib.splatraster_densification_stats_window(
+                P, n, gp, rp, None if only_max else _ptr(xyz_gradient_accum), None if only_max else _ptr(denom),
+                _ptr(max_radii2D), _stream(dev)), "densification_stats_window")
+
+
 # ---------------------------------------------------------------------------------------------------
 # densify / clone / split / prune with optimizer-state surgery (gaussian_model.py:477-675)
 # ---------------------------------------------------------------------------------------------------
@@ -195,3 +234,71 @@ def reset_opacity_nonvisible(gaussians, visibility_filters) -> None:
             st["exp_avg_sq"] = torch.zeros_like(p)
             opt.state[p] = st
         gaussians._opacity = p
+
+
+def extend_from_pcd(gaussians, fused_point_cloud, features, scales, rots, opacities, markers, kp_scores) -> int:
+    """Drop-in for `GaussianModel.extend_from_pcd(...)` (gaussian_model.py:222-241 -> densification_postfix :565-587 ->
+    cat_tensors_to_optimizer :528-553; the key-frame insertion of train_gaussians.py:173-177) on the reference's own
+    model object: the new rows are appended to the 8 parameter tensors and zero rows to the Adam moments of every group
+    that has state in ONE launch (the reference: a torch.cat per tensor and per moment), new `nn.Parameter`s are bound
+    to the model and to the optimizer's groups with the `step` counters carried over, and the densification
+    statistics are reset, exactly as densification_postfix does.  `features` is [N, 3, (max_sh_degree + 1)^2]."""
+    import ctypes as C
+    from torch import nn
+    lib = _native.load()
+    dev = fused_point_cloud.device
+    _require_gpu(fused_point_cloud, "fused_point_cloud")
+    N = int(fused_point_cloud.shape[0])
+    f32c = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+    extra = {"xyz": f32c(fused_point_cloud), "f_dc": f32c(features[:, :, 0:1].transpose(1, 2)),
+             "f_rest": f32c(features[:, :, 1:].transpose(1, 2)), "opacity": f32c(opacities), "marker": f32c(markers),
+             "kp_score": f32c(kp_scores), "scaling": f32c(scales), "rotation": f32c(rots)}
+    opt = gaussians.optimizer
+    groups = {g["name"]: g for g in opt.param_groups}
+    params = {k: getattr(gaussians, ATTR[k]).detach().contiguous() for k in GROUPS}
+    P = int(params["xyz"].shape[0])
+    widths = {k: _row_width(extra[k]) for k in GROUPS}
+    for k in GROUPS:
+        if P and _row_width(params[k]) != widths[k]:
+            raise RuntimeError(f"extend_from_pcd: group `{k}` has rows of {_row_width(params[k])} floats, the new rows {widths[k]}")
+        if int(extra[k].shape[0]) != N:
+            raise RuntimeError(f"extend_from_pcd: `{k}` has {int(extra[k].shape[0])} rows, expected {N}")
+    m, v = {}, {}
+    for k in GROUPS:
+        st = opt.state.get(groups[k]["params"][0], None)
+        if st is not None and "exp_avg" in st:
+            m[k], v[k] = st["exp_avg"].contiguous(), st["exp_avg_sq"].contiguous()
+    n = P + N
+    f32 = dict(dtype=torch.float32, device=dev)
+    new_p = {k: torch.empty((n,) + tuple(extra[k].shape[1:]), **f32) for k in GROUPS}
+    alloc = torch.empty_like if P else torch.zeros_like    # an empty model with state: nothing to copy, all rows new
+    new_m = {k: alloc(new_p[k]) for k in m}
+    new_v = {k: alloc(new_p[k]) for k in m}
+    if n:
+        src = _model_struct(params, P, widths)
+        ext = _model_struct(extra, N, widths)
+        out = _model_struct(new_p, n, widths)
+        has = bool(m)
+        m_in = _model_struct(m, P, widths) if has else None
+        v_in = _model_struct(v, P, widths) if has else None
+        m_out = _model_struct(new_m, n, widths) if has else None
+        v_out = _model_struct(new_v, n, widths) if has else None
+        ref = lambda s: None if s is None else C.byref(s)  # noqa: E731
+        with _on_device(dev):
+            _native.check(lib.splatraster_model_append(C.byref(src), ref(m_in), ref(v_in), C.byref(ext), C.byref(out),
+                                                       ref(m_out), ref(v_out), _stream(dev)), "model_append")
+    for k in GROUPS:
+        grp = groups[k]
+        old = grp["params"][0]
+        st = opt.state.pop(old, None)
+        p = nn.Parameter(new_p[k].requires_grad_(True))
+        grp["params"][0] = p
+        if st is not None:
+            if k in new_m:
+                st["exp_avg"], st["exp_avg_sq"] = new_m[k], new_v[k]
+            opt.state[p] = st
+        setattr(gaussians, ATTR[k], p)
+    gaussians.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+    gaussians.denom = torch.zeros((n, 1), device=dev)
+    gaussians.max_radii2D = torch.zeros((n,), device=dev)
+    return n

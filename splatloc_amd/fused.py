@@ -240,7 +240,7 @@ def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier
     pkgs, extra = [], []
     dev = pc._xyz.device
     # view-independent activations once per window (on the caller's stream, before the fork)
-    shared = shared_activations(pc, pipe) if (share_activations and len(viewpoints) > 1 and pc._xyz.shape[0] > 0) else None
+    shared = shared_activations(pc, pipe) if (share_activations and (len(viewpoints) > 1 or batched) and pc._xyz.shape[0] > 0) else None
     if batched and shared is not None:
         settings = [_view_settings(vp, pc, bg_color, scaling_modifier) for vp in viewpoints]
         if _window_compatible(settings):
@@ -254,9 +254,19 @@ def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier
                 except Exception:  # noqa: BLE001
                     pass
                 carriers.append(sp)
-            outs = rasterize_window(settings, xyz, carriers, colors, opacity, scales=scales, rotations=rotations)
-            for k, (vp, (img, depth, alpha, radii)) in enumerate(zip(viewpoints, outs)):
-                pkg = {"render": img[:3, :, :], "kp_prob": img[-1, :, :], "viewspace_points": carriers[k],
+            # render = image[:3] and kp_prob = image[-1] leave the rasterizer as separate autograd outputs: their
+            # gradients reach the backward kernel as separate planes, and an output the loss never touches costs nothing
+            # (SplatLoc's layout [rgb | kp_score], C = 4; wider feature tables keep the one colour output and its slices)
+            split = int(colors.shape[1]) == 4
+            outs = rasterize_window(settings, xyz, carriers, colors, opacity, scales=scales, rotations=rotations,
+                                    split_last=split)
+            for k, (vp, o) in enumerate(zip(viewpoints, outs)):
+                if split:
+                    rgb, kp_prob, depth, alpha, radii = o
+                else:
+                    img, depth, alpha, radii = o
+                    rgb, kp_prob = img[:3, :, :], img[-1, :, :]
+                pkg = {"render": rgb, "kp_prob": kp_prob, "viewspace_points": carriers[k],
                        "visibility_filter": radii > 0, "radii": radii, "depth": depth, "opacity": alpha}
                 pkgs.append(pkg)
                 extra.append(per_view(k, vp, pkg) if per_view is not None else None)

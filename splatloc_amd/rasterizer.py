@@ -255,10 +255,16 @@ class _RasterizeWindow(torch.autograd.Function):
     splatraster_forward_window_* / splatraster_backward_window (include/splatraster.h).  Inputs: the shared
     rasterizer arguments, the list of per-view settings, then one `means2D` gradient carrier per view.  Outputs:
     (color_0, depth_0, alpha_0, radii_0, color_1, ...).  The backward runs once, when autograd has the output
-    gradients of every view, and returns parameter gradients already summed over the views."""
+    gradients of every view, and returns parameter gradients already summed over the views.
+
+    `split_last`: the colour buffer of every view is handed out as TWO autograd outputs, channels [0, C-1) and channel
+    C-1 — SplatLoc's `render` = image[:3] and `kp_prob` = image[-1] (gaussian_renderer/__init__.py:133-135) — so the
+    outputs are (rgb_0, last_0, depth_0, alpha_0, radii_0, rgb_1, ...).  Their gradients then reach the kernel as
+    separate planes (no zero-padded [C,H,W] copies and no add, which is what slicing one output costs in autograd),
+    and a channel / auxiliary plane that did not reach the loss is skipped by the backward (color_refinement)."""
 
     @staticmethod
-    def forward(ctx, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, *means2D):
+    def forward(ctx, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, split_last, *means2D):
         lib = _native.load()
         _require_gpu(means3D, "means3D")
         dev = means3D.device
@@ -303,6 +309,8 @@ class _RasterizeWindow(torch.autograd.Function):
             _native.check(lib.splatraster_forward_window_render(
                 C.byref(st), V, views, P, R, _ptr(bg), _ptr(col), _ptr(geom), _ptr(binning), _ptr(img), stream),
                 "forward_window_render")
+        split_last = bool(split_last) and Cn >= 2
+        ctx.split_last = split_last
         ctx.st, ctx.V, ctx.R = st, V, [int(r) for r in R]
         ctx.tanfov = [(float(rs.tanfovx), float(rs.tanfovy)) for rs in settings]
         ctx.have = (sca is not None, cov is not None)
@@ -314,7 +322,10 @@ class _RasterizeWindow(torch.autograd.Function):
         for v in range(V):
             rv = radii[v]
             rad.append(rv)
-            outs += [color[v], depth[v], alpha[v], rv]
+            if split_last:
+                outs += [color[v, :Cn - 1], color[v, Cn - 1], depth[v], alpha[v], rv]
+            else:
+                outs += [color[v], depth[v], alpha[v], rv]
         ctx.mark_non_differentiable(*rad)
         ctx.set_materialize_grads(False)
         return tuple(outs)
@@ -349,8 +360,14 @@ class _RasterizeWindow(torch.autograd.Function):
         views = (_native.WindowView * V)()
         keep = []
         zeros_color = None
+        split = ctx.split_last
+        nout = 5 if split else 4
         for v in range(V):
-            g_color, g_depth, g_alpha = gouts[4 * v], gouts[4 * v + 1], gouts[4 * v + 2]
+            if split:
+                g_color, g_last, g_depth, g_alpha = gouts[nout * v:nout * v + 4]
+                g_last = _prep(g_last, dev) if g_last is not None else None
+            else:
+                (g_color, g_depth, g_alpha), g_last = gouts[nout * v:nout * v + 3], None
             g_color = _prep(g_color, dev) if g_color is not None else None
             if g_color is None:     # this view's colour buffer did not reach the loss
                 if zeros_color is None:
@@ -358,7 +375,7 @@ class _RasterizeWindow(torch.autograd.Function):
                 g_color = zeros_color
             g_depth = _prep(g_depth, dev) if g_depth is not None else None
             g_alpha = _prep(g_alpha, dev) if g_alpha is not None else None
-            keep += [g_color, g_depth, g_alpha]
+            keep += [g_color, g_depth, g_alpha, g_last]
             w = views[v]
             cv, cp, cc = flat_cams[3 * v], flat_cams[3 * v + 1], flat_cams[3 * v + 2]
             w.viewmatrix, w.projmatrix = cv.data_ptr(), cp.data_ptr()
@@ -370,6 +387,8 @@ class _RasterizeWindow(torch.autograd.Function):
             w.dL_dout_depth = None if g_depth is None else g_depth.data_ptr()
             w.dL_dout_alpha = None if g_alpha is None else g_alpha.data_ptr()
             w.dL_dmeans2D = d_m2[v].data_ptr() if P else None
+            w.dL_dout_last = None if g_last is None else g_last.data_ptr()
+            w.color_grad_channels = Cn - 1 if split else 0
         R = (C.c_int64 * V)(*ctx.R)
         with _on_device(dev):
             _native.check(lib.splatraster_backward_window(
@@ -377,17 +396,18 @@ class _RasterizeWindow(torch.autograd.Function):
                 _ptr(binning), _ptr(img), _ptr(d_m3), _ptr(d_col), _ptr(d_op), _ptr(d_sca), _ptr(d_rot), _ptr(d_cov),
                 _stream(dev)), "backward_window")
         del keep
-        # (means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, *means2D)
-        return (d_m3, d_col, d_op, d_sca, d_rot, d_cov, None) + tuple(d_m2[v] for v in range(V))
+        # (means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, split_last, *means2D)
+        return (d_m3, d_col, d_op, d_sca, d_rot, d_cov, None, None) + tuple(d_m2[v] for v in range(V))
 
 
 def rasterize_window(settings, means3D, means2D, colors_precomp, opacities, scales=None, rotations=None,
-                     cov3D_precomp=None):
+                     cov3D_precomp=None, split_last: bool = False):
     """`[GaussianRasterizer(s)(means3D, m2, opacities, colors_precomp=..., ...) for s, m2 in zip(settings, means2D)]`
     as one launch sequence per chunk of <= 8 views.  `settings`: GaussianRasterizationSettings per view (same
     image size / scale modifier / background); `means2D`: one gradient carrier per view.  Returns a list of
     (color, depth, alpha, radii) per view — bit-identical to the per-view calls; the backward sums the views'
-    parameter gradients in-kernel (one gradient set per window instead of V sets + V accumulation passes)."""
+    parameter gradients in-kernel (one gradient set per window instead of V sets + V accumulation passes).
+    `split_last`: (rgb [C-1,H,W], last [H,W], depth, alpha, radii) per view instead — see _RasterizeWindow."""
     settings, means2D = list(settings), list(means2D)
     if colors_precomp is None:
         raise Exception("rasterize_window needs precomputed colors (view-dependent SH colours: per-view calls)")
@@ -402,8 +422,9 @@ def rasterize_window(settings, means3D, means2D, colors_precomp, opacities, scal
     K = _native.MAX_WINDOW_VIEWS
     for a in range(0, len(settings), K):
         flat = _RasterizeWindow.apply(means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                      tuple(settings[a:a + K]), *means2D[a:a + K])
-        out += [tuple(flat[4 * v:4 * v + 4]) for v in range(len(flat) // 4)]
+                                      tuple(settings[a:a + K]), bool(split_last), *means2D[a:a + K])
+        n = 5 if (split_last and int(colors_precomp.shape[1]) >= 2) else 4
+        out += [tuple(flat[n * v:n * v + n]) for v in range(len(flat) // n)]
     return out
 
 
