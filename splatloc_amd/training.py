@@ -75,3 +75,91 @@ def color_refinement_step(viewpoint_cam, gaussians, pipe, background, lambda_dss
         opt.zero_grad(set_to_none=True)
         update_learning_rate(gaussians, iteration)
     return loss
+
+
+def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: int, *, densify=None,
+             gaussian_reset: int = 0, seed: int = 0, group=None):
+    """One iteration of the loop body of SplatLoc.map (train_gaussians.py:188-267) on the window `viewpoints` (the
+    caller has drawn it: `all_viewpoint_stack[torch.randperm(len(...))[:window_size]]`, :195), with the device-side
+    pieces of this package, single- or multi-GPU:
+
+        render the window + per-view get_loss_mapping + get_loss_marker      -> fused.render_window (ONE launch sequence)
+        + 0.01 * isotropic regulariser (primitive_reg)                        -> losses.isotropic_loss (no .cpu() mask)
+        backward                                                              -> one window backward (gradients summed in-kernel)
+        key-primitive gate, max_radii2D / add_densification_stats per view    -> one statistics launch
+        densify_and_prune every `densify["every"]` iterations (offset)        -> densify.densify_and_prune
+        reset_opacity_nonvisible every `gaussian_reset` iterations            -> densify.reset_opacity_nonvisible
+        optimizer.step, zero_grad, update_learning_rate(iteration_count)
+
+    Frame-parallel data parallelism (torch.distributed initialised, one process per GPU, a full replica of
+    the scene per rank): the views of the window are dealt round-robin to the ranks (frame_parallel.shard_views), the
+    parameter gradients are SUM-all-reduced, the statistics increments SUM / MAX-reduced and the visibility union
+    OR-reduced, so every replica takes the SAME optimizer step and densifies identically (the split noise is
+    counter-based: keyed by (seed, iteration_count, source row, copy)) — the replicas stay bit-identical without ever
+    broadcasting parameters.  The regulariser is added on rank 0 only (the reduced gradient contains it once).
+    `densify`: dict(grad_threshold, min_opacity, extent, size_threshold, every, offset) or None.
+    Returns the rank's loss tensor (None on a rank without work)."""
+    import torch.distributed as dist
+    from .densify import densify_and_prune, reset_opacity_nonvisible
+    from .frame_parallel import allreduce_grads, shard_views, sync_densification_stats
+    from .losses import isotropic_loss, mapping_loss
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if multi else 0
+    world = dist.get_world_size(group) if multi else 1
+    primitive_reg = bool(config["Training"].get("primitive_reg", True))
+    viewpoints = list(viewpoints)
+    mine = [viewpoints[i] for i in shard_views(list(range(len(viewpoints))), rank, world)]
+    pkgs, losses = render_window(mine, gaussians, pipe, background,
+                                 per_view=lambda k, vp, pkg: mapping_loss(config, pkg["render"], pkg["depth"], pkg["kp_prob"], vp))
+    pkgs = [p for p in pkgs if p is not None]
+    loss = None
+    for term in losses:
+        if term is not None:
+            loss = term if loss is None else loss + term
+    if primitive_reg and rank == 0 and gaussians._xyz.shape[0] > 0:
+        reg = 0.01 * isotropic_loss(torch.exp(gaussians._scaling), gaussians._marker)
+        loss = reg if loss is None else loss + reg
+    if loss is not None:
+        loss.backward()
+    params = [getattr(gaussians, a) for a in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_kp_score", "_scaling",
+                                              "_rotation")]      # `_marker` never receives a gradient in map()
+    opt = gaussians.optimizer
+    with torch.no_grad():
+        P = int(gaussians._xyz.shape[0])
+        dev = gaussians._xyz.device
+        if multi:
+            for p in params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            allreduce_grads([p.grad for p in params if p.numel()], group=group)
+        if primitive_reg:
+            if hasattr(opt, "set_key_gate"):
+                opt.set_key_gate(gaussians._marker, 0.005)
+            elif gaussians._xyz.grad is not None:
+                gaussians._xyz.grad[gaussians._marker.detach().squeeze() > 0.005] = 0
+        grads2d = [p["viewspace_points"].grad for p in pkgs]
+        radii = [p["radii"] for p in pkgs]
+        if multi:
+            inc_a, inc_d = torch.zeros((P, 1), device=dev), torch.zeros((P, 1), device=dev)
+            if pkgs:
+                add_densification_stats_window(grads2d, radii, inc_a, inc_d, gaussians.max_radii2D)
+            sync_densification_stats(inc_a, inc_d, gaussians.max_radii2D, group=group)
+            gaussians.xyz_gradient_accum += inc_a
+            gaussians.denom += inc_d
+        elif pkgs:
+            add_densification_stats_window(grads2d, radii, gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D)
+        update_gaussian = bool(densify) and iteration_count % int(densify["every"]) == int(densify.get("offset", 0))
+        if update_gaussian:
+            densify_and_prune(gaussians, densify["grad_threshold"], densify["min_opacity"], densify["extent"],
+                              densify["size_threshold"], seed=seed, draw_id=iteration_count)
+        if gaussian_reset and iteration_count % gaussian_reset == 0 and not update_gaussian:
+            seen = torch.zeros(int(gaussians._xyz.shape[0]), dtype=torch.uint8, device=dev)
+            for p in pkgs:
+                seen |= p["visibility_filter"].to(torch.uint8)
+            if multi:
+                dist.all_reduce(seen, op=dist.ReduceOp.MAX, group=group)
+            reset_opacity_nonvisible(gaussians, [seen.bool()])
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        update_learning_rate(gaussians, iteration_count)
+    return loss

@@ -157,7 +157,29 @@ def test_bench_two_ranks_on_one_gpu_gloo(scaling):
     assert len(set(out["config"]["tile_instances_R_per_view"])) == 2   # different cameras -> different lists
 
 
-@pytest.mark.parametrize("stage,extra", [("activations", []), ("loss", []), ("map_step", ["--workload", "S0"])])
+def test_replicas_stay_bit_identical_through_map_steps_densify_and_reset():
+    """Frame-parallel readiness without a second GPU: 2 ranks (gloo, both on cuda:0), every rank a
+    replica of the scene, 4 map steps of splatloc_amd.training.map_step with the 5 views of each window dealt to the
+    ranks, one densify_and_prune (counter-based split noise) and one opacity reset in between.  Parameters, Adam
+    moments and step counters, statistics and row counts must be BIT-identical on both ranks afterwards
+    (tools/replica_check.py compares sha256 digests): the replicas exchange reduced gradients / statistics only."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SPLATLOC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "replica_check.py"), "--steps", "4"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-2500:])
+    out = json.loads(lines[0])
+    assert out["world"] == 2 and out["identical"] and not out["mismatched"]
+    assert out["rows_per_step"][1] != out["rows_per_step"][0]           # the densification really changed the model
+    assert out["tensors_compared"] >= 25
+
+
+@pytest.mark.parametrize("stage,extra", [("activations", []), ("loss", []), ("map_step", ["--workload", "S0"]),
+                                         ("refine_step", ["--workload", "S0"])])
 def test_bench_secondary_stages_run(stage, extra):
     """bench.py --stage ...: the §8f stage figures and the map()-shaped step stay runnable and
     print ONE JSON line with the contract's keys."""
@@ -168,7 +190,7 @@ def test_bench_secondary_stages_run(stage, extra):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["value"] > 0 and out["unit"].endswith("/s") and "NOT the BASELINE metric" in out["metric"]
-    if stage != "map_step":
+    if stage not in ("map_step", "refine_step"):
         assert 0 < out["roofline"]["frac"] < 1
 
 
