@@ -450,9 +450,14 @@ int splatraster_refinement_loss(int32_t channels, int32_t height, int32_t width,
 /* ---- simple_knn._C.distCUDA2 (gaussian_model.py:206) ---------------------------------- */
 
 size_t splatknn_workspace_bytes(int32_t N);
-/* out[i] = mean of the squared distances from points[i] to its 3 nearest other points. */
+/* out[i] = mean of the squared distances from points[i] to its 3 nearest other points.  Exact: a tiled brute force below
+ * 10 000 points, an exact uniform-grid search from there on (SplatLoc passes 5-20 k per key-frame) — same distance
+ * arithmetic, bit-identical results.  No host synchronisation. */
 int splatknn_dist2(int32_t N, const float* points /* [N,3] */, float* out /* [N] */,
                    void* workspace, void* stream);
+
+/* test hook: point count from which splatknn_dist2 takes the grid search (< 0 restores the default 10 000) */
+int splatknn_debug_set_grid_min(int32_t n);
 
 /* ---- per-stage timing (HIP events on the launch stream) ----------------------------- */
 

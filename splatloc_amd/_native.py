@@ -109,6 +109,7 @@ SYMBOLS = {
     "splatraster_timing_collect": (C.c_int, [_vp, _vp]),
     "splatknn_workspace_bytes": (_sz, [_i32]),
     "splatknn_dist2": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
+    "splatknn_debug_set_grid_min": (C.c_int, [_i32]),
     "splatraster_activate_forward": (C.c_int, [_i32] * 5 + [_vp] * 13),
     "splatraster_activate_backward": (C.c_int, [_i32] * 5 + [_vp] * 19),
     "splatraster_densification_stats": (C.c_int, [_i32] + [_vp] * 6),
@@ -170,6 +171,9 @@ def load(build_if_missing: bool = True):
         fn.restype = res
         fn.argtypes = args
     _LIB = lib
+    # A/B knobs for perf experiments (process-wide debug switches of the library; never set in production)
+    if os.environ.get("SPLATRASTER_SMALL_PANEL_MAX_WAVES"):
+        lib.splatraster_debug_set_small_panel_max_waves(int(os.environ["SPLATRASTER_SMALL_PANEL_MAX_WAVES"]))
     return lib
 
 

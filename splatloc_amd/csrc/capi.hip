@@ -871,6 +871,12 @@ int splatraster_refinement_loss(int32_t channels, int32_t height, int32_t width,
                                   reinterpret_cast<hipStream_t>(stream));
 }
 
+int splatknn_debug_set_grid_min(int32_t n)
+{
+    knn_set_grid_min(n);
+    return SPLATRASTER_OK;
+}
+
 int splatknn_dist2(int32_t N, const float* points, float* out, void* workspace, void* stream)
 {
     if (N < 0) return SPLATRASTER_ERR_BAD_ARG;

@@ -209,5 +209,6 @@ int launch_refinement_loss(int32_t C, int32_t H, int32_t W, float lambda, const 
 
 int knn_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream);
 size_t knn_workspace_bytes(int32_t N);
+void knn_set_grid_min(int n);   // point count from which the exact grid search replaces the tiled brute force (< 0: default)
 
 }  // namespace sr

@@ -602,7 +602,9 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
                        im.final_T, im.n_contrib, gacc, gacc_row_floats(s.channels),                                    \
                        gacc_moment_offset(s.channels), gacc64)
     if constexpr (NC >= 4 && NC <= 15 && AUX) {   // C = 3 and below: the flush costs what the 8 saved butterfly values gain (A/B: S0 0.036 vs 0.041 ms)
-        if (4 * L.V * tiles <= g_small_panel_max_waves)   // every quadrant-wave of the launch resident at once
+        // per VIEW: small frames (SplatLoc's 640x480) take the panel variant — also as a window of V views (A/B at the
+        // reference layout, 5 views: 0.816 vs 0.869 ms); large frames the butterfly variant at full occupancy
+        if (4 * tiles <= g_small_panel_max_waves)
             SR_BWD_LAUNCH(true);
         else
             SR_BWD_LAUNCH(false);

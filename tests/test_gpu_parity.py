@@ -246,6 +246,51 @@ def test_dist2_matches_oracle(n):
         np.testing.assert_allclose(out.cpu().numpy(), (d[:, 1:] ** 2).mean(1), rtol=1e-4, atol=1e-9)
 
 
+@pytest.mark.parametrize("n,kind", [(9, "uniform"), (1000, "uniform"), (20_000, "surface"), (40_000, "uniform"), (60_000, "plane"),
+                                    (200_000, "surface"), (500_000, "clustered")])
+def test_dist2_grid_equals_brute_force(n, kind):
+    """The exact uniform-grid search (taken from 10 000 points; forced here at every size) against the tiled brute
+    force: BIT-identical distances — same arithmetic, same 3 smallest values — on uniform clouds, a depth-map-like
+    surface (what create_pcd_from_image produces), an exactly flat plane, clusters with duplicates; and against the
+    CPU oracle where that is fast."""
+    from oracle import oracle
+    from simple_knn._C import distCUDA2
+    from splatloc_amd import _native
+    lib = _native.load()
+    rng = np.random.default_rng(n)
+    if kind == "uniform":
+        pts = rng.random((n, 3)) * np.array([5.0, 3.0, 4.0])
+    elif kind == "surface":
+        xy = rng.random((n, 2)) * 6.0 - 3.0
+        pts = np.concatenate([xy, (1.5 + 0.3 * np.sin(2 * xy[:, :1]) * np.cos(3 * xy[:, 1:]) + 0.002 * rng.normal(size=(n, 1)))], 1)
+    elif kind == "plane":
+        pts = np.concatenate([rng.random((n, 2)) * 4.0, np.full((n, 1), 2.5)], 1)
+    else:
+        centres = rng.normal(size=(40, 3)) * 3.0
+        pts = centres[rng.integers(0, 40, n)] + rng.normal(size=(n, 3)) * rng.choice([0.01, 0.1, 0.5], size=(n, 1))
+        pts[::1000] = pts[1::1000][: len(pts[::1000])]          # exact duplicates
+    pts = torch.from_numpy(pts.astype(np.float32)).cuda()
+    try:
+        lib.splatknn_debug_set_grid_min(1 << 30)
+        brute = distCUDA2(pts) if n <= 200_000 else None     # 500 k points: 2.5e11 evaluations — the oracle / brute leg stops at 200 k
+        lib.splatknn_debug_set_grid_min(0)
+        grid = distCUDA2(pts)
+    finally:
+        lib.splatknn_debug_set_grid_min(-1)
+    default = distCUDA2(pts)
+    assert torch.equal(default, grid if n >= 10_000 else (brute if brute is not None else grid))
+    if brute is not None:
+        assert torch.equal(grid.view(torch.int32), brute.view(torch.int32)), \
+            f"{int((grid.view(torch.int32) != brute.view(torch.int32)).sum())} of {n} distances differ"
+    if n <= 20_000:
+        assert np.array_equal(grid.cpu().numpy().view(np.uint32), oracle.dist2(pts.cpu().numpy()).view(np.uint32))
+    from scipy.spatial import cKDTree
+    sub = rng.choice(n, size=min(n, 20_000), replace=False)
+    p64 = pts.cpu().numpy().astype(np.float64)
+    d, _ = cKDTree(p64).query(p64[sub], k=4)
+    np.testing.assert_allclose(grid.cpu().numpy()[sub], (d[:, 1:] ** 2).mean(1), rtol=2e-4, atol=1e-9)
+
+
 def test_full_size_properties():
     """North-star shape (S2: 500k Gaussians, 1920x1080, C = 35): size-independent checks —
     sortedness of the instance list, range table partition, alpha = 1 - final_T,

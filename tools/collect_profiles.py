@@ -2,7 +2,9 @@
 """Copies the summaries of a tools/profile_round.sh + tools/pmc_passes.sh run (gpurun_out/prof_TAG) into the
 tracked profiles/ directory as rNN_* files and refreshes profiles/traffic.json (HBM bytes per launch of every
 kernel group, read by bench.py as roofline.traffic) and profiles/valu.json (VALU / MFMA / issue statistics of the
-two compositing kernels, read by bench.py as frame_valu).  usage: collect_profiles.py TAG rNN"""
+two compositing kernels, read by bench.py as frame_valu / roofline_valu).  Both files record the workload and the launch
+mode (frames per launch) they were measured on: bench.py attaches them only to a run of the same kind.
+usage: collect_profiles.py TAG rNN [WORKLOAD=S2] [FRAMES_PER_LAUNCH=5]"""
 import json
 import os
 import shutil
@@ -10,6 +12,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "S2"
+fpl = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 for a, b in (("summary_kernel_stats.txt", "kernel_stats.txt"), ("summary_pmc.json", "pmc_hbm.json"), ("timeline.txt", "timeline.txt"),
@@ -34,11 +38,15 @@ for g, keys in group.items():
             tot += int(e["hbm_bytes_per_launch"] * per_frame)
     if tot:
         traffic[g] = tot
-traffic["_note"] = (f"HBM bytes per frame of each stage from rocprofv3 PMC passes on S2 (profiles/{rnd}_pmc_hbm.json): "
-                    "2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB -> bytes; one launch per frame for the compositing kernels")
+traffic["_workload"] = workload
+traffic["_frames_per_launch"] = fpl
+traffic["_note"] = (f"HBM bytes per launch sequence ({fpl} frame(s): one window) of each stage from rocprofv3 PMC passes on {workload} "
+                    f"(profiles/{rnd}_pmc_hbm.json): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB -> bytes; one launch per "
+                    "sequence for the compositing kernels")
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 sq = json.load(open(os.path.join(dst, f"{rnd}_pmc_sq_counters.json")))
-valu = {"_note": f"rocprofv3 SQ counters per launch on S2 (profiles/{rnd}_pmc_sq_counters.json, summed over the 8 XCDs); "
+valu = {"_workload": workload, "_frames_per_launch": fpl,
+        "_note": f"rocprofv3 SQ counters per launch ({fpl} frame(s)) on {workload} (profiles/{rnd}_pmc_sq_counters.json, summed over the 8 XCDs); "
                  "valu_busy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8; "
                  "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 * kernel cycles)"}
 for k, c in sq.items():
