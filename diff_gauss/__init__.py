@@ -4,7 +4,8 @@ from splatloc_amd.rasterizer import (  # noqa: F401
     GaussianRasterizationSettings,
     GaussianRasterizer,
     rasterize_gaussians,
+    rasterize_window,
     _RasterizeGaussians,
 )
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_window"]

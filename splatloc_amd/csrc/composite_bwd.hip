@@ -66,6 +66,19 @@
 #ifndef SR_BWD_DOT_PREFETCH
 #define SR_BWD_DOT_PREFETCH 1  // double-buffered LDS reads in the 4x4x1 dot (A/B on S2: 0.8645 -> 0.860 ms)
 #endif
+// Timing probes only (WRONG results; tools/ablate.py): what would a kernel cost that reduced the geometric moments on the
+// matrix pipe instead of through the moment products + packed butterfly?
+//   SR_BWD_PROBE = 1: the per-pair butterfly + atomic dropped (their inputs stay live)
+//   SR_BWD_PROBE = 2: additionally the moment products dropped: E alone is parked in a second LDS panel
+//   SR_BWD_PROBE = 3: as 2, plus SR_BWD_PROBE_BLOCKS more 16-column MFMA blocks per flush fed from that panel
+//   SR_BWD_PROBE = 4: the 4x4x1 MFMA dot products dropped (q = a cheap stand-in): is the matrix pipe a co-bottleneck?
+//   SR_BWD_PROBE = 5: the flush's 16x16x4 MFMAs dropped (atomics kept)
+#ifndef SR_BWD_PROBE
+#define SR_BWD_PROBE 0
+#endif
+#ifndef SR_BWD_PROBE_BLOCKS
+#define SR_BWD_PROBE_BLOCKS 1
+#endif
 #ifndef SR_BWD_DOTM_MIN
 #define SR_BWD_DOTM_MIN 8  // channels from which the 4x4x1 MFMA dot product is used
 #endif
@@ -100,7 +113,7 @@ struct BwdCfg {
     static constexpr bool MFMA = NC >= 32 || SMALLP;
     static constexpr int NM = NC >= 32 ? 32 : (SMALLP ? NC : 0);   // channels reduced on the matrix pipe
     static constexpr int NB = NC >= 32 ? 2 : 1;                    // 16-column blocks of the contraction
-    static constexpr bool XD = SMALLP;                             // column NC of the block = the depth weight
+    static constexpr bool XD = SMALLP && AUX;                      // column NC of the block = the depth weight
     static constexpr int NV = NC - NM;         // channels reduced with the packed butterfly
     // AUX = false: no view of the launch has a depth / alpha gradient (color_refinement, train_gaussians.py:283-285):
     // the depth weight w g_D is identically zero and leaves the reduction
@@ -139,7 +152,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      int MO, long long* __restrict__ gacc64 /*[V * P, GROW] fixed point, DET only*/)
 {
     using Cfg = BwdCfg<NC, SP, AUX>;
-    static_assert(AUX || !SP, "the no-aux variant exists for the butterfly kernels only");
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
     constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
     constexpr bool MFMA = Cfg::MFMA, XD = Cfg::XD;
@@ -154,6 +166,9 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
     __shared__ uint32_t s_cgid[FS];
     __shared__ float s_w[MFMA ? WAVE * WS : 1];   // matrix-pipe weight panel w[64 pix][GROUP]
+#if SR_BWD_PROBE >= 2
+    __shared__ float s_e[MFMA ? WAVE * WS : 1];   // probe: second panel (E values)
+#endif
     __shared__ uint32_t s_gid[MFMA ? GROUP : 1];  // Gaussian id of every parked panel column
 
 #ifdef SR_TRACE_WAVES
@@ -265,12 +280,43 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         __builtin_amdgcn_wave_barrier();
         f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
         const int row = (lane >> 4) * WS + (lane & 15);
+#if SR_BWD_PROBE >= 3
+        f32x4 DP[SR_BWD_PROBE_BLOCKS];
+#pragma unroll
+        for (int q = 0; q < SR_BWD_PROBE_BLOCKS; ++q) DP[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float xl = (float)(lane >> 4), cj = (float)(lane & 15);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const float a = s_w[4 * kk * WS + row];
+#if SR_BWD_PROBE == 5
+            D0[kk & 3] += a * gt[kk][0];
+            if (NB > 1) D1[kk & 3] += a * gt[kk][NB > 1 ? 1 : 0];
+#else
             D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][0], D0, 0, 0, 0);
             if (NB > 1) D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][NB > 1 ? 1 : 0], D1, 0, 0, 0);
+#endif
+#if SR_BWD_PROBE >= 3
+            const float ae = s_e[4 * kk * WS + row];
+            const float bp = fmaf(cj, xl + (float)(4 * (kk & 1)), (float)(kk >> 1));   // stands in for the 2-FMA polynomial operand
+#pragma unroll
+            for (int q = 0; q < SR_BWD_PROBE_BLOCKS; ++q) DP[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(q ? a : ae, bp, DP[q], 0, 0, 0);
+#endif
         }
+#if SR_BWD_PROBE >= 3
+#pragma unroll
+        for (int q = 0; q < SR_BWD_PROBE_BLOCKS; ++q) {   // shift + atomics stand-in: ~5 VALU per register, one atomic per register
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = DP[q][r];
+                v = fmaf(v, xl, dpp_get<0x111, 0xf>(v));
+                v = fmaf(v, cj, dpp_get<0x112, 0xf>(v));
+                v = fmaf(v, xl, dpp_get<0x113, 0xf>(v));
+                const int gs = 4 * (lane >> 4) + r;
+                if (gs < count && (lane & 15) < 7) acc_add<DET>(gacc, gacc64, (size_t)(__umul24(s_gid[gs], (uint32_t)GROW) + (uint32_t)(32 + (lane & 15))), v);
+            }
+        }
+#endif
         // one block: column j < NC is channel c0 + j, column NC the depth weight (moment slot 6, first pass only)
         const int j0c = lane & 15;
         const bool col_ok = NB > 1 || j0c < NC || (XD && j0c == NC && first_pass);
@@ -430,10 +476,19 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     red[ch] = w0 * g[NM + ch];
                     red[KV + ch] = w1 * g[NM + ch];
                 }
+#if SR_BWD_PROBE >= 2
+                constexpr bool MOMENTS = !MFMA;
+                if (MFMA) {
+                    s_e[lane * WS + nslot] = G0 * dA0;
+                    s_e[lane * WS + nslot + 1] = G1 * dA1;
+                }
+#else
+                constexpr bool MOMENTS = true;
+#endif
                 // geometric partials as raw moments of E = G dL/dalpha over the pixel offset d;
                 // the per-Gaussian factors (conic, opacity, 0.5 W / 0.5 H) are applied once per
                 // Gaussian in preprocess_bwd instead of once per (pixel, Gaussian) here
-                {
+                if (MOMENTS) {
                     const float E = G0 * dA0, Ex = E * dx0, Ey = E * dy0;
                     red[NV + 0] = Ex;
                     red[NV + 1] = Ey;
@@ -443,7 +498,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     red[NV + 5] = E;
                     if (!XD && AUX) red[NV + ((XD || !AUX) ? 5 : 6)] = w0 * gD;
                 }
-                {
+                if (MOMENTS) {
                     const float E = G1 * dA1, Ex = E * dx1, Ey = E * dy1;
                     red[KV + NV + 0] = Ex;
                     red[KV + NV + 1] = Ey;
@@ -455,6 +510,14 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 }
                 BP_T(tp2);
                 BP_ADD(3, tp2 - tp1);
+#if SR_BWD_PROBE >= 1
+                if (MFMA) {
+#if SR_BWD_PROBE == 1
+#pragma unroll
+                    for (int k = 0; k < 2 * KV; ++k) asm volatile("" ::"v"(red[k]));
+#endif
+                } else {
+#endif
                 const float outv = wave_reduce_pack<2 * KV>(red, lane);
 #ifdef SR_BWD_PROFILE
                 asm volatile("" ::"v"(outv));
@@ -468,6 +531,10 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 asm volatile("" ::"v"(di), "v"(outv));
 #else
                 if (slot_ok && (has1 || !slot_second)) acc_add<DET>(gacc, gacc64, di, outv);
+#endif
+#if SR_BWD_PROBE >= 1
+                }
+                const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];
 #endif
                 if (MFMA) {
                     // park the weights (0 for pixels that miss); a pair never straddles a flush
@@ -540,7 +607,12 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 float qm[4] = {0.f, 0.f, 0.f, 0.f};
                 BP_T(td0);
                 if (DOTM) {
+#if SR_BWD_PROBE == 4
+                    const float zq = reinterpret_cast<const float*>(&s_rec0[min(slot + (lane & 3), ncand - 1)])[2];
+                    const f32x4 Q = {zq * gD, zq * g[0], zq * g[1], zq * g[2]};
+#else
                     const f32x4 Q = dot4(slot);
+#endif
                     qm[0] = Q[0]; qm[1] = Q[1]; qm[2] = Q[2]; qm[3] = Q[3];
 #ifdef SR_BWD_PROFILE
                     asm volatile("" ::"v"(qm[0]), "v"(qm[3]));
@@ -634,7 +706,7 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int32_t V, in
         any_aux = any_aux || grads.dL_ddepth[v] != nullptr || grads.dL_dalpha[v] != nullptr;
     }
     if (grads.gc < C && !any_last) C = grads.gc;
-    if (C == 3 && !any_aux && !det)
+    if (C == 3 && !any_aux && !det)   // (the panel variant of this kernel measured equal at 640x480: 0.752 vs 0.760 ms per refinement iteration)
         return launch_one_bwd<3, false, false>(s, 0, 1, g, b, im, feat, feat_stride, L, gacc, gacc64, stream);
 #define SR_BWD_ARGS g, b, im, feat, feat_stride, L, gacc, gacc64, stream
 #define SR_BWD_ONE(N, c0_, first_) (det ? launch_one_bwd<N, true>(s, c0_, first_, SR_BWD_ARGS) : launch_one_bwd<N, false>(s, c0_, first_, SR_BWD_ARGS))
