@@ -256,8 +256,13 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                     const float a = s_feat[((lane >> 5) ? s1 : slot) * NCP + (lane & 31)];  // A[i = ch][k = g]
                     float b0 = w0, b1 = w1;
                     swap_halves(b0, b1);  // b0 -> B for pixels 0-31, b1 -> B for pixels 32-63
+#if defined(SR_FWD_PROBE) && SR_FWD_PROBE == 1   // timing probe (wrong colours): the matrix pipe out of the picture
+                    accA[0] += a * b0;
+                    accB[0] += a * b1;
+#else
                     mfma_acc_32x32x2(accA, a, b0);
                     mfma_acc_32x32x2(accB, a, b1);
+#endif
                 }
                 if (__builtin_amdgcn_ballot_w64(active) == 0) { wave_done = true; break; }
             }

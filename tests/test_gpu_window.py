@@ -229,3 +229,18 @@ def test_window_empty_scene_and_all_culled():
                             rotations=e(0, 4))
     assert outs[2][0].shape == (3, 96, 128) and outs[2][3].numel() == 0
     sum(o[0].sum() for o in outs).backward()
+
+
+def test_window_soak_random_shapes():
+    """Random window sizes / scene sizes / frame sizes / channel counts back to back: every per-view result of the window
+    bit-identical to the per-view call (sort path switches with V * P, scan look-back under different block counts, the
+    16-bit (view, tile) keys near their pass boundaries, buffer re-sizing between windows)."""
+    g = torch.Generator().manual_seed(2024)
+    for it in range(16):
+        V = int(torch.randint(1, 9, (1,), generator=g).item())
+        P = int(10 ** (1.0 + 3.7 * torch.rand(1, generator=g).item()))
+        W = int(16 + torch.randint(0, 700, (1,), generator=g).item())
+        H = int(16 + torch.randint(0, 500, (1,), generator=g).item())
+        C = [1, 3, 4, 7, 35][int(torch.randint(0, 5, (1,), generator=g).item())]
+        sm = 10 ** (-2.3 + 1.2 * torch.rand(1, generator=g).item())
+        _compare(make_scene(P, W, H, C, seed=700 + it, scale_median=sm), V)
