@@ -121,11 +121,16 @@ def _build_lock():
         yield
         return
     with f:
-        fcntl.flock(f.fileno(), fcntl.LOCK_EX)
+        locked = True
+        try:
+            fcntl.flock(f.fileno(), fcntl.LOCK_EX)
+        except OSError:      # a file system without advisory locks: proceed unlocked (single-process use still works)
+            locked = False
         try:
             yield
         finally:
-            fcntl.flock(f.fileno(), fcntl.LOCK_UN)
+            if locked:
+                fcntl.flock(f.fileno(), fcntl.LOCK_UN)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -148,3 +148,33 @@ def test_product_does_not_import_oracle():
                     txt = open(os.path.join(dp, f)).read()
                     assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
                     assert "splat_oracle" not in txt and "liborc" not in txt, os.path.join(dp, f)
+
+
+def test_concurrent_imports_after_a_source_change_build_once_and_all_load():
+    """Every rank of a `torchrun --nproc-per-node N` job imports the package at the same moment.  With a stale manifest
+    (= a source edit) they would all rebuild: the build holds an exclusive flock and installs the objects, the library
+    and the manifest with atomic renames, so one process builds, the others wait and find everything up to date, and
+    nobody dlopens a half-written ELF (round-2 advisor finding)."""
+    import json
+    import subprocess
+    import sys
+    from splatloc_amd import build
+    if not build.have_hipcc():
+        pytest.skip("no hipcc")
+    build.build()
+    m = json.load(open(build.MANIFEST))
+    m["knn.hip"] = "stale"                      # what a source edit looks like to up_to_date()
+    json.dump(m, open(build.MANIFEST, "w"))
+    code = ("from splatloc_amd import _native; lib = _native.load(); "
+            "print('ok', lib.splatraster_abi_version())")
+    procs = [subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(4)]
+    outs = [p.communicate() for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-400:] for o in outs]
+    assert all(o[0].split() == ["ok", str(_abi())] for o in outs), outs
+    assert build.up_to_date()
+
+
+def _abi():
+    from splatloc_amd import _native
+    return _native.ABI_VERSION
