@@ -889,6 +889,9 @@ def main():
                           "frac_of_peak": round(frame_bytes * value / world / 1e9 / HBM_PEAK_GBS, 5),
                           "ms_per_frame": round(ms_per_step / max(len(views), 1), 4)},
             "frame_valu": valu,
+            # the same step as the reference's own loop of per-view GaussianRasterizer calls (secondary; None when that IS the run)
+            "per_view_loop": next(({"value": m["value"], "ms_per_step": m["ms_per_step"], "unit": "frames/s"}
+                                   for m in multi_stream if m["streams"] == 1), None),
             "multi_stream": multi_stream or None,
             "stages": per_stage,
             "stages_note": f"per-stage table from {BREAKDOWN_STEPS} untimed steps with every stage bracketed by HIP "
