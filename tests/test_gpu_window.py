@@ -244,3 +244,40 @@ def test_window_soak_random_shapes():
         C = [1, 3, 4, 7, 35][int(torch.randint(0, 5, (1,), generator=g).item())]
         sm = 10 ** (-2.3 + 1.2 * torch.rand(1, generator=g).item())
         _compare(make_scene(P, W, H, C, seed=700 + it, scale_median=sm), V)
+
+
+@pytest.mark.parametrize("name,V", [("S2", 3), ("S2-ref-layout", 5)])
+def test_window_full_size_against_oracle(name, V):
+    """BASELINE.json's full sizes through the window path: 3 views of S2 (500k Gaussians, 1920x1080, C = 35) and the
+    5-view window SplatLoc really renders (500k, 640x480, C = 4) — every view's radii / point list / ranges / n_contrib /
+    final_T bit-exact against the CPU oracle, images <= 1e-4, per-view dL/dmeans2D and the SUMMED parameter gradients
+    against the sum of the oracle's per-view gradients."""
+    from oracle import oracle
+    from splatloc_amd.synthetic import make_workload
+    sc = make_workload(name)
+    dev = torch.device(DEV)
+    views = _views(sc, V, dev)
+    Lw, outs, m2s, states = _window(sc, views, dev)
+    tot = {}
+    for v, (cam, rs, g) in enumerate(views):
+        f = oracle.forward(oracle.Settings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy), sc.bg.numpy(),
+                           sc.means3D.numpy(), sc.opacities.numpy(), cam.world_view_transform.cpu().numpy(),
+                           cam.full_proj_transform.cpu().numpy(), cam.camera_center.cpu().numpy(),
+                           colors_precomp=sc.features.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy(), omp=True)
+        b = oracle.backward(f, g[0].cpu().numpy(), g[1].cpu().numpy(), g[2].cpu().numpy(), omp=True)
+        st, R = states[v]
+        assert R == f["num_rendered"] > 500_000
+        assert np.array_equal(outs[v][3].cpu().numpy(), f["radii"])
+        assert np.array_equal(st["point_list"].cpu().numpy().astype(np.uint32), f["point_list"])
+        assert np.array_equal(st["ranges"].cpu().numpy().astype(np.uint32), f["ranges"])
+        assert np.array_equal(st["n_contrib"].cpu().numpy().astype(np.int64), f["n_contrib"].astype(np.int64))
+        assert np.array_equal(st["final_T"].cpu().numpy().view(np.uint32), f["final_T"].view(np.uint32))
+        assert np.abs(outs[v][0].detach().cpu().numpy() - f["color"]).max() <= 1e-4
+        assert np.abs(outs[v][1].detach().cpu().numpy() - f["depth"]).max() <= 1e-4 * max(1.0, float(f["depth"].max()))
+        assert_grad_close(f"means2D[{v}]", m2s[v].grad.cpu().numpy(), b["dL_dmeans2D"])
+        for k in ("dL_dmeans3D", "dL_dcolors", "dL_dopacities", "dL_dscales", "dL_drotations"):
+            tot[k] = b[k].astype(np.float64) + tot.get(k, 0.0)
+        del f, b
+    for k, nm in (("dL_dmeans3D", "means3D"), ("dL_dcolors", "colors"), ("dL_dopacities", "opac"),
+                  ("dL_dscales", "scales"), ("dL_drotations", "rots")):
+        assert_grad_close(k, Lw[nm].grad.cpu().numpy(), tot[k])
