@@ -137,6 +137,8 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
                 opt.set_key_gate(gaussians._marker, 0.005)
             elif gaussians._xyz.grad is not None:
                 gaussians._xyz.grad[gaussians._marker.detach().squeeze() > 0.005] = 0
+        elif hasattr(opt, "set_key_gate"):
+            opt.set_key_gate(None)
         grads2d = [p["viewspace_points"].grad for p in pkgs]
         radii = [p["radii"] for p in pkgs]
         if multi:
