@@ -98,6 +98,7 @@ SYMBOLS = {
     "splatraster_get_window_binning_layout": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _i32, C.POINTER(BinningLayout)]),
     "splatraster_get_window_image_layout": (C.c_int, [_i32, _i32, _i32, C.POINTER(ImageLayout)]),
     "splatraster_debug_set_small_panel_max_waves": (C.c_int, [C.c_int]),
+    "splatraster_debug_set_split_max_waves": (C.c_int, [C.c_int]),
     "splatraster_mark_visible": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_get_geometry_layout": (C.c_int, [_i32, C.POINTER(GeometryLayout)]),
     "splatraster_get_binning_layout": (C.c_int, [_i32, _i64, _i32, _i32, _i32, C.POINTER(BinningLayout)]),
@@ -172,6 +173,8 @@ def load(build_if_missing: bool = True):
         fn.argtypes = args
     _LIB = lib
     # A/B knobs for perf experiments (process-wide debug switches of the library; never set in production)
+    if os.environ.get("SPLATRASTER_SPLIT_MAX_WAVES"):
+        lib.splatraster_debug_set_split_max_waves(int(os.environ["SPLATRASTER_SPLIT_MAX_WAVES"]))
     if os.environ.get("SPLATRASTER_SMALL_PANEL_MAX_WAVES"):
         lib.splatraster_debug_set_small_panel_max_waves(int(os.environ["SPLATRASTER_SMALL_PANEL_MAX_WAVES"]))
     return lib

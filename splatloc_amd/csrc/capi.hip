@@ -12,6 +12,9 @@ namespace sr {
 
 static thread_local std::string g_last_error;
 static int g_deterministic = 0;   // splatraster_debug_set_deterministic
+static int g_split_max_waves = SPLIT_MAX_WAVES;
+void set_split_max_waves(int waves) { g_split_max_waves = waves < 0 ? SPLIT_MAX_WAVES : (waves > SPLIT_MAX_WAVES ? SPLIT_MAX_WAVES : waves); }
+int split_max_waves() { return g_split_max_waves; }
 
 void set_hip_error(hipError_t e, const char* what)
 {
@@ -150,7 +153,7 @@ GeomView geom_view(void* base, int32_t P, int32_t V)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, ckpt, bytes;
 };
 static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t H, int32_t C)
 {
@@ -173,6 +176,10 @@ static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t 
     L.gacc = take((size_t)(P > 0 ? P : 1) * nv * gacc_row_floats(C) * sizeof(float));
     // (the deterministic debug mode's 64-bit accumulator is NOT part of this buffer: it is a stream-ordered
     //  allocation made by the backward only while that mode is on)
+    // mid-list checkpoints of the forward for split launches (small frames, narrow layouts): the maximum is reserved
+    // whenever the shape qualifies, whatever the run-time knob says
+    const bool ck = C <= 4 && 4 * (size_t)tiles <= (size_t)SPLIT_MAX_WAVES;
+    L.ckpt = take(ck ? nv * (size_t)(SPLIT_PARTS - 1) * (size_t)(C + 2) * (size_t)W * (size_t)H * sizeof(float) : 16);
     L.bytes = o;
     return L;
 }
@@ -192,6 +199,7 @@ BinView bin_view(void* base, int32_t P, int32_t V, int64_t R, int32_t W, int32_t
     v.imask = reinterpret_cast<uint8_t*>(b + L.imask);
     v.featp = reinterpret_cast<float*>(b + L.featp);
     v.gacc = reinterpret_cast<float*>(b + L.gacc);
+    v.ckpt = reinterpret_cast<float*>(b + L.ckpt);
     return v;
 }
 
@@ -664,6 +672,12 @@ int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, 
 int splatraster_debug_set_small_panel_max_waves(int waves)
 {
     set_small_panel_max_waves(waves);
+    return SPLATRASTER_OK;
+}
+
+int splatraster_debug_set_split_max_waves(int waves)
+{
+    set_split_max_waves(waves);
     return SPLATRASTER_OK;
 }
 

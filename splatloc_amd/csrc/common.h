@@ -109,6 +109,7 @@ struct BinView {
     uint8_t* imask;       // [R] bit q: the Gaussian may reach quadrant q of its tile
     float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows); shared by the views
     float* gacc;          // [V * P * gacc_row_floats(C)] backward gradient accumulator rows (one per row)
+    float* ckpt;          // [V][SPLIT_PARTS - 1][C + 2][H * W] list checkpoints of the forward (T, colours, depth), split launches only
 };
 struct ImgView {
     float* final_T;       // [V][H * W]
@@ -164,6 +165,25 @@ static inline int padded_channels(int C) { return (C + 3) & ~3; }
 // The moments share the last 64-byte line of the features when they fit.
 __host__ __device__ static inline int gacc_moment_offset(int C) { return ((C & 15) + 7 <= 16) ? C : ((C + 15) & ~15); }
 __host__ __device__ static inline int gacc_row_floats(int C) { return (gacc_moment_offset(C) + 7 + 15) & ~15; }
+// One small frame alone (SplatLoc's color_refinement: 640x480, one view) is 4 800 quadrant-waves on a machine with room
+// for ~8 000: every wave starts at once and the compositing kernel lasts as long as its LONGEST list.  For such launches
+// (narrow layouts, all waves resident) the forward checkpoints every pixel's state (T, colours, depth) at the quarter
+// points of the tile's list and the backward runs SPLIT_PARTS waves per quadrant, one per quarter of the list: wave k > 0
+// starts from checkpoint k (T_k, S_k = S_total - C_k . g - D_k g_D).  The backward only needs the list up to the quadrant's
+// deepest contributor (63 % of it on average), so quarters balance better than halves.  The forward itself — T chain,
+// n_contrib, final_T, the images — is untouched, so every bit-exact contract holds.  Lists shorter than SPLIT_MIN_LIST
+// are not split.
+constexpr int SPLIT_MAX_WAVES = 8192;
+constexpr int SPLIT_MIN_LIST = 256;
+constexpr int SPLIT_PARTS = 4;
+void set_split_max_waves(int waves);   // A/B hook (< 0: default)
+int split_max_waves();
+static inline bool split_lists(int C, int V, int tiles) { return C <= 4 && 4 * V * tiles <= split_max_waves(); }
+// entries per part of a list of `len` entries (a multiple of the 64-entry chunk; len when the list is not split)
+__host__ __device__ static inline uint32_t split_part(uint32_t len)
+{
+    return len < (uint32_t)SPLIT_MIN_LIST ? len : ((len / (uint32_t)SPLIT_PARTS + 63u) & ~63u);
+}
 
 int launch_composite_fwd(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g, const BinView& b,
                          const ImgView& im, const float* featp /*padded rows, shared by the views*/, const float* bg,

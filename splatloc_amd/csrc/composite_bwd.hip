@@ -149,7 +149,9 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      WinGrad grads,
                      const float* __restrict__ final_T_all, const uint32_t* __restrict__ n_contrib_all,
                      float* __restrict__ gacc /*[V * P, GROW]*/, int GROW,
-                     int MO, long long* __restrict__ gacc64 /*[V * P, GROW] fixed point, DET only*/)
+                     int MO, long long* __restrict__ gacc64 /*[V * P, GROW] fixed point, DET only*/,
+                     const float* __restrict__ ckpt_all /*split launches (common.h; gridDim.y == SPLIT_PARTS): the forward's list
+                                                          checkpoints [V][SPLIT_PARTS - 1][NC + 2][H * W], else null*/)
 {
     using Cfg = BwdCfg<NC, SP, AUX>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
@@ -207,7 +209,20 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     const float fx = (float)px, fy = (float)py;
     const size_t plane = (size_t)H * W;
     const size_t pix = inside ? (size_t)py * W + px : 0;
-    const uint32_t beg = ranges[2 * gtile], end0 = ranges[2 * gtile + 1];
+    uint32_t beg = ranges[2 * gtile], end0 = ranges[2 * gtile + 1];
+    // split launches: wave blockIdx.y of the quadrant takes part blockIdx.y of the tile's list
+    const uint32_t list0 = beg;                                // list positions (n_contrib) count from the tile's first entry
+    const bool split = NC <= 4 && ckpt_all != nullptr;
+    const int seg = split ? (int)blockIdx.y : 0;
+    const bool second = seg > 0;                               // starts from a checkpoint
+    if (split) {
+        const uint32_t part = split_part(end0 - beg);
+        beg += (uint32_t)seg * part;
+        if (seg < SPLIT_PARTS - 1) end0 = min(end0, beg + part);
+        if (beg >= end0) return;
+    }
+    // (the forward wrote C_total + 2 planes per checkpoint: T, its C_total colours, depth — this pass may cover fewer channels)
+    const float* __restrict__ ckpt = ckpt_all + ((size_t)view * (SPLIT_PARTS - 1) + (second ? seg - 1 : 0)) * (C_total + 2) * ((size_t)H * W);
 
     // per-pixel constants
     float g[NC];
@@ -226,6 +241,14 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             gD = dL_ddepth ? dL_ddepth[pix] : 0.0f;
             const float gA = dL_dalpha ? dL_dalpha[pix] : 0.0f;
             S += out_depth[pix] * gD - final_T[pix] * gA;
+        }
+        if (NC <= 4) {
+            if (second) {   // S_k = S_total - sum_{j < k part} w_j q_j = S_total - C_k . g - D_k g_D
+                const float* ck = ckpt + pix;
+#pragma unroll
+                for (int ch = 0; ch < NC; ++ch) S = fmaf(-ck[(size_t)(1 + ch) * plane], g[ch], S);
+                if (AUX) S = fmaf(-ck[(size_t)(1 + C_total) * plane], gD, S);
+            }
         }
     } else {
 #pragma unroll
@@ -254,13 +277,15 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     uint32_t wave_last = last;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, d, WAVE));
-    const uint32_t end = min(end0, beg + wave_last);
+    const uint32_t end = min(end0, list0 + wave_last);
+    if (NC <= 4) { if (split && beg >= end) return; }   // nothing of this half contributes
 
 #ifdef SR_BWD_PROFILE
     unsigned long long bprof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     BP_T(tk0);
 #endif
     float T = 1.0f;
+    if (NC <= 4) { if (second && inside) T = ckpt[pix]; }
     // wave_reduce_pack leaves total k in lane bitreverse6(k); values [0, KV) belong to the first
     // Gaussian of a pair, [KV, 2 KV) to the second; inside a Gaussian: NV colours then 7 geometric
     const int slotv = (int)(__brev((unsigned)lane) >> 26);
@@ -377,7 +402,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             }
         }
         fetch(base + WAVE, reach, gid, a0, a1);  // next chunk, consumed after this one
-        const uint32_t idx0 = base - beg;
+        const uint32_t idx0 = base - list0;
 #pragma unroll 1
         while (cand != 0) {
             // ---- stage the feature rows of the next <= FS candidates ----
@@ -656,6 +681,7 @@ void set_small_panel_max_waves(int waves) { g_small_panel_max_waves = waves < 0 
 struct BwdLaunch {
     int P, V;
     const WinGrad* grads;
+    const float* ckpt;   // non-null: split launch — two waves per quadrant, the second from the forward's mid-list checkpoint
 };
 
 template <int NC, bool DET, bool AUX = true>
@@ -667,12 +693,14 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
     const int tiles = gx * gy;
     const unsigned blocks = quadrant_blocks(L.V * tiles, gx);  // 4 quadrants per (view, tile) (+ padding of the id space)
+    const float* ckpt = (NC <= 4 && c0 == 0 && first) ? L.ckpt : nullptr;
+    const dim3 grid(blocks, ckpt ? (unsigned)SPLIT_PARTS : 1u);
 #define SR_BWD_LAUNCH(SPV)                                                                                          \
-    hipLaunchKernelGGL((composite_bwd_kernel<NC, DET, SPV, AUX>), dim3(blocks), dim3(WAVE), 0, stream, s.image_width,   \
+    hipLaunchKernelGGL((composite_bwd_kernel<NC, DET, SPV, AUX>), grid, dim3(WAVE), 0, stream, s.image_width,           \
                        s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, L.V, L.P,      \
                        b.ranges, b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), *L.grads,       \
                        im.final_T, im.n_contrib, gacc, gacc_row_floats(s.channels),                                    \
-                       gacc_moment_offset(s.channels), gacc64)
+                       gacc_moment_offset(s.channels), gacc64, ckpt)
     if constexpr (NC >= 4 && NC <= 15 && AUX) {   // C = 3 and below: the flush costs what the 8 saved butterfly values gain (A/B: S0 0.036 vs 0.041 ms)
         // per VIEW: small frames (SplatLoc's 640x480) take the panel variant — also as a window of V views (A/B at the
         // reference layout, 5 views: 0.816 vs 0.869 ms); large frames the butterfly variant at full occupancy
@@ -695,7 +723,8 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int32_t V, in
     if (R == 0) return SPLATRASTER_OK;
     const bool det = gacc64 != nullptr;
     int C = s.channels;
-    const BwdLaunch L{P, V, &grads};
+    const int tiles_v = ((s.image_width + TILE - 1) / TILE) * ((s.image_height + TILE - 1) / TILE);
+    const BwdLaunch L{P, V, &grads, split_lists(s.channels, V, tiles_v) ? b.ckpt : nullptr};
     // Channels and auxiliary planes that did not reach the loss are not computed: when the last channel's gradient
     // travels apart (grads.gc = C - 1) and NO view has one, the launch covers channels [0, C - 1) only — its dL/dfeature
     // column stays at the zero the accumulator rows were cleared to; without any depth / alpha gradient the RGB kernel

@@ -93,14 +93,15 @@ struct FwdCfg {
 };
 
 template <int NC>
-__global__ void __launch_bounds__(WAVE, SR_FWD_MINW)
+__global__ void __launch_bounds__(WAVE, (NC <= 4) ? 8 : SR_FWD_MINW)   // narrow layouts stay within 64 registers (8 waves per SIMD)
 composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_aux, int tiles /*per view*/, int V,
                      int P /*rows per view*/,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                      const float4* __restrict__ irec,
                      const uint8_t* __restrict__ imask, const float4* __restrict__ featp4,
                      const float* __restrict__ bg, WinOut outs,
-                     float* __restrict__ final_T_all, uint32_t* __restrict__ n_contrib_all)
+                     float* __restrict__ final_T_all, uint32_t* __restrict__ n_contrib_all,
+                     float* __restrict__ ckpt_all /*split launches (common.h): [V][SPLIT_PARTS - 1][NC + 2][H * W] list checkpoints, else null*/)
 {
     using Cfg = FwdCfg<NC>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, FS = Cfg::FS;
@@ -172,8 +173,26 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
     fetch(beg, reach, gid, a0, a1);
 
     bool wave_done = __builtin_amdgcn_ballot_w64(active) == 0;
+    // split launches: wave k > 0 of this quadrant's backward starts at list entry beg + k * part
+    const uint32_t part = (NC <= 4 && ckpt_all != nullptr) ? split_part(end - beg) : 0u;
+    uint32_t ck_at = part ? beg + part : 0xFFFFFFFFu;
+    int ck_k = 0;
 #pragma unroll 1
     for (uint32_t base = beg; base < end && !wave_done; base += WAVE) {
+        if (NC <= 4) {
+            if (base == ck_at) {   // every pixel's state in front of this entry: T, the colours so far, the depth so far
+                if (inside) {
+                    const size_t pl = (size_t)H * W;
+                    float* ck = ckpt_all + ((size_t)view * (SPLIT_PARTS - 1) + ck_k) * (NC + 2) * pl + (size_t)py * W + px;
+                    ck[0] = T;
+#pragma unroll
+                    for (int ch = 0; ch < NV; ++ch) ck[(size_t)(1 + ch) * pl] = acc[ch];
+                    ck[(size_t)(1 + NV) * pl] = D;
+                }
+                ++ck_k;
+                ck_at = ck_k < SPLIT_PARTS - 1 ? ck_at + part : 0xFFFFFFFFu;
+            }
+        }
         uint64_t cand = __builtin_amdgcn_ballot_w64(reach);
         const uint32_t cur_gid = gid;
         const bool cur_reach = reach;
@@ -319,6 +338,7 @@ int launch_debug_exp2(int64_t n, const float* x, float* y, hipStream_t stream)
 struct FwdLaunch {
     int P, V;
     const WinOut* outs;
+    float* ckpt;   // non-null: split launch (the backward runs two waves per quadrant)
 };
 
 template <int NC>
@@ -333,7 +353,7 @@ static int launch_one(const splatraster_settings& s, int c0, int write_aux, cons
     hipLaunchKernelGGL(composite_fwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
                        s.image_height, padded_channels(feat_stride) / 4, c0, s.bg_channels, write_aux, tiles, L.V, L.P, b.ranges,
                        b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(featp), bg, *L.outs, im.final_T,
-                       im.n_contrib);
+                       im.n_contrib, (NC <= 4 && c0 == 0 && write_aux) ? L.ckpt : nullptr);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
@@ -343,7 +363,8 @@ int launch_composite_fwd(const splatraster_settings& s, int32_t P, int32_t V, in
 {
     (void)R;
     const int C = s.channels;
-    const FwdLaunch L{P, V, &outs};
+    const int tiles_v = ((s.image_width + TILE - 1) / TILE) * ((s.image_height + TILE - 1) / TILE);
+    const FwdLaunch L{P, V, &outs, split_lists(C, V, tiles_v) ? b.ckpt : nullptr};
     int c0 = 0, aux = 1, st = SPLATRASTER_OK;
 #define SR_FWD_CASE(N)                                                                              \
     case N:                                                                                         \

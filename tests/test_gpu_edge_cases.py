@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from splatloc_amd.synthetic import make_scene
-from tests.helpers import HipRun, oracle_backward, oracle_forward
+from tests.helpers import HipRun, assert_grad_close, oracle_backward, oracle_forward
 from tests.test_gpu_parity import _check_backward, _check_forward
 
 pytestmark = pytest.mark.gpu
@@ -212,3 +212,39 @@ def test_empty_scene_backward_zeroes_pose_gradients():
     (color.sum() + depth.sum()).backward()
     for t in (V, PM, cp):
         assert t.grad is not None and bool((t.grad == 0).all())
+
+
+@pytest.mark.parametrize("C,aux", [(4, True), (3, True), (4, False), (1, True)])
+def test_split_backward_matches_unsplit(C, aux):
+    """Small frames of narrow layouts run the backward as FOUR waves per quadrant, one per quarter of the tile's list, the
+    later ones starting from the forward's checkpoints (T_k, S_k = S_total - C_k . g - D_k g_D; common.h).  Same images
+    bit for bit (the forward's arithmetic is untouched) and the same gradients as the one-wave-per-quadrant backward, to
+    float-atomic rounding — and to 1e-5 in the deterministic-sum mode — on deep lists (hundreds of entries per tile)."""
+    from splatloc_amd import _native
+    lib = _native.load()
+    sc = make_scene(40_000, 256, 256, C, seed=90 + C, scale_median=0.05)
+    names = ["means3D", "means2D", "opacities", "colors", "scales", "rotations"]
+    for det in (False, True):
+        _native.set_deterministic(det)
+        try:
+            lib.splatraster_debug_set_split_max_waves(0)
+            a = HipRun(sc, use_depth=aux, use_alpha=aux)
+            lib.splatraster_debug_set_split_max_waves(-1)
+            b = HipRun(sc, use_depth=aux, use_alpha=aux)
+        finally:
+            lib.splatraster_debug_set_split_max_waves(-1)
+            _native.set_deterministic(False)
+        rng = a.state["ranges"].long()
+        assert int((rng[:, 1] - rng[:, 0]).max()) >= 4 * 256          # lists long enough to be split in four
+        assert torch.equal(a.color, b.color) and torch.equal(a.depth, b.depth) and torch.equal(a.alpha, b.alpha)
+        assert torch.equal(a.state["n_contrib"], b.state["n_contrib"])
+        for n in names:
+            ga, gb = getattr(a, n).grad.cpu().numpy(), getattr(b, n).grad.cpu().numpy()
+            if det:
+                assert_grad_close(n, gb, ga, rtol=2e-5, atol_scale=2e-6)
+            else:
+                assert_grad_close(n, gb, ga)
+    f = oracle_forward(sc)
+    bo = oracle_backward(f, sc, use_depth=aux, use_alpha=aux)
+    assert_grad_close("dL_dmeans3D vs oracle", b.np(b.means3D.grad), bo["dL_dmeans3D"])
+    assert_grad_close("dL_dcolors vs oracle", b.np(b.colors.grad), bo["dL_dcolors"])
