@@ -508,7 +508,7 @@ int splatraster_debug_set_deterministic(int on);
 int splatraster_debug_set_small_panel_max_waves(int waves);
 /* A/B hook: narrow-layout launches (C <= 4) with at most this many quadrant-waves split every list of >= 256 entries in
  * two for the backward (the forward checkpoints every pixel's state at the middle of its tile's list).
- * 0 = never, < 0 or > 8192 = the built-in default 8192.  Must not change between a forward and its backward. */
+ * 0 = never, < 0 or > 26000 = the built-in default 26000.  Must not change between a forward and its backward. */
 int splatraster_debug_set_split_max_waves(int waves);
 int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
 

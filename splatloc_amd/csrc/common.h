@@ -167,13 +167,17 @@ __host__ __device__ static inline int gacc_moment_offset(int C) { return ((C & 1
 __host__ __device__ static inline int gacc_row_floats(int C) { return (gacc_moment_offset(C) + 7 + 15) & ~15; }
 // One small frame alone (SplatLoc's color_refinement: 640x480, one view) is 4 800 quadrant-waves on a machine with room
 // for ~8 000: every wave starts at once and the compositing kernel lasts as long as its LONGEST list.  For such launches
-// (narrow layouts, all waves resident) the forward checkpoints every pixel's state (T, colours, depth) at the quarter
+// (narrow layouts, at most SPLIT_MAX_WAVES quadrant-waves: measured 233 -> 180 us at 4 800 waves, 201 -> 187 us at 12 900,
+// 810 -> 790 us at 24 000, and a LOSS at 64 500: 783 -> 871 us) the forward checkpoints every pixel's state (T, colours, depth) at the quarter
 // points of the tile's list and the backward runs SPLIT_PARTS waves per quadrant, one per quarter of the list: wave k > 0
 // starts from checkpoint k (T_k, S_k = S_total - C_k . g - D_k g_D).  The backward only needs the list up to the quadrant's
 // deepest contributor (63 % of it on average), so quarters balance better than halves.  The forward itself — T chain,
 // n_contrib, final_T, the images — is untouched, so every bit-exact contract holds.  Lists shorter than SPLIT_MIN_LIST
 // are not split.
-constexpr int SPLIT_MAX_WAVES = 8192;
+#ifndef SR_SPLIT_MAX_WAVES
+#define SR_SPLIT_MAX_WAVES 26000
+#endif
+constexpr int SPLIT_MAX_WAVES = SR_SPLIT_MAX_WAVES;
 constexpr int SPLIT_MIN_LIST = 256;
 constexpr int SPLIT_PARTS = 4;
 void set_split_max_waves(int waves);   // A/B hook (< 0: default)
