@@ -69,15 +69,25 @@
 // Timing probes only (WRONG results; tools/ablate.py): what would a kernel cost that reduced the geometric moments on the
 // matrix pipe instead of through the moment products + packed butterfly?
 //   SR_BWD_PROBE = 1: the per-pair butterfly + atomic dropped (their inputs stay live)
-//   SR_BWD_PROBE = 2: additionally the moment products dropped: E alone is parked in a second LDS panel
-//   SR_BWD_PROBE = 3: as 2, plus SR_BWD_PROBE_BLOCKS more 16-column MFMA blocks per flush fed from that panel
+//   (probes 2 and 3 of round 3 — E parked in a second 16-column panel, extra MFMA blocks fed from it — are recorded in
+//    profiles/r03_ab_probes.txt; the transposed moment reduction below replaced them)
 //   SR_BWD_PROBE = 4: the 4x4x1 MFMA dot products dropped (q = a cheap stand-in): is the matrix pipe a co-bottleneck?
 //   SR_BWD_PROBE = 5: the flush's 16x16x4 MFMAs dropped (atomics kept)
+//   SR_BWD_PROBE = 6 / 7: the set-up's plane loads dropped (all / the colour planes only)
 #ifndef SR_BWD_PROBE
 #define SR_BWD_PROBE 0
 #endif
-#ifndef SR_BWD_PROBE_BLOCKS
-#define SR_BWD_PROBE_BLOCKS 1
+#ifndef SR_BWD_TM
+#define SR_BWD_TM 1   // 1 = transposed moment reduction (small-layout panel variant): E = G dL/dalpha parked in an 8-column LDS panel, reduced by lane = (Gaussian, pixel column)
+#endif
+#ifndef SR_BWD_TM_WIDE
+#define SR_BWD_TM_WIDE 0  // 1 = also in the NC >= 32 kernels (A/B on S2: LOSES — the E panel's 2.4 KB and the registers cost a wave per SIMD)
+#endif
+#ifndef SR_BWD_NB3
+#define SR_BWD_NB3 0  // 1 = channels beyond the first 32 (and the depth weight) as a third 16-column block of the flush (A/B on S2: loses)
+#endif
+#ifndef SR_BWD_MINW_TM
+#define SR_BWD_MINW_TM 3  // waves per SIMD of the NC >= 32 kernel WITH the E panel (12.6 KB of LDS per wave: 12 workgroups per CU)
 #endif
 #ifndef SR_BWD_DOTM_MIN
 #define SR_BWD_DOTM_MIN 8  // channels from which the 4x4x1 MFMA dot product is used
@@ -111,13 +121,24 @@ struct BwdCfg {
     // (S1, 1200x680: 0.198 vs 0.238 ms), and below 4 channels the flush costs what it saves.
     static constexpr bool SMALLP = NC <= 15 && SP;
     static constexpr bool MFMA = NC >= 32 || SMALLP;
-    static constexpr int NM = NC >= 32 ? 32 : (SMALLP ? NC : 0);   // channels reduced on the matrix pipe
-    static constexpr int NB = NC >= 32 ? 2 : 1;                    // 16-column blocks of the contraction
-    static constexpr bool XD = SMALLP && AUX;                      // column NC of the block = the depth weight
+    // NC in (32, 47]: the channels beyond 32 and the depth weight are a THIRD 16-column block of the flush (16 more
+    // MFMAs per 16 Gaussians) instead of 4 of the 10 butterfly values per Gaussian
+    static constexpr bool B3 = SR_BWD_NB3 && NC > 32 && NC < 48;
+    static constexpr int NM = NC >= 32 ? (B3 ? NC : 32) : (SMALLP ? NC : 0);   // channels reduced on the matrix pipe
+    static constexpr int NB = NC >= 32 ? (B3 ? 3 : 2) : 1;         // 16-column blocks of the contraction
+    static constexpr bool XD = (SMALLP || B3) && AUX;              // column NC of the blocks = the depth weight
     static constexpr int NV = NC - NM;         // channels reduced with the packed butterfly
+    // TM (small-layout panel variant; measured on the reference layout, 5 views: 0.791 -> 0.762 ms): the six geometric
+    // moments leave the butterfly too.  E = G dL/dalpha is parked in an
+    // 8-column LDS panel [64 pix][8 Gaussians]; every 8 Gaussians lane (g = l & 7, i = l >> 3) sums its Gaussian over
+    // pixel column i (8 reads), forms the moments with ITS Gaussian's mean, and three swap stages fold the 8 columns:
+    // ~8 VALU per Gaussian instead of 6 moment products + 13 butterfly instructions.
+    static constexpr bool TM = SR_BWD_TM && (SMALLP || (SR_BWD_TM_WIDE && MFMA));
+    static constexpr int EG = 8;               // Gaussians per E-panel reduction
+    static constexpr int ES = 9;               // LDS row stride of the E panel [64 pix][EG]
     // AUX = false: no view of the launch has a depth / alpha gradient (color_refinement, train_gaussians.py:283-285):
     // the depth weight w g_D is identically zero and leaves the reduction
-    static constexpr int KV = NV + ((XD || !AUX) ? 6 : 7);   // butterfly values per Gaussian
+    static constexpr int KV = NV + ((XD || !AUX) ? 0 : 1) + (TM ? 0 : 6);   // butterfly values per Gaussian
     static constexpr int NCP = (NC + 3) & ~3;
     static constexpr int FS = SR_BWD_FS;             // feature rows staged per round
     static constexpr int GROUP = 16;           // Gaussians per MFMA flush (M of v_mfma_f32_16x16x4_f32)
@@ -139,8 +160,11 @@ __device__ __forceinline__ void acc_add(float* gacc, long long* gacc64, size_t i
         atomicAdd(gacc + idx, v);
 }
 
+template <int NC, bool SP, bool AUX>
+constexpr int bwd_min_waves() { return (BwdCfg<NC, SP, AUX>::TM && NC >= 32) ? SR_BWD_MINW_TM : SR_BWD_MINW; }
+
 template <int NC, bool DET, bool SP, bool AUX>
-__global__ void __launch_bounds__(WAVE, SR_BWD_MINW)
+__global__ void __launch_bounds__(WAVE, (bwd_min_waves<NC, SP, AUX>()))
 composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass, int tiles /*per view*/, int V,
                      int P /*rows per view*/,
                      const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -158,6 +182,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
     constexpr bool MFMA = Cfg::MFMA, XD = Cfg::XD;
     constexpr int NB = Cfg::NB;
+    constexpr bool TM = Cfg::TM;
+    constexpr int EG = Cfg::EG, ES = Cfg::ES;
     constexpr bool DOTM = NC >= SR_BWD_DOTM_MIN;  // dot products q = f . g on the matrix pipe
     constexpr int PPR = NCP / 4;  // 16-byte pieces per staged row
     static_assert(2 * KV <= WAVE, "at most 25 butterfly-reduced channels per pass");
@@ -168,10 +194,9 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
     __shared__ uint32_t s_cgid[FS];
     __shared__ float s_w[MFMA ? WAVE * WS : 1];   // matrix-pipe weight panel w[64 pix][GROUP]
-#if SR_BWD_PROBE >= 2
-    __shared__ float s_e[MFMA ? WAVE * WS : 1];   // probe: second panel (E values)
-#endif
     __shared__ uint32_t s_gid[MFMA ? GROUP : 1];  // Gaussian id of every parked panel column
+    __shared__ float s_e[TM ? WAVE * ES : 1];     // E panel [64 pix][EG]: column c belongs to weight-panel slot e0 + c
+    __shared__ float2 s_emean[TM ? GROUP : 1];    // projected mean of every parked Gaussian
 
 #ifdef SR_TRACE_WAVES
     struct TraceEnd {
@@ -234,8 +259,16 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
             const int c = c0 + ch;
+#if SR_BWD_PROBE == 6   // timing probe: no gradient / colour plane loads in the set-up
+            g[ch] = 1e-3f * (float)(c + 1) + 1e-5f * (float)lane;
+            S += 0.5f * g[ch];
+#elif SR_BWD_PROBE == 7   // timing probe: the gradient planes only (S_total without the colour planes)
+            g[ch] = c < gc ? dL_dcolor[(size_t)c * plane + pix] : (dL_dlast ? dL_dlast[pix] : 0.0f);
+            S += 0.5f * g[ch];
+#else
             g[ch] = c < gc ? dL_dcolor[(size_t)c * plane + pix] : (dL_dlast ? dL_dlast[pix] : 0.0f);
             S += out_color[(size_t)c * plane + pix] * g[ch];
+#endif
         }
         if (AUX && first_pass) {
             gD = dL_ddepth ? dL_ddepth[pix] : 0.0f;
@@ -293,9 +326,10 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     const int sv = slot_second ? slotv - KV : slotv;
     const bool slot_col = sv < NV;
     const bool slot_ok = slotv < 2 * KV;
-    const int slot_off = slot_col ? (c0 + NM + sv) : (MO + sv - NV);  // float offset inside the Gaussian's row
+    const int slot_off = slot_col ? (c0 + NM + sv) : (TM ? MO + 6 : MO + sv - NV);  // float offset inside the Gaussian's row
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
     int nslot = 0;  // Gaussians parked in the weight panel (wave-uniform)
+    int e0 = 0;     // weight-panel slot of the E panel's column 0 (wave-uniform)
 
     // dL/dfeature of the parked Gaussians: D[g][ch] = sum_pix W[pix][g] * G[pix][ch]
     // (v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
@@ -303,65 +337,87 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     auto flush_panel = [&](int count) {
         BP_T(tf0);
         __builtin_amdgcn_wave_barrier();
-        f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
-        const int row = (lane >> 4) * WS + (lane & 15);
-#if SR_BWD_PROBE >= 3
-        f32x4 DP[SR_BWD_PROBE_BLOCKS];
+        f32x4 D[NB];
 #pragma unroll
-        for (int q = 0; q < SR_BWD_PROBE_BLOCKS; ++q) DP[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float xl = (float)(lane >> 4), cj = (float)(lane & 15);
-#endif
+        for (int t = 0; t < NB; ++t) D[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int row = (lane >> 4) * WS + (lane & 15);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const float a = s_w[4 * kk * WS + row];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
 #if SR_BWD_PROBE == 5
-            D0[kk & 3] += a * gt[kk][0];
-            if (NB > 1) D1[kk & 3] += a * gt[kk][NB > 1 ? 1 : 0];
+                D[t][kk & 3] += a * gt[kk][t];
 #else
-            D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][0], D0, 0, 0, 0);
-            if (NB > 1) D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][NB > 1 ? 1 : 0], D1, 0, 0, 0);
+                D[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][t], D[t], 0, 0, 0);
 #endif
-#if SR_BWD_PROBE >= 3
-            const float ae = s_e[4 * kk * WS + row];
-            const float bp = fmaf(cj, xl + (float)(4 * (kk & 1)), (float)(kk >> 1));   // stands in for the 2-FMA polynomial operand
-#pragma unroll
-            for (int q = 0; q < SR_BWD_PROBE_BLOCKS; ++q) DP[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(q ? a : ae, bp, DP[q], 0, 0, 0);
-#endif
-        }
-#if SR_BWD_PROBE >= 3
-#pragma unroll
-        for (int q = 0; q < SR_BWD_PROBE_BLOCKS; ++q) {   // shift + atomics stand-in: ~5 VALU per register, one atomic per register
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = DP[q][r];
-                v = fmaf(v, xl, dpp_get<0x111, 0xf>(v));
-                v = fmaf(v, cj, dpp_get<0x112, 0xf>(v));
-                v = fmaf(v, xl, dpp_get<0x113, 0xf>(v));
-                const int gs = 4 * (lane >> 4) + r;
-                if (gs < count && (lane & 15) < 7) acc_add<DET>(gacc, gacc64, (size_t)(__umul24(s_gid[gs], (uint32_t)GROW) + (uint32_t)(32 + (lane & 15))), v);
             }
         }
-#endif
-        // one block: column j < NC is channel c0 + j, column NC the depth weight (moment slot 6, first pass only)
+        // column c = 16 t + (l & 15): channel c0 + c below NM, the depth weight (moment slot 6, first pass only) at NM
         const int j0c = lane & 15;
-        const bool col_ok = NB > 1 || j0c < NC || (XD && j0c == NC && first_pass);
-        const int col_off = (NB > 1 || j0c < NC) ? (c0 + j0c) : (MO + 6);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gs = 4 * (lane >> 4) + r;
             if (gs < count) {
-                const size_t di = (size_t)(__umul24(s_gid[gs], (uint32_t)GROW) + (uint32_t)col_off);
+                const uint32_t rowi = __umul24(s_gid[gs], (uint32_t)GROW);
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const int c = 16 * t + j0c;
+                    const bool full = 16 * t + 16 <= NM;   // every column of the block is a channel
+                    const bool col_ok = full || c < NM || (XD && c == NM && first_pass);
+                    const uint32_t col_off = (full || c < NM) ? (uint32_t)(c0 + c) : (uint32_t)(MO + 6);
 #if SR_BWD_ABLATE_ATOMIC
-                asm volatile("" ::"v"(di), "v"(D0[r]), "v"(D1[r]));
+                    asm volatile("" ::"v"(rowi + col_off), "v"(D[t][r]));
 #else
-                if (col_ok) acc_add<DET>(gacc, gacc64, di, D0[r]);
-                if (NB > 1) acc_add<DET>(gacc, gacc64, di + 16, D1[r]);
+                    if (col_ok) acc_add<DET>(gacc, gacc64, (size_t)(rowi + col_off), D[t][r]);
 #endif
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
         BP_T(tf1);
         BP_ADD(6, tf1 - tf0);
+    };
+
+    // Moments of the parked E columns.  Lane (g = l & 7, i = l >> 3) owns Gaussian column g and pixel column i of the
+    // quadrant: it reads E[pix = 8 j + i][g] for the 8 rows j, multiplies by ITS Gaussian's offsets d = mean - pixel
+    // (dx is constant in the lane), and the first three stages of the packed butterfly (lane bits 5, 4, 3 = the pixel
+    // column) fold the 8 columns: lane l ends with moment (l >> 5 & 1) + 2 (l >> 4 & 1) + 4 (l >> 3 & 1) of Gaussian g.
+    auto reduce_e = [&](int count) {
+        if constexpr (TM) {
+            BP_T(te0);
+            __builtin_amdgcn_wave_barrier();
+            const int eg = lane & 7, ei = lane >> 3;
+            const float2 mu = s_emean[min(e0 + eg, GROUP - 1)];
+            const float dx = mu.x - (float)(qx + ei);
+            const float dy0 = mu.y - (float)qy;
+            float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // sum E, sum E dy, sum E dy^2 (then the six moments)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float e = s_e[(8 * j + ei) * ES + eg];
+                const float dy = dy0 - (float)j;
+                const float ey = e * dy;
+                m[5] += e;
+                m[1] += ey;
+                m[4] = fmaf(ey, dy, m[4]);
+            }
+            m[0] = m[5] * dx;    // sum E dx
+            m[2] = m[0] * dx;    // sum E dx^2
+            m[3] = m[1] * dx;    // sum E dx dy
+            const float outv = wave_reduce_hi3<6>(m, lane);
+            const int vi = ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1);
+            if (eg < count && vi < 6) {
+                const size_t di = (size_t)(__umul24(s_gid[e0 + eg], (uint32_t)GROW) + (uint32_t)(MO + vi));
+#if SR_BWD_ABLATE_ATOMIC
+                asm volatile("" ::"v"(di), "v"(outv));
+#else
+                acc_add<DET>(gacc, gacc64, di, outv);
+#endif
+            }
+            __builtin_amdgcn_wave_barrier();
+            BP_T(te1);
+            BP_ADD(4, te1 - te0);
+        }
     };
 
     // chunk in flight: mask bit, id and record of list entry base + lane
@@ -495,86 +551,94 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 S = fmaf(-w1, qd1, S);
                 const float dA1 = hit1 ? fmaf(T, qd1, -S * __builtin_amdgcn_rcpf(1.0f - al1)) : 0.0f;
                 T = hit1 ? transmit(T, al1) : T;
-                float red[2 * KV];
-#pragma unroll
-                for (int ch = 0; ch < NV; ++ch) {
-                    red[ch] = w0 * g[NM + ch];
-                    red[KV + ch] = w1 * g[NM + ch];
-                }
-#if SR_BWD_PROBE >= 2
-                constexpr bool MOMENTS = !MFMA;
-                if (MFMA) {
-                    s_e[lane * WS + nslot] = G0 * dA0;
-                    s_e[lane * WS + nslot + 1] = G1 * dA1;
-                }
-#else
-                constexpr bool MOMENTS = true;
+                const float E0 = G0 * dA0, E1 = G1 * dA1;   // (0 for a miss)
+                const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];
+#ifdef SR_BWD_PROFILE
+                asm volatile("" ::"v"(E0), "v"(E1), "v"(w0), "v"(w1));
 #endif
-                // geometric partials as raw moments of E = G dL/dalpha over the pixel offset d;
-                // the per-Gaussian factors (conic, opacity, 0.5 W / 0.5 H) are applied once per
-                // Gaussian in preprocess_bwd instead of once per (pixel, Gaussian) here
-                if (MOMENTS) {
-                    const float E = G0 * dA0, Ex = E * dx0, Ey = E * dy0;
-                    red[NV + 0] = Ex;
-                    red[NV + 1] = Ey;
-                    red[NV + 2] = Ex * dx0;
-                    red[NV + 3] = Ex * dy0;
-                    red[NV + 4] = Ey * dy0;
-                    red[NV + 5] = E;
-                    if (!XD && AUX) red[NV + ((XD || !AUX) ? 5 : 6)] = w0 * gD;
-                }
-                if (MOMENTS) {
-                    const float E = G1 * dA1, Ex = E * dx1, Ey = E * dy1;
-                    red[KV + NV + 0] = Ex;
-                    red[KV + NV + 1] = Ey;
-                    red[KV + NV + 2] = Ex * dx1;
-                    red[KV + NV + 3] = Ex * dy1;
-                    red[KV + NV + 4] = Ey * dy1;
-                    red[KV + NV + 5] = E;
-                    if (!XD && AUX) red[KV + NV + ((XD || !AUX) ? 5 : 6)] = w1 * gD;
-                }
                 BP_T(tp2);
                 BP_ADD(3, tp2 - tp1);
-#if SR_BWD_PROBE >= 1
-                if (MFMA) {
-#if SR_BWD_PROBE == 1
+                if constexpr (KV > 0) {
+                    float red[2 * KV];
 #pragma unroll
-                    for (int k = 0; k < 2 * KV; ++k) asm volatile("" ::"v"(red[k]));
+                    for (int ch = 0; ch < NV; ++ch) {
+                        red[ch] = w0 * g[NM + ch];
+                        red[KV + ch] = w1 * g[NM + ch];
+                    }
+                    // geometric partials as raw moments of E = G dL/dalpha over the pixel offset d;
+                    // the per-Gaussian factors (conic, opacity, 0.5 W / 0.5 H) are applied once per
+                    // Gaussian in preprocess_bwd instead of once per (pixel, Gaussian) here
+                    if constexpr (!TM) {
+                        const float Ex0 = E0 * dx0, Ey0 = E0 * dy0, Ex1 = E1 * dx1, Ey1 = E1 * dy1;
+                        red[NV + 0] = Ex0;
+                        red[NV + 1] = Ey0;
+                        red[NV + 2] = Ex0 * dx0;
+                        red[NV + 3] = Ex0 * dy0;
+                        red[NV + 4] = Ey0 * dy0;
+                        red[NV + 5] = E0;
+                        red[KV + NV + 0] = Ex1;
+                        red[KV + NV + 1] = Ey1;
+                        red[KV + NV + 2] = Ex1 * dx1;
+                        red[KV + NV + 3] = Ex1 * dy1;
+                        red[KV + NV + 4] = Ey1 * dy1;
+                        red[KV + NV + 5] = E1;
+                    }
+                    if constexpr (!XD && AUX) {
+                        red[KV - 1] = w0 * gD;
+                        red[2 * KV - 1] = w1 * gD;
+                    }
+#if SR_BWD_PROBE == 1
+                    if (MFMA) {
+#pragma unroll
+                        for (int k = 0; k < 2 * KV; ++k) asm volatile("" ::"v"(red[k]));
+                    } else
 #endif
-                } else {
-#endif
-                const float outv = wave_reduce_pack<2 * KV>(red, lane);
+                    {
+                        const float outv = wave_reduce_pack<2 * KV>(red, lane);
 #ifdef SR_BWD_PROFILE
-                asm volatile("" ::"v"(outv));
+                        asm volatile("" ::"v"(outv));
 #endif
-                BP_T(tp3);
-                BP_ADD(4, tp3 - tp2);
-                const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];
-                const uint32_t gi = slot_second ? gi1 : gi0;
-                const size_t di = (size_t)(__umul24(gi, (uint32_t)GROW) + (uint32_t)slot_off);   // gi < 2^24 (checked on the host)
+                        BP_T(tp3);
+                        BP_ADD(4, tp3 - tp2);
+                        const uint32_t gi = slot_second ? gi1 : gi0;
+                        const size_t di = (size_t)(__umul24(gi, (uint32_t)GROW) + (uint32_t)slot_off);   // gi < 2^24 (checked on the host)
 #if SR_BWD_ABLATE_ATOMIC
-                asm volatile("" ::"v"(di), "v"(outv));
+                        asm volatile("" ::"v"(di), "v"(outv));
 #else
-                if (slot_ok && (has1 || !slot_second)) acc_add<DET>(gacc, gacc64, di, outv);
+                        if (slot_ok && (has1 || !slot_second)) acc_add<DET>(gacc, gacc64, di, outv);
 #endif
-#if SR_BWD_PROBE >= 1
+                    }
                 }
-                const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];
-#endif
-                if (MFMA) {
+                BP_T(tp4);
+                if constexpr (MFMA) {
                     // park the weights (0 for pixels that miss); a pair never straddles a flush
                     s_w[lane * WS + nslot] = w0;
                     s_w[lane * WS + nslot + 1] = w1;
+                    if constexpr (TM) {   // and E = G dL/dalpha in the 8-column panel (column = slot - e0)
+                        s_e[lane * ES + (nslot - e0)] = E0;
+                        s_e[lane * ES + (nslot - e0) + 1] = E1;
+                    }
                     if (lane == 0) {
                         s_gid[nslot] = gi0;
                         s_gid[nslot + 1] = gi1;
+                        if constexpr (TM) {
+                            s_emean[nslot] = make_float2(p0.x, p0.y);
+                            s_emean[nslot + 1] = make_float2(p1.x, p1.y);
+                        }
                     }
                     nslot += has1 ? 2 : 1;
-                    BP_T(tp4);
-                    BP_ADD(5, tp4 - tp3);
+                    BP_T(tp5);
+                    BP_ADD(5, tp5 - tp4);
+                    if constexpr (TM) {
+                        if (nslot - e0 >= EG - 1 || nslot >= GROUP - 1) {
+                            reduce_e(nslot - e0);
+                            e0 = nslot;
+                        }
+                    }
                     if (nslot >= GROUP - 1) {
                         flush_panel(nslot);
                         nslot = 0;
+                        e0 = 0;
                     }
                 }
             };
@@ -650,6 +714,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             }
         }
     }
+    if constexpr (TM) { if (nslot - e0 > 0) reduce_e(nslot - e0); }
     if (MFMA && nslot > 0) flush_panel(nslot);
 #ifdef SR_BWD_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

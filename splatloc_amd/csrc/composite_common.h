@@ -248,4 +248,34 @@ __device__ __forceinline__ float wave_reduce_pack(const float (&v)[K], int lane)
     return keep6 + dpp_get<0xB1, 0xf>(send6);  // quad_perm [1,0,3,2]
 }
 
+// The first three stages of wave_reduce_pack only: K <= 8 per-lane values are summed over lane bits 5, 4, 3 (lanes that
+// differ in bits 0..2 stay separate); lane l ends with the total of value (l >> 5 & 1) + 2 (l >> 4 & 1) + 4 (l >> 3 & 1).
+template <int K>
+__device__ __forceinline__ float wave_reduce_hi3(const float (&v)[K], int lane)
+{
+    static_assert(K >= 1 && K <= 8, "at most 8 values");
+    constexpr int N1 = (K + 1) / 2, N2 = (N1 + 1) / 2;
+    float a[N1];
+#pragma unroll
+    for (int m = 0; m < N1; ++m) {
+        const float x = v[2 * m];
+        const float y = (2 * m + 1 < K) ? v[2 * m + 1] : 0.0f;
+        const auto r = __builtin_amdgcn_permlane32_swap(as_u(x), as_u(y), false, false);
+        a[m] = as_f(r[0]) + as_f(r[1]);
+    }
+    float b[N2];
+#pragma unroll
+    for (int m = 0; m < N2; ++m) {
+        const float x = a[2 * m];
+        const float y = (2 * m + 1 < N1) ? a[2 * m + 1] : 0.0f;
+        const auto r = __builtin_amdgcn_permlane16_swap(as_u(x), as_u(y), false, false);
+        b[m] = as_f(r[0]) + as_f(r[1]);
+    }
+    const bool lo = (lane & 8) == 0;
+    const float x = b[0];
+    const float y = (N2 > 1) ? b[N2 > 1 ? 1 : 0] : 0.0f;
+    const float keep = lo ? x : y, send = lo ? y : x;
+    return keep + dpp_get<0x128, 0xf>(send);  // row_ror:8
+}
+
 }  // namespace sr
