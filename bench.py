@@ -698,7 +698,8 @@ def main():
     def window_step(record):
         # the whole window as ONE launch sequence: forward of the V views, ONE backward that sums their parameter
         # gradients in-kernel, then the per-view densification statistics (train_gaussians.py:238-245)
-        carriers = [torch.zeros_like(means3D, requires_grad=True) for _ in views]   # render(): screenspace_points per view
+        block = torch.zeros((len(views),) + tuple(means3D.shape), dtype=means3D.dtype, device=means3D.device)
+        carriers = [block[k].requires_grad_(True) for k in range(len(views))]       # render(): screenspace_points per view (one zero fill)
         outs = rasterize_window([rs for _, _, rs in views], means3D, carriers, colors, opac, scales=scales, rotations=rots)
         if record:
             for k in range(0, len(outs), 8):

@@ -245,7 +245,7 @@ typedef struct splatraster_geometry_layout {
     size_t rec0;          /* 32-byte records, stride 32: float4 at rec0 + 32 i = pixel x, pixel y, view depth, radius (float, 0 = culled) */
     size_t rec1;          /* = rec0 + 16: float4 at rec1 + 32 i = conic a, b, c, opacity */
     size_t tiles_touched; /* uint32[P] (original index order) */
-    size_t depth_order;   /* uint32[P]: Gaussian indices, stable-sorted by depth bits (culled last) */
+    size_t depth_order;   /* uint32[P]: Gaussian indices (bits 0..23; bits 24..31 = min(tiles_touched, 255)), stable-sorted by depth bits (culled last) */
     size_t offsets;       /* uint32[P]: inclusive scan of tiles_touched in depth_order */
     size_t rgb;           /* float[3P]: SH colours (only with shs) */
     size_t clamped;       /* uint8[3P]: SH clamp flags (only with shs) */

@@ -88,7 +88,7 @@ emit_kernel(int64_t R, int P /*rows: V * P*/, int Pv /*Gaussians per view*/, int
         nr = a;
     }
     for (int q = t; q < nr; q += EMIT_BLOCK) {
-        const uint32_t g = depth_order[r_lo + q];
+        const uint32_t g = depth_order[r_lo + q] & 0xFFFFFFu;
         const float4 p = rec[2 * g];
         const float rf = p.w;  // integer-valued radius stored by preprocess
         const int rminx = min(gx, max(0, f2i_sat_b((p.x - rf) / (float)TILE)));

@@ -367,6 +367,8 @@ static int window_geometry(const splatraster_settings* s, int32_t V, const splat
         if (s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1)) return SPLATRASTER_ERR_BAD_ARG;
     }
     if ((int64_t)P * V >= ((int64_t)1 << 31)) return SPLATRASTER_ERR_OVERFLOW;
+    st = check_row_index_range(P, V, s->channels);   // (the depth-order words keep the row in 24 bits)
+    if (st) return st;
     st = lookback_error_init();
     if (st) return st;
     const int32_t n = P * V;

@@ -88,7 +88,8 @@ struct GeomView {
     float4* rec;             // [2n] 32-byte records: rec[2g] = px, py, depth, radius (float; 0 = culled),
                              //                       rec[2g+1] = conic a, b, c, opacity
     uint32_t* tiles_touched; // [n] row order
-    uint32_t* depth_order;   // [n] rows sorted by depth (all views together; culled rows last)
+    uint32_t* depth_order;   // [n] rows sorted by depth (all views together; culled rows last): row in bits 0..23,
+                             //     min(tiles_touched[row], 255) in bits 24..31 (the scan then needs no gather)
     uint32_t* offsets;       // [n] inclusive scan of tiles_touched in depth order
     float* rgb;              // [3P]   (SH colours: single-view calls only)
     uint8_t* clamped;        // [3P]
@@ -143,7 +144,8 @@ size_t sort_tmp_bytes(int64_t n);
 size_t sort_zero_bytes(int64_t n, int key_bits);
 int sort_pairs_u32(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
                    int key_bits, void* tmp, hipStream_t stream, bool* result_in_alt, bool tmp_zeroed = false);
-// inclusive scan of in[perm[i]] (perm may be null) into out[i]; total (u64 as 2 words) optional
+// inclusive scan of in[perm[i] & 0xFFFFFF] (perm may be null; its words carry min(in[row], 255) in bits 24..31:
+// scan_sort.hip perm_value) into out[i]; total (u64 as 2 words) optional
 size_t scan_tmp_bytes(int64_t n);
 size_t scan_state_bytes(int64_t n);
 int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint32_t* out, uint32_t* total,

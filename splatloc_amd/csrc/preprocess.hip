@@ -208,7 +208,7 @@ preprocess_kernel(int P, int V, int W, int H, float scale_modifier, int sh_degre
             // input of the depth sort: view depth > 0.2 for every visible Gaussian, so its IEEE bits
             // order like the value; culled rows sort to the end
             sort_keys[g] = out_radius > 0 ? __float_as_uint(tz) : 0xFFFFFFFFu;
-            sort_vals[g] = (uint32_t)g;
+            sort_vals[g] = (uint32_t)g | (min(out_tiles, 255u) << 24);   // (rows < 2^24; the count rides along for the scan)
         }
         uint32_t t = out_tiles;
 #pragma unroll

@@ -246,14 +246,11 @@ def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier
         if _window_compatible(settings):
             scales, rotations, opacity, colors = shared
             xyz = pc._xyz
-            carriers = []
-            for _ in viewpoints:   # render(): screenspace_points, the per-view gradient carrier
-                sp = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-                try:
-                    sp.retain_grad()
-                except Exception:  # noqa: BLE001
-                    pass
-                carriers.append(sp)
+            # render(): screenspace_points, the per-view gradient carrier (zeros whose .grad the densification statistics
+            # read).  One zero fill for the window instead of the reference's `zeros_like(...) + 0` pair of kernels per view:
+            # each carrier is a leaf view of the block.
+            block = torch.zeros((len(viewpoints),) + tuple(xyz.shape), dtype=xyz.dtype, device=xyz.device)
+            carriers = [block[k].requires_grad_(True) for k in range(len(viewpoints))]
             # render = image[:3] and kp_prob = image[-1] leave the rasterizer as separate autograd outputs: their
             # gradients reach the backward kernel as separate planes, and an output the loss never touches costs nothing
             # (SplatLoc's layout [rgb | kp_score], C = 4; wider feature tables keep the one colour output and its slices)

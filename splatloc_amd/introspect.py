@@ -26,7 +26,7 @@ def geometry_views(geom: torch.Tensor, P: int) -> dict:
         rec0=_view(geom, L.rec0, 8 * P, torch.float32).view(P, 8)[:, :4],
         rec1=_view(geom, L.rec0, 8 * P, torch.float32).view(P, 8)[:, 4:],
         tiles_touched=_view(geom, L.tiles_touched, P, torch.int32),
-        depth_order=_view(geom, L.depth_order, P, torch.int32),
+        depth_order=_view(geom, L.depth_order, P, torch.int32) & 0xFFFFFF,   # (bits 24..31: min(tiles_touched, 255))
         offsets=_view(geom, L.offsets, P, torch.int32),
         rgb=_view(geom, L.rgb, 3 * P, torch.float32).view(P, 3),
         clamped=_view(geom, L.clamped, 3 * P, torch.uint8).view(P, 3),

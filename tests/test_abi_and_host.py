@@ -50,8 +50,12 @@ def test_host_only_entry_points():
     B = _native.BinningLayout()
     assert lib.splatraster_get_binning_layout(1000, 5000, 640, 480, 4, C.byref(B)) == 0
     assert B.total == lib.splatraster_binning_bytes(1000, 5000, 640, 480, 4)
+    # narrow layouts (C <= 4) of small frames hold the forward's list checkpoints for the split backward:
+    # 3 checkpoints x (C + 2) planes
+    b8 = lib.splatraster_binning_bytes(1000, 5000, 640, 480, 8)
+    assert B.total >= b8 - 1000 * 4 * 4 + 3 * (4 + 2) * 640 * 480 * 4 - 4096
     # C % 4 != 0 adds the 16-byte-aligned feature table
-    assert lib.splatraster_binning_bytes(1000, 5000, 640, 480, 35) >= B.total + 1000 * 36 * 4 - 256
+    assert lib.splatraster_binning_bytes(1000, 5000, 640, 480, 35) >= b8 + 1000 * (36 - 8) * 4 - 256
     assert lib.splatraster_get_geometry_layout(10, None) == 1           # BAD_ARG, no crash
     assert lib.splatknn_workspace_bytes(20_000) >= 20_000 * 12
     assert lib.splatraster_sort_tmp_bytes(1 << 20) > 8 * (1 << 20)
