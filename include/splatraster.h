@@ -470,7 +470,7 @@ int splatknn_debug_set_grid_min(int32_t n);
 #define SPLATRASTER_STAGE_SCAN 2           /* inclusive scan of tiles_touched */
 #define SPLATRASTER_STAGE_EMIT 3           /* emit_kernel */
 #define SPLATRASTER_STAGE_TILE_SORT 4      /* R-sized radix sort on tile id */
-#define SPLATRASTER_STAGE_RANGES 5         /* clearing the per-tile range table (boundaries: payload_kernel) */
+#define SPLATRASTER_STAGE_RANGES 5         /* clearing the per-tile range table when nothing was emitted; the launch order of small grids (tile_order_kernel) */
 #define SPLATRASTER_STAGE_COMPOSITE_FWD 6  /* composite_fwd_kernel */
 #define SPLATRASTER_STAGE_COMPOSITE_BWD 7  /* composite_bwd_kernel (the accumulator memset before it is not bracketed) */
 #define SPLATRASTER_STAGE_PREPROCESS_BWD 8 /* preprocess_bwd_kernel */

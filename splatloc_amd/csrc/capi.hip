@@ -153,7 +153,7 @@ GeomView geom_view(void* base, int32_t P, int32_t V)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, ckpt, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, ckpt, tile_order, bytes;
 };
 static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t H, int32_t C)
 {
@@ -180,6 +180,7 @@ static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t 
     // whenever the shape qualifies, whatever the run-time knob says
     const bool ck = C <= 4 && 4 * (size_t)tiles <= (size_t)SPLIT_MAX_WAVES;
     L.ckpt = take(ck ? nv * (size_t)(SPLIT_PARTS - 1) * (size_t)(C + 2) * (size_t)W * (size_t)H * sizeof(float) : 16);
+    L.tile_order = take(4 * (tiles > 0 ? tiles : 1));
     L.bytes = o;
     return L;
 }
@@ -200,6 +201,7 @@ BinView bin_view(void* base, int32_t P, int32_t V, int64_t R, int32_t W, int32_t
     v.featp = reinterpret_cast<float*>(b + L.featp);
     v.gacc = reinterpret_cast<float*>(b + L.gacc);
     v.ckpt = reinterpret_cast<float*>(b + L.ckpt);
+    v.tile_order = reinterpret_cast<uint32_t*>(b + L.tile_order);
     return v;
 }
 
@@ -477,6 +479,11 @@ static int window_render(const splatraster_settings* s, int32_t V, const splatra
             st = launch_pad_features(P, s->channels, feat, b.featp, stream);
             featp = b.featp;
         }
+    }
+    if (st) return st;
+    {   // launch order of the compositing grids (the range table is final here, also when nothing was emitted)
+        StageTimer t(SPLATRASTER_STAGE_RANGES, stream);
+        st = launch_tile_order(*s, V, b, stream);
     }
     if (st) return st;
     WinOut outs{};

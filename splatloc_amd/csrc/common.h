@@ -111,6 +111,7 @@ struct BinView {
     float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows); shared by the views
     float* gacc;          // [V * P * gacc_row_floats(C)] backward gradient accumulator rows (one per row)
     float* ckpt;          // [V][SPLIT_PARTS - 1][C + 2][H * W] list checkpoints of the forward (T, colours, depth), split launches only
+    uint32_t* tile_order; // [V * tiles] global tile ids, longest list first: the launch order of the compositing kernels
 };
 struct ImgView {
     float* final_T;       // [V][H * W]
@@ -194,6 +195,15 @@ __host__ __device__ static inline uint32_t split_part(uint32_t len)
 int launch_composite_fwd(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g, const BinView& b,
                          const ImgView& im, const float* featp /*padded rows, shared by the views*/, const float* bg,
                          const WinOut& out, hipStream_t stream);
+// launch order of the compositing grids: global tile ids by descending list length (binning.hip) — for launches of a few
+// rounds of waves only (a window of 640x480 frames: fwd 0.409 -> 0.397, bwd 0.758 -> 0.744 ms); on large grids the order costs
+// more L2 locality between neighbouring tiles than the shorter tail gains (S2: fwd 1.93 -> 1.97, bwd 4.24 -> 4.31 ms)
+#ifndef SR_TILE_ORDER
+#define SR_TILE_ORDER 1   // 0 = compositing grids always in tile order (A/B)
+#endif
+constexpr int TILE_ORDER_MAX_WAVES = 32768;
+static inline bool use_tile_order(int V, int tiles_per_view) { return SR_TILE_ORDER && 4ll * V * tiles_per_view <= TILE_ORDER_MAX_WAVES; }
+int launch_tile_order(const splatraster_settings& s, int32_t V, const BinView& b, hipStream_t stream);
 int launch_composite_bwd(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g,
                          const BinView& b, const ImgView& im, const float* feat, int feat_stride,
                          const WinGrad& grads,

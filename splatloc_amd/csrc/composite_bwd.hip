@@ -175,7 +175,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      float* __restrict__ gacc /*[V * P, GROW]*/, int GROW,
                      int MO, long long* __restrict__ gacc64 /*[V * P, GROW] fixed point, DET only*/,
                      const float* __restrict__ ckpt_all /*split launches (common.h; gridDim.y == SPLIT_PARTS): the forward's list
-                                                          checkpoints [V][SPLIT_PARTS - 1][NC + 2][H * W], else null*/)
+                                                          checkpoints [V][SPLIT_PARTS - 1][NC + 2][H * W], else null*/,
+                     const uint32_t* __restrict__ tile_order /*launch order (binning.hip), or null*/)
 {
     using Cfg = BwdCfg<NC, SP, AUX>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
@@ -213,7 +214,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #endif
     int gtile, quad;   // global tile = view * tiles + tile: the grid covers the V views of the window
     const int gx = (W + TILE - 1) / TILE;
-    quadrant_of_block(blockIdx.x, V * tiles, gx, gtile, quad);
+    quadrant_of_block(blockIdx.x, V * tiles, gx, gtile, quad, tile_order);
     if (gtile >= V * tiles) return;
     const int view = (V == 1) ? 0 : gtile / tiles;      // wave-uniform (scalar)
     const int tile = gtile - view * tiles;
@@ -765,7 +766,7 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
                        s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, L.V, L.P,      \
                        b.ranges, b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), *L.grads,       \
                        im.final_T, im.n_contrib, gacc, gacc_row_floats(s.channels),                                    \
-                       gacc_moment_offset(s.channels), gacc64, ckpt)
+                       gacc_moment_offset(s.channels), gacc64, ckpt, use_tile_order(L.V, tiles) ? b.tile_order : nullptr)
     if constexpr (NC >= 4 && NC <= 15 && AUX) {   // C = 3 and below: the flush costs what the 8 saved butterfly values gain (A/B: S0 0.036 vs 0.041 ms)
         // per VIEW: small frames (SplatLoc's 640x480) take the panel variant — also as a window of V views (A/B at the
         // reference layout, 5 views: 0.816 vs 0.869 ms); large frames the butterfly variant at full occupancy

@@ -132,11 +132,14 @@ __device__ __forceinline__ float transmit(float T, float alpha)
 // XCD and share its L2 for the tile's list; consecutive tiles are interleaved over the XCDs, which balances the
 // load and spreads the atomics of one Gaussian over time (mapping every XCD to its own contiguous band of tiles
 // was measured slower: forward 0.476 vs 0.419 ms, backward 0.982 vs 0.853 ms on S2).  Speed only, never correctness.
-__device__ __forceinline__ void quadrant_of_block(unsigned id, int tiles, int gx, int& tile, int& quad)
+// `order` (binning.hip tile_order_kernel; null = identity) turns the tile slot into the tile that runs there: longest lists first.
+__device__ __forceinline__ void quadrant_of_block(unsigned id, int tiles, int gx, int& tile, int& quad,
+                                                  const uint32_t* __restrict__ order = nullptr)
 {
-    (void)gx; (void)tiles;
+    (void)gx;
     tile = (int)((id >> 5) * 8u + (id & 7u));
     quad = (int)((id >> 3) & 3u);
+    if (order && tile < tiles) tile = (int)order[tile];
 }
 // blocks to launch so that every tile's four quadrants get an id
 __host__ __device__ static inline unsigned quadrant_blocks(int tiles, int gx)

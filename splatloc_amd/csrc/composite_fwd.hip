@@ -101,7 +101,8 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                      const uint8_t* __restrict__ imask, const float4* __restrict__ featp4,
                      const float* __restrict__ bg, WinOut outs,
                      float* __restrict__ final_T_all, uint32_t* __restrict__ n_contrib_all,
-                     float* __restrict__ ckpt_all /*split launches (common.h): [V][SPLIT_PARTS - 1][NC + 2][H * W] list checkpoints, else null*/)
+                     float* __restrict__ ckpt_all /*split launches (common.h): [V][SPLIT_PARTS - 1][NC + 2][H * W] list checkpoints, else null*/,
+                     const uint32_t* __restrict__ tile_order /*launch order (binning.hip), or null*/)
 {
     using Cfg = FwdCfg<NC>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, FS = Cfg::FS;
@@ -127,7 +128,7 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
 #endif
     int gtile, quad;   // global tile = view * tiles + tile: the grid covers the V views of the window
     const int gx = (W + TILE - 1) / TILE;
-    quadrant_of_block(blockIdx.x, V * tiles, gx, gtile, quad);
+    quadrant_of_block(blockIdx.x, V * tiles, gx, gtile, quad, tile_order);
     if (gtile >= V * tiles) return;
     const int view = (V == 1) ? 0 : gtile / tiles;      // wave-uniform (scalar)
     const int tile = gtile - view * tiles;
@@ -353,7 +354,7 @@ static int launch_one(const splatraster_settings& s, int c0, int write_aux, cons
     hipLaunchKernelGGL(composite_fwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
                        s.image_height, padded_channels(feat_stride) / 4, c0, s.bg_channels, write_aux, tiles, L.V, L.P, b.ranges,
                        b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(featp), bg, *L.outs, im.final_T,
-                       im.n_contrib, (NC <= 4 && c0 == 0 && write_aux) ? L.ckpt : nullptr);
+                       im.n_contrib, (NC <= 4 && c0 == 0 && write_aux) ? L.ckpt : nullptr, use_tile_order(L.V, tiles) ? b.tile_order : nullptr);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
