@@ -37,6 +37,19 @@ def test_screen_filling_gaussians():
     assert (f["tiles_touched"][f["radii"] > 0] == tiles).mean() > 0.5
 
 
+def test_gaussians_over_more_than_255_tiles():
+    """The depth-order words carry min(tiles_touched, 255) for the offsets scan; a Gaussian over >= 255 tiles takes the
+    look-up path (scan_sort.hip perm_value).  Mixed with small ones so that both paths meet in one scan."""
+    big = make_scene(60, 320, 240, 3, seed=43, scale_median=2.5)
+    small = make_scene(400, 320, 240, 3, seed=44, scale_median=0.05)
+    sc = big
+    for name in ("means3D", "features", "opacities", "scales", "rotations"):
+        setattr(sc, name, torch.cat([getattr(big, name), getattr(small, name)], 0))
+    run, f = _run_and_check(sc)
+    tt = f["tiles_touched"]
+    assert (tt >= 255).sum() >= 10 and ((tt > 0) & (tt < 255)).sum() >= 50
+
+
 def test_exact_depth_ties_keep_index_order():
     """Identical depths: the (tile, depth, index) order must fall back to the Gaussian index."""
     sc = make_scene(600, 128, 96, 3, seed=42, scale_median=0.06)
