@@ -170,8 +170,8 @@ __device__ __forceinline__ float dpp_get(float v)
 // readlane/select gather per value.
 //   stage 1 (lane bit 5): v_permlane32_swap + add      (2 instr per pair)
 //   stage 2 (lane bit 4): v_permlane16_swap + add      (2 instr per pair)
-//   stage 3 (lane bit 3): select / select / add row_ror:8
-//   stage 4 (lane bit 2): select / select / two bank-masked row_ror movs / add
+//   stage 3 (lane bit 3): two bank-masked v_add_f32_dpp row_ror:8       (fold_lane_bit3)
+//   stage 4 (lane bit 2): two bank-masked v_add_f32_dpp row_ror:12 / 4   (fold_lane_bit2)
 //   stage 5 (lane bit 1): select / select / add quad_perm[2,3,0,1]
 //   stage 6 (lane bit 0): select / select / add quad_perm[1,0,3,2]
 __device__ __forceinline__ float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
@@ -183,6 +183,47 @@ __device__ __forceinline__ float dpp_mov_old(float old, float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
                                                                  __builtin_bit_cast(int, v), CTRL, 0xf,
                                                                  BANK_MASK, false));
+}
+
+// One stage of the packed butterfly on lane bit 3 / bit 2: lanes with the bit clear end with x + x[partner], lanes with it
+// set with y + y[partner] (partner = lane ^ 8 / lane ^ 4).  Both bits are constant inside a DPP bank (4 lanes), so each half is
+// ONE bank-masked v_add_f32_dpp on the untouched inputs — 2 instructions per output instead of select / select / (moves) / add
+// (3 for bit 3, 6 for bit 2).  s_nop 1 = the two wait states a DPP read of a just-written VGPR needs (the compiler cannot see
+// into the asm).
+#ifndef SR_BUTTERFLY_ASM
+#define SR_BUTTERFLY_ASM 1   // 0 = the select / move formulation through compiler builtins (A/B)
+#endif
+__device__ __forceinline__ float fold_lane_bit3(float x, float y)
+{
+#if !SR_BUTTERFLY_ASM
+    const bool lo = (__lane_id() & 8) == 0;
+    const float keep = lo ? x : y, send = lo ? y : x;
+    return keep + dpp_get<0x128, 0xf>(send);
+#endif
+    float d;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(d)
+        : "v"(x), "v"(y));
+    return d;
+}
+__device__ __forceinline__ float fold_lane_bit2(float x, float y)
+{
+#if !SR_BUTTERFLY_ASM
+    const bool lo = (__lane_id() & 4) == 0;
+    const float keep = lo ? x : y, send = lo ? y : x;
+    float t = dpp_mov_old<0x12C, 0x5>(0.0f, send);
+    t = dpp_mov_old<0x124, 0xA>(t, send);
+    return keep + t;
+#endif
+    float d;   // banks 0, 2 (bit clear) read lane + 4 = row_ror:12; banks 1, 3 read lane - 4 = row_ror:4
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa"
+        : "=&v"(d)
+        : "v"(x), "v"(y));
+    return d;
 }
 
 template <int K>
@@ -209,30 +250,12 @@ __device__ __forceinline__ float wave_reduce_pack(const float (&v)[K], int lane)
         b[m] = as_f(r[0]) + as_f(r[1]);
     }
     float c[N3];
-    {
-        const bool lo = (lane & 8) == 0;
 #pragma unroll
-        for (int m = 0; m < N3; ++m) {
-            const float x = b[2 * m];
-            const float y = (2 * m + 1 < N2) ? b[2 * m + 1] : 0.0f;
-            const float keep = lo ? x : y, send = lo ? y : x;
-            c[m] = keep + dpp_get<0x128, 0xf>(send);  // row_ror:8
-        }
-    }
+    for (int m = 0; m < N3; ++m) c[m] = fold_lane_bit3(b[2 * m], (2 * m + 1 < N2) ? b[2 * m + 1] : 0.0f);
     float d[N4];
-    {
-        const bool lo = (lane & 4) == 0;
 #pragma unroll
-        for (int m = 0; m < N4; ++m) {
-            const float x = c[2 * m];
-            const float y = (2 * m + 1 < N3) ? c[2 * m + 1] : 0.0f;
-            const float keep = lo ? x : y, send = lo ? y : x;
-            // partner = lane ^ 4: banks 0,2 read lane+4 (row_ror:12), banks 1,3 read lane-4 (row_ror:4)
-            float t = dpp_mov_old<0x12C, 0x5>(0.0f, send);
-            t = dpp_mov_old<0x124, 0xA>(t, send);
-            d[m] = keep + t;
-        }
-    }
+    for (int m = 0; m < N4; ++m) d[m] = fold_lane_bit2(c[2 * m], (2 * m + 1 < N3) ? c[2 * m + 1] : 0.0f);
+    (void)lane;
     float e[N5];
     {
         const bool lo = (lane & 2) == 0;
@@ -274,11 +297,8 @@ __device__ __forceinline__ float wave_reduce_hi3(const float (&v)[K], int lane)
         const auto r = __builtin_amdgcn_permlane16_swap(as_u(x), as_u(y), false, false);
         b[m] = as_f(r[0]) + as_f(r[1]);
     }
-    const bool lo = (lane & 8) == 0;
-    const float x = b[0];
-    const float y = (N2 > 1) ? b[N2 > 1 ? 1 : 0] : 0.0f;
-    const float keep = lo ? x : y, send = lo ? y : x;
-    return keep + dpp_get<0x128, 0xf>(send);  // row_ror:8
+    (void)lane;
+    return fold_lane_bit3(b[0], (N2 > 1) ? b[N2 > 1 ? 1 : 0] : 0.0f);
 }
 
 }  // namespace sr
