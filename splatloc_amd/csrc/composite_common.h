@@ -251,27 +251,38 @@ __device__ __forceinline__ float wave_reduce_pack(const float (&v)[K], int lane)
     }
     float c[N3];
 #pragma unroll
-    for (int m = 0; m < N3; ++m) c[m] = fold_lane_bit3(b[2 * m], (2 * m + 1 < N2) ? b[2 * m + 1] : 0.0f);
+    // A stage's last register may have no partner value (odd count): the lanes that would hold it then belong to value
+    // indices >= K, which no caller consumes (and which never feed a lane of an existing index: later stages pair lanes
+    // that agree in all higher bits) — there x + x[partner] in every lane is one instruction.
+    for (int m = 0; m < N3; ++m)
+        c[m] = (2 * m + 1 < N2) ? fold_lane_bit3(b[2 * m], b[2 * m + 1 < N2 ? 2 * m + 1 : 0]) : b[2 * m] + dpp_get<0x128, 0xf>(b[2 * m]);
     float d[N4];
 #pragma unroll
-    for (int m = 0; m < N4; ++m) d[m] = fold_lane_bit2(c[2 * m], (2 * m + 1 < N3) ? c[2 * m + 1] : 0.0f);
-    (void)lane;
+    for (int m = 0; m < N4; ++m)
+        d[m] = (2 * m + 1 < N3) ? fold_lane_bit2(c[2 * m], c[2 * m + 1 < N3 ? 2 * m + 1 : 0]) : fold_lane_bit2(c[2 * m], c[2 * m]);
     float e[N5];
     {
         const bool lo = (lane & 2) == 0;
 #pragma unroll
         for (int m = 0; m < N5; ++m) {
             const float x = d[2 * m];
-            const float y = (2 * m + 1 < N4) ? d[2 * m + 1] : 0.0f;
-            const float keep = lo ? x : y, send = lo ? y : x;
-            e[m] = keep + dpp_get<0x4E, 0xf>(send);  // quad_perm [2,3,0,1]
+            if (2 * m + 1 < N4) {
+                const float y = d[2 * m + 1 < N4 ? 2 * m + 1 : 0];
+                const float keep = lo ? x : y, send = lo ? y : x;
+                e[m] = keep + dpp_get<0x4E, 0xf>(send);  // quad_perm [2,3,0,1]
+            } else {
+                e[m] = x + dpp_get<0x4E, 0xf>(x);
+            }
         }
     }
-    const bool lo1 = (lane & 1) == 0;
     const float x6 = e[0];
-    const float y6 = (N5 > 1) ? e[N5 > 1 ? 1 : 0] : 0.0f;
-    const float keep6 = lo1 ? x6 : y6, send6 = lo1 ? y6 : x6;
-    return keep6 + dpp_get<0xB1, 0xf>(send6);  // quad_perm [1,0,3,2]
+    if (N5 > 1) {
+        const bool lo1 = (lane & 1) == 0;
+        const float y6 = e[N5 > 1 ? 1 : 0];
+        const float keep6 = lo1 ? x6 : y6, send6 = lo1 ? y6 : x6;
+        return keep6 + dpp_get<0xB1, 0xf>(send6);  // quad_perm [1,0,3,2]
+    }
+    return x6 + dpp_get<0xB1, 0xf>(x6);
 }
 
 // The first three stages of wave_reduce_pack only: K <= 8 per-lane values are summed over lane bits 5, 4, 3 (lanes that
@@ -298,7 +309,8 @@ __device__ __forceinline__ float wave_reduce_hi3(const float (&v)[K], int lane)
         b[m] = as_f(r[0]) + as_f(r[1]);
     }
     (void)lane;
-    return fold_lane_bit3(b[0], (N2 > 1) ? b[N2 > 1 ? 1 : 0] : 0.0f);
+    if (N2 > 1) return fold_lane_bit3(b[0], b[N2 > 1 ? 1 : 0]);
+    return b[0] + dpp_get<0x128, 0xf>(b[0]);
 }
 
 }  // namespace sr
