@@ -190,10 +190,12 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     static_assert(2 * KV <= WAVE, "at most 25 butterfly-reduced channels per pass");
     // records of the staged candidates only (row-indexed, like s_feat): with the 64-entry chunk
     // records here the workgroup needs 11.2 KB and only 14 fit a CU; at 10 KB all 16 (4 / SIMD) do
-    __shared__ __attribute__((aligned(16))) float4 s_rec0[FS];
-    __shared__ __attribute__((aligned(16))) float4 s_rec1[FS];
+    // (+ 1: the second Gaussian of a pair is ALWAYS read from row r0 + 1 — adjacent rows share one address register —
+    //  also when the round's last pair has no second member: that row is then stale, and the pair's second half is masked)
+    __shared__ __attribute__((aligned(16))) float4 s_rec0[FS + 1];
+    __shared__ __attribute__((aligned(16))) float4 s_rec1[FS + 1];
     __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
-    __shared__ uint32_t s_cgid[FS];
+    __shared__ uint32_t s_cgid[FS + 1];
     __shared__ float s_w[MFMA ? WAVE * WS : 1];   // matrix-pipe weight panel w[64 pix][GROUP]
     __shared__ uint32_t s_gid[MFMA ? GROUP : 1];  // Gaussian id of every parked panel column
     __shared__ float s_e[TM ? WAVE * ES : 1];     // E panel [64 pix][EG]: column c belongs to weight-panel slot e0 + c
@@ -710,8 +712,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 }
                 BP_T(td1);
                 BP_ADD(7, td1 - td0);
-                process_pair(j0, j1, has1, slot, has1 ? slot + 1 : slot, qm[0], qm[1]);
-                if (has2) process_pair(j2, j3, has3, slot + 2, has3 ? slot + 3 : slot + 2, qm[2], qm[3]);
+                process_pair(j0, j1, has1, slot, slot + 1, qm[0], qm[1]);
+                if (has2) process_pair(j2, j3, has3, slot + 2, slot + 3, qm[2], qm[3]);
             }
         }
     }
