@@ -194,7 +194,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     //  also when the round's last pair has no second member: that row is then stale, and the pair's second half is masked)
     __shared__ __attribute__((aligned(16))) float4 s_rec0[FS + 1];
     __shared__ __attribute__((aligned(16))) float4 s_rec1[FS + 1];
-    __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
+    __shared__ __attribute__((aligned(16))) float s_feat[(FS + (DOTM ? 0 : 1)) * NCP];   // (the MFMA dot product clamps its rows)
     __shared__ uint32_t s_cgid[FS + 1];
     __shared__ float s_w[MFMA ? WAVE * WS : 1];   // matrix-pipe weight panel w[64 pix][GROUP]
     __shared__ uint32_t s_gid[MFMA ? GROUP : 1];  // Gaussian id of every parked panel column
@@ -540,6 +540,9 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                         qd0 += f0[ch] * g[ch];
                         qd1 += f1[ch] * g[ch];
                     }
+                    // a round's last pair may have no second member: row r0 + 1 is then stale (or never written: any bit
+                    // pattern), and S = fma(-0, NaN, S) would poison the chain — everything else of that half is masked
+                    qd1 = has1 ? qd1 : 0.0f;
                 }
                 // ---- Gaussian 0, then Gaussian 1 (sequential in T and S) ----
                 // Branch-free: a miss has w = 0 (S unchanged), dA = 0 and keeps T.  1 / (1 - alpha) is the
