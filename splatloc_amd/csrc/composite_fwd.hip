@@ -270,8 +270,14 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 const float* f0 = &s_feat[slot * NCP + NM];
                 const float* f1 = &s_feat[s1 * NCP + NM];
 #pragma unroll
-                for (int ch = 0; ch < NV; ++ch) acc[ch] += f0[ch] * w0 + f1[ch] * w1;
-                D += p0.z * w0 + p1.z * w1;
+                for (int ch = 0; ch < NV; ++ch) {
+                    // narrow layouts: two FMAs in list order (forward -2.7 % at C = 3 / 4); beside the MFMA accumulation of
+                    // C = 35 the pair-sum form (mul + fma + add) measured FASTER (1.90 vs 1.99 ms per window)
+                    if (MFMA) acc[ch] += f0[ch] * w0 + f1[ch] * w1;
+                    else acc[ch] = fmaf(f1[ch], w1, fmaf(f0[ch], w0, acc[ch]));
+                }
+                if (MFMA) D += p0.z * w0 + p1.z * w1;
+                else D = fmaf(p1.z, w1, fmaf(p0.z, w0, D));
                 if (MFMA) {
                     const float a = s_feat[((lane >> 5) ? s1 : slot) * NCP + (lane & 31)];  // A[i = ch][k = g]
                     float b0 = w0, b1 = w1;
