@@ -146,6 +146,10 @@ int launch_ranges_clear(int32_t tiles, uint32_t* ranges, hipStream_t stream)
 // loads instead of chasing id -> record through 16-byte gathers scattered over HBM:
 //   irec[2j] = (pixel x, y, depth, radius) of point_list[j], irec[2j+1] = its conic pre-scaled for
 //   the compositing kernels (payload_conic) and opacity;  imask[j] = reach bits.
+#ifndef SR_PAYLOAD_NT_MIN
+#define SR_PAYLOAD_NT_MIN (8ll << 20)   // instances from which the payload is written with streaming stores (33 B each: 264 MB)
+#endif
+template <bool NT>
 __global__ void __launch_bounds__(256)
 payload_kernel(int64_t R, int gx, int tiles_per_view, int V, const uint32_t* __restrict__ point_list,
                const uint32_t* __restrict__ tile_list, const float4* __restrict__ rec,
@@ -159,9 +163,23 @@ payload_kernel(int64_t R, int gx, int tiles_per_view, int V, const uint32_t* __r
 #pragma unroll 1
     for (int v = 1; v < V && tl >= (uint32_t)tiles_per_view; ++v) tl -= (uint32_t)tiles_per_view;
     const uint32_t ty = tl / (uint32_t)gx, tx = tl - ty * (uint32_t)gx;
-    irec[2 * j] = a0;
-    irec[2 * j + 1] = payload_conic(a1);   // pre-scaled for gauss_log2 (composite_common.h)
-    imask[j] = (uint8_t)quadrant_reach_mask(a0, a1, (float)(tx * TILE), (float)(ty * TILE));
+    const float4 c1 = payload_conic(a1);   // pre-scaled for gauss_log2 (composite_common.h)
+    const uint8_t m = (uint8_t)quadrant_reach_mask(a0, a1, (float)(tx * TILE), (float)(ty * TILE));
+    if (NT) {
+        // Streaming stores for lists larger than the memory-side cache (S2 window: 20 M instances, 657 MB): what is written
+        // here is next read after the whole list has gone by, and must not push the 32-byte records this kernel gathers
+        // out of the caches (S2: 0.436 -> 0.377 ms).  Smaller lists (a window of 640x480 frames: 6 M instances) are read
+        // back FROM the caches by the compositing kernels: there plain stores win (0.122 vs 0.142 ms).
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        f32x4_t* out = reinterpret_cast<f32x4_t*>(irec) + 2 * j;
+        __builtin_nontemporal_store((f32x4_t){a0.x, a0.y, a0.z, a0.w}, out);
+        __builtin_nontemporal_store((f32x4_t){c1.x, c1.y, c1.z, c1.w}, out + 1);
+        __builtin_nontemporal_store(m, imask + j);
+    } else {
+        irec[2 * j] = a0;
+        irec[2 * j + 1] = c1;
+        imask[j] = m;
+    }
     // per-tile [start, end) of the sorted list (the table was zeroed for the empty tiles)
     if (j == 0 || tile_list[j - 1] != t) ranges[2 * t] = (uint32_t)j;
     if (j == R - 1 || tile_list[j + 1] != t) ranges[2 * t + 1] = (uint32_t)(j + 1);
@@ -171,8 +189,12 @@ int launch_payload(const splatraster_settings& s, int32_t V, int64_t R, const Ge
 {
     if (R == 0) return SPLATRASTER_OK;
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
-    hipLaunchKernelGGL(payload_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, gx * gy, V, b.point_list,
-                       b.tile_list, g.rec, b.irec, b.imask, b.ranges);
+    if (R >= SR_PAYLOAD_NT_MIN)
+        hipLaunchKernelGGL(payload_kernel<true>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, gx * gy, V,
+                           b.point_list, b.tile_list, g.rec, b.irec, b.imask, b.ranges);
+    else
+        hipLaunchKernelGGL(payload_kernel<false>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, gx * gy, V,
+                           b.point_list, b.tile_list, g.rec, b.irec, b.imask, b.ranges);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
