@@ -507,9 +507,12 @@ int splatraster_debug_set_deterministic(int on);
  * variant; < 0 restores the built-in default. */
 int splatraster_debug_set_small_panel_max_waves(int waves);
 /* A/B hook: narrow-layout launches (C <= 4) with at most this many quadrant-waves split every list of >= 256 entries in
- * two for the backward (the forward checkpoints every pixel's state at the middle of its tile's list).
+ * four for the backward (the forward checkpoints every pixel's state at the quarter points of its tile's list).
  * 0 = never, < 0 or > 26000 = the built-in default 26000.  Must not change between a forward and its backward. */
 int splatraster_debug_set_split_max_waves(int waves);
+/* A/B / test hook: instance count from which the per-instance payload is written with streaming (non-temporal) stores
+ * (DESIGN.md §11); < 0 restores the built-in default (8 Mi instances), 0 = always.  Results never depend on it. */
+int splatraster_debug_set_payload_stream_min(int64_t instances);
 int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
 
 const char* splatraster_error_string(int status);

@@ -99,6 +99,7 @@ SYMBOLS = {
     "splatraster_get_window_image_layout": (C.c_int, [_i32, _i32, _i32, C.POINTER(ImageLayout)]),
     "splatraster_debug_set_small_panel_max_waves": (C.c_int, [C.c_int]),
     "splatraster_debug_set_split_max_waves": (C.c_int, [C.c_int]),
+    "splatraster_debug_set_payload_stream_min": (C.c_int, [C.c_int64]),
     "splatraster_mark_visible": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_get_geometry_layout": (C.c_int, [_i32, C.POINTER(GeometryLayout)]),
     "splatraster_get_binning_layout": (C.c_int, [_i32, _i64, _i32, _i32, _i32, C.POINTER(BinningLayout)]),

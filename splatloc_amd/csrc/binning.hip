@@ -149,6 +149,9 @@ int launch_ranges_clear(int32_t tiles, uint32_t* ranges, hipStream_t stream)
 #ifndef SR_PAYLOAD_NT_MIN
 #define SR_PAYLOAD_NT_MIN (8ll << 20)   // instances from which the payload is written with streaming stores (33 B each: 264 MB)
 #endif
+static int64_t g_payload_stream_min = SR_PAYLOAD_NT_MIN;
+void set_payload_stream_min(int64_t instances) { g_payload_stream_min = instances < 0 ? (int64_t)SR_PAYLOAD_NT_MIN : instances; }
+
 template <bool NT>
 __global__ void __launch_bounds__(256)
 payload_kernel(int64_t R, int gx, int tiles_per_view, int V, const uint32_t* __restrict__ point_list,
@@ -189,7 +192,7 @@ int launch_payload(const splatraster_settings& s, int32_t V, int64_t R, const Ge
 {
     if (R == 0) return SPLATRASTER_OK;
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
-    if (R >= SR_PAYLOAD_NT_MIN)
+    if (R >= g_payload_stream_min)
         hipLaunchKernelGGL(payload_kernel<true>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, gx * gy, V,
                            b.point_list, b.tile_list, g.rec, b.irec, b.imask, b.ranges);
     else

@@ -684,6 +684,12 @@ int splatraster_debug_set_small_panel_max_waves(int waves)
     return SPLATRASTER_OK;
 }
 
+int splatraster_debug_set_payload_stream_min(int64_t instances)
+{
+    sr::set_payload_stream_min(instances);
+    return SPLATRASTER_OK;
+}
+
 int splatraster_debug_set_split_max_waves(int waves)
 {
     set_split_max_waves(waves);

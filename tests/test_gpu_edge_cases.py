@@ -261,3 +261,26 @@ def test_split_backward_matches_unsplit(C, aux):
     bo = oracle_backward(f, sc, use_depth=aux, use_alpha=aux)
     assert_grad_close("dL_dmeans3D vs oracle", b.np(b.means3D.grad), bo["dL_dmeans3D"])
     assert_grad_close("dL_dcolors vs oracle", b.np(b.colors.grad), bo["dL_dcolors"])
+
+
+def test_streaming_payload_stores_change_nothing():
+    """Lists of >= 8 Mi instances write the per-instance payload with non-temporal stores (binning.hip); the hook forces that
+    path on a small scene: same payload, images and (deterministic-sum mode) gradients, bit for bit."""
+    from splatloc_amd import _native
+    lib = _native.load()
+    sc = make_scene(3000, 200, 120, 35, seed=77, scale_median=0.12)
+    _native.set_deterministic(True)
+    try:
+        lib.splatraster_debug_set_payload_stream_min(0)
+        a = HipRun(sc)
+        lib.splatraster_debug_set_payload_stream_min(-1)
+        b = HipRun(sc)
+    finally:
+        lib.splatraster_debug_set_payload_stream_min(-1)
+        _native.set_deterministic(False)
+    for k in ("irec", "imask", "ranges", "n_contrib", "final_T"):
+        if k in a.state:
+            assert torch.equal(a.state[k], b.state[k]), k
+    assert torch.equal(a.color, b.color) and torch.equal(a.depth, b.depth) and torch.equal(a.alpha, b.alpha)
+    for n in ("means3D", "means2D", "opacities", "colors", "scales", "rotations"):
+        assert torch.equal(getattr(a, n).grad, getattr(b, n).grad), n
