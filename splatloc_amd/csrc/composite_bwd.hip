@@ -518,10 +518,14 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 const float4 p1 = s_rec0[r1], q1 = s_rec1[r1];
                 const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
                 const float pw0 = gauss_log2(q0, dx0, dy0), pw1 = gauss_log2(q1, dx1, dy1);  // log2 of the weight
-                const float G0 = exp2_shared(pw0), G1 = exp2_shared(pw1);
-                const float al0 = fminf(ALPHA_MAX, q0.w * G0), al1 = fminf(ALPHA_MAX, q1.w * G1);
-                const bool hit0 = (idx0 + (uint32_t)j0 < last) && pw0 <= 0.0f && al0 >= ALPHA_MIN;
-                const bool hit1 = has1 && (idx0 + (uint32_t)j1 < last) && pw1 <= 0.0f && al1 >= ALPHA_MIN;
+                // (alpha is tested before the min with 0.99: same decision as the forward's, and a NaN from an overflowed power
+                //  is a miss — exp2_core; for the same reason a miss zeroes G below, not dL/dalpha)
+                const float Gr0 = exp2_core(pw0), Gr1 = exp2_core(pw1);
+                const float ar0 = q0.w * Gr0, ar1 = q1.w * Gr1;
+                const float al0 = fminf(ALPHA_MAX, ar0), al1 = fminf(ALPHA_MAX, ar1);
+                const bool hit0 = (idx0 + (uint32_t)j0 < last) && pw0 <= 0.0f && ar0 >= ALPHA_MIN;
+                const bool hit1 = has1 && (idx0 + (uint32_t)j1 < last) && pw1 <= 0.0f && ar1 >= ALPHA_MIN;
+                const float G0 = hit0 ? Gr0 : 0.0f, G1 = hit1 ? Gr1 : 0.0f;
 #if SR_BWD_SKIP_BRANCH
                 if (__builtin_amdgcn_ballot_w64(hit0 || hit1) == 0) return;
 #endif
@@ -551,11 +555,11 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 // the forward's two-rounding transmit() bit for bit.
                 const float w0 = hit0 ? al0 * T : 0.0f;
                 S = fmaf(-w0, qd0, S);
-                const float dA0 = hit0 ? fmaf(T, qd0, -S * __builtin_amdgcn_rcpf(1.0f - al0)) : 0.0f;
+                const float dA0 = fmaf(T, qd0, -S * __builtin_amdgcn_rcpf(1.0f - al0));   // (finite also for a miss; E = G dA = 0 there)
                 T = hit0 ? transmit(T, al0) : T;
                 const float w1 = hit1 ? al1 * T : 0.0f;
                 S = fmaf(-w1, qd1, S);
-                const float dA1 = hit1 ? fmaf(T, qd1, -S * __builtin_amdgcn_rcpf(1.0f - al1)) : 0.0f;
+                const float dA1 = fmaf(T, qd1, -S * __builtin_amdgcn_rcpf(1.0f - al1));
                 T = hit1 ? transmit(T, al1) : T;
                 const float E0 = G0 * dA0, E1 = G1 * dA1;   // (0 for a miss)
                 const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];

@@ -101,14 +101,18 @@ __device__ __forceinline__ float gauss_log2(const float4& q, float dx, float dy)
 // not reproducible off the GPU; -DSR_EXP2_HW selects it for A/B timing only (cost: DESIGN.md §5).
 constexpr float EXP2_C0 = 1.0f, EXP2_C1 = 0.6931470036506653f, EXP2_C2 = 0.24022242426872253f,
                 EXP2_C3 = 0.05550733581185341f, EXP2_C4 = 0.009671512991189957f, EXP2_C5 = 0.001326472731307149f;
-__device__ __forceinline__ float exp2_shared(float x)
+// The arithmetic without the argument clamp, for the BACKWARD (backward -2 % on S2 / S1; the forward measured no gain and keeps
+// exp2_shared): there the clamp's only job (an argument of -inf or
+// NaN, reachable through an overflowing conic * d^2) is done for free by testing alpha BEFORE the min with 0.99 — NaN fails
+// the >= 1/255 test, the Gaussian is a miss exactly as with the clamped 2^-200 = 0 — and by zeroing G, not dL/dalpha, for a
+// miss in the backward.  For every finite argument the value is the clamped function's, bit for bit: below -200 both flush to
+// 0 in v_ldexp_f32, above 0 the pixel is skipped (power > 0) whatever comes out.  v_cvt_i32_f32 saturates and maps NaN to 0;
+// it is written as asm because an out-of-range float -> int conversion is undefined in C++.
+__device__ __forceinline__ float exp2_core(float x)
 {
 #ifdef SR_EXP2_HW
     return __builtin_amdgcn_exp2f(x);
 #else
-    // clamp first, exactly like orc_exp2: x = -inf would make f = NaN (and min(0.99, o * NaN) = 0.99, a spurious
-    // opaque hit), and (int)n of an out-of-range float is undefined.  2^-200 flushes to 0 in ldexp either way.
-    x = fminf(fmaxf(x, -200.0f), 200.0f);
     const float n = __builtin_rintf(x);
     const float f = x - n;
     float p = fmaf(EXP2_C5, f, EXP2_C4);
@@ -116,8 +120,16 @@ __device__ __forceinline__ float exp2_shared(float x)
     p = fmaf(p, f, EXP2_C2);
     p = fmaf(p, f, EXP2_C1);
     p = fmaf(p, f, EXP2_C0);
-    return __builtin_amdgcn_ldexpf(p, (int)n);   // v_cvt_i32_f32 saturates; underflow -> 0
+    int e;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(e) : "v"(n));
+    return __builtin_amdgcn_ldexpf(p, e);
 #endif
+}
+__device__ __forceinline__ float exp2_shared(float x)
+{
+    // clamp first, exactly like orc_exp2: x = -inf would make f = NaN (and min(0.99, o * NaN) = 0.99, a spurious
+    // opaque hit), and (int)n of an out-of-range float is undefined.  2^-200 flushes to 0 in ldexp either way.
+    return exp2_core(fminf(fmaxf(x, -200.0f), 200.0f));
 }
 // T (1 - alpha) with two roundings, never a contracted fma: the oracle's transmittance chain
 __device__ __forceinline__ float transmit(float T, float alpha)
