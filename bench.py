@@ -343,7 +343,7 @@ def bench_map_step(args, dev):
     from splatloc_amd.camera import PinholeCamera
     from splatloc_amd.densify import add_densification_stats_window, densify_and_prune
     from splatloc_amd.fused import render as fused_render, render_window
-    from splatloc_amd.losses import isotropic_loss, mapping_loss
+    from splatloc_amd.losses import isotropic_loss, mapping_loss, mapping_loss_window
     from splatloc_amd.optim import Adam as FusedAdam
     from splatloc_amd.synthetic import WORKLOADS, make_workload
     wl = WORKLOADS[args.workload]
@@ -416,7 +416,13 @@ def bench_map_step(args, dev):
 
     def step(pc, fused, it, densify_ms):
         loss, pkgs = 0, []
-        if fused:   # one activate_pack per window; the views on --streams HIP streams
+        bw_tensors, bw_grads = [], []
+        if fused and max(args.streams, 1) == 1:
+            # training.map_step's path: one launch sequence for the window, the per-view losses carry their own gradients
+            # (losses.mapping_loss_window): ONE backward on the rasterizer's outputs
+            pkgs, _ = render_window(views, pc, pipe, bg)
+            bw_tensors, bw_grads, loss = mapping_loss_window(cfg, pkgs, views)
+        elif fused:   # one activate_pack per window; the views on --streams HIP streams
             pkgs, losses = render_window(views, pc, pipe, bg, streams=max(args.streams, 1),
                                          per_view=lambda k, cam, pkg: mapping_loss(cfg, pkg["render"], pkg["depth"], pkg["kp_prob"], cam))
             loss = sum(losses)
@@ -428,13 +434,19 @@ def bench_map_step(args, dev):
                 else:
                     loss = loss + composed_loss(cam, pkg["render"], pkg["depth"], pkg["kp_prob"])
                 pkgs.append(pkg)
-        if fused:      # train_gaussians.py:221-228, no .cpu() sync
+        if fused and bw_tensors:
+            reg = 0.01 * isotropic_loss(torch.exp(pc._scaling), pc._marker)
+            bw_tensors, bw_grads = bw_tensors + [reg], bw_grads + [None]
+        elif fused:      # train_gaussians.py:221-228, no .cpu() sync
             loss = loss + 0.01 * isotropic_loss(torch.exp(pc._scaling), pc._marker)
         else:
             scaling, score = torch.exp(pc._scaling), pc._marker.detach()
             mask = score.cpu().squeeze() > 0.005
             loss = loss + 0.01 * torch.abs(scaling.mean(dim=1).view(-1, 1)[mask] / (0.02 * (1 - score[mask])) - 1).mean()
-        loss.backward()
+        if bw_tensors:
+            torch.autograd.backward(bw_tensors, bw_grads)
+        else:
+            loss.backward()
         with torch.no_grad():   # train_gaussians.py:231-267, gaussian_model.py:677-679
             if fused:
                 pc.optimizer.set_key_gate(pc._marker, 0.005)

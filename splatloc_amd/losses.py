@@ -22,31 +22,39 @@ from . import _native
 from .rasterizer import _prep, _ptr, _require_gpu, _stream, _on_device
 
 
+def _mapping_loss_launch(image, depth, marker, gt_image, gt_depth, kp, threshold: float, exposure, out=None):
+    """One launch of the fused mapping loss: returns (g_image, g_depth, g_marker, out) with out = [loss_mapping, loss_marker,
+    dL/dexposure_a, dL/dexposure_b].  `out`: optional preallocated 4-float tensor (a row of a per-window table)."""
+    lib = _native.load()
+    _require_gpu(image, "image")
+    dev = image.device
+    H, W = int(image.shape[-2]), int(image.shape[-1])
+    HW = H * W
+    if tuple(image.shape) != (3, H, W) or depth.numel() != HW or marker.numel() != HW:
+        raise RuntimeError("mapping_loss: expected image [3,H,W], depth [1,H,W], marker [H,W]")
+    im, de, ma, gi, gd = (_prep(t, dev) for t in (image, depth, marker, gt_image, gt_depth))
+    # the BCE target is the score map itself (`gt.view(-1).float()`, train_gaussians.py:40): a soft
+    # target in [0, 1] on real data (utils/dataset.py:94), 0/1 when a bool mask is passed
+    k8 = _prep(kp.to(torch.float32), dev)
+    ex = _prep(exposure, dev) if exposure is not None else None
+    f32 = dict(dtype=torch.float32, device=dev)
+    g_image = torch.empty((3, H, W), **f32)
+    g_depth = torch.empty(tuple(depth.shape), **f32)
+    g_marker = torch.empty(tuple(marker.shape), **f32)
+    if out is None:
+        out = torch.empty((4,), **f32)
+    ws = torch.empty((lib.splatraster_mapping_loss_workspace_bytes(HW),), dtype=torch.uint8, device=dev)
+    with _on_device(dev):
+        _native.check(lib.splatraster_mapping_loss(
+            HW, _ptr(im), _ptr(de), _ptr(ma), _ptr(gi), _ptr(gd), _ptr(k8), C.c_float(float(threshold)), _ptr(ex),
+            _ptr(g_image), _ptr(g_depth), _ptr(g_marker), _ptr(out), _ptr(ws), _stream(dev)), "mapping_loss")
+    return g_image, g_depth, g_marker, out
+
+
 class _MappingLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, depth, marker, gt_image, gt_depth, kp, threshold: float, exposure):
-        lib = _native.load()
-        _require_gpu(image, "image")
-        dev = image.device
-        H, W = int(image.shape[-2]), int(image.shape[-1])
-        HW = H * W
-        if tuple(image.shape) != (3, H, W) or depth.numel() != HW or marker.numel() != HW:
-            raise RuntimeError("mapping_loss: expected image [3,H,W], depth [1,H,W], marker [H,W]")
-        im, de, ma, gi, gd = (_prep(t, dev) for t in (image, depth, marker, gt_image, gt_depth))
-        # the BCE target is the score map itself (`gt.view(-1).float()`, train_gaussians.py:40): a soft
-        # target in [0, 1] on real data (utils/dataset.py:94), 0/1 when a bool mask is passed
-        k8 = _prep(kp.to(torch.float32), dev)
-        ex = _prep(exposure, dev) if exposure is not None else None
-        f32 = dict(dtype=torch.float32, device=dev)
-        g_image = torch.empty((3, H, W), **f32)
-        g_depth = torch.empty(tuple(depth.shape), **f32)
-        g_marker = torch.empty(tuple(marker.shape), **f32)
-        out = torch.empty((4,), **f32)
-        ws = torch.empty((lib.splatraster_mapping_loss_workspace_bytes(HW),), dtype=torch.uint8, device=dev)
-        with _on_device(dev):
-            _native.check(lib.splatraster_mapping_loss(
-                HW, _ptr(im), _ptr(de), _ptr(ma), _ptr(gi), _ptr(gd), _ptr(k8), C.c_float(float(threshold)), _ptr(ex),
-                _ptr(g_image), _ptr(g_depth), _ptr(g_marker), _ptr(out), _ptr(ws), _stream(dev)), "mapping_loss")
+        g_image, g_depth, g_marker, out = _mapping_loss_launch(image, depth, marker, gt_image, gt_depth, kp, threshold, exposure)
         ctx.save_for_backward(g_image, g_depth, g_marker, out)
         ctx.has_exposure = exposure is not None
         return out[0] + out[1]
@@ -81,6 +89,48 @@ def mapping_loss(config, image, depth, marker, viewpoint, initialization: bool =
     b = None if initialization else viewpoint.exposure_b
     return mapping_loss_tensors(image, depth, marker, viewpoint.original_image.to(dev), gt_depth,
                                 viewpoint.kp_score.to(dev), thr, a, b)
+
+
+def mapping_loss_window(config, pkgs, viewpoints, initialization: bool = False):
+    """The per-view mapping losses of a window WITHOUT autograd nodes of their own: every view's fused launch already holds
+    the gradients w.r.t. its rendered buffers (the loss terms are summed with weight 1, train_gaussians.py:217-218), so the
+    caller hands them to ONE torch.autograd.backward on the rasterizer's outputs instead of building, per view, a loss node,
+    three `g * grad` products and an addition (≈ 9 small launches per view in map_step).
+
+    Returns (tensors, grads, value): `tensors` / `grads` for torch.autograd.backward(tensors, grads) — the rendered buffers of
+    every view and their gradients — and `value`, the summed loss as a 0-dim tensor (no graph).  The gradients of the exposure
+    parameters (when a view has them and they require grad) are accumulated into their `.grad` here."""
+    if not pkgs:
+        return [], [], None
+    dev = pkgs[0]["render"].device
+    thr = config["Training"]["rgb_boundary_threshold"]
+    V = len(pkgs)
+    table = torch.empty((V, 4), dtype=torch.float32, device=dev)
+    ex_all = None
+    if not initialization and all(getattr(vp, "exposure_a", None) is not None for vp in viewpoints):
+        ex_all = torch.cat([t.reshape(1) for vp in viewpoints for t in (vp.exposure_a, vp.exposure_b)]).to(torch.float32).detach()
+    tensors, grads = [], []
+    with torch.no_grad():
+        for v, (pkg, vp) in enumerate(zip(pkgs, viewpoints)):
+            gt_depth = vp.depth
+            if isinstance(gt_depth, np.ndarray):
+                gt_depth = torch.from_numpy(gt_depth)
+            gt_depth = gt_depth.to(dtype=torch.float32, device=dev)
+            a = None if initialization else getattr(vp, "exposure_a", None)
+            ex = ex_all[2 * v:2 * v + 2] if ex_all is not None else (
+                None if a is None else torch.cat((vp.exposure_a.reshape(1), vp.exposure_b.reshape(1))).to(torch.float32))
+            g_image, g_depth, g_marker, out = _mapping_loss_launch(
+                pkg["render"].detach(), pkg["depth"].detach(), pkg["kp_prob"].detach(), vp.original_image.to(dev), gt_depth,
+                vp.kp_score.to(dev), thr, ex, out=table[v])
+            tensors += [pkg["render"], pkg["depth"], pkg["kp_prob"]]
+            grads += [g_image, g_depth, g_marker]
+            if ex is not None:
+                for prm, col in ((vp.exposure_a, 2), (vp.exposure_b, 3)):
+                    if isinstance(prm, torch.Tensor) and prm.requires_grad:
+                        gpart = table[v, col:col + 1].reshape(prm.shape)
+                        prm.grad = gpart.clone() if prm.grad is None else prm.grad + gpart
+        value = table[:, :2].sum()
+    return tensors, grads, value
 
 
 class _RefinementLoss(torch.autograd.Function):

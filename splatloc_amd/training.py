@@ -102,25 +102,24 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
     import torch.distributed as dist
     from .densify import densify_and_prune, reset_opacity_nonvisible
     from .frame_parallel import allreduce_grads, shard_views, sync_densification_stats
-    from .losses import isotropic_loss, mapping_loss
+    from .losses import isotropic_loss, mapping_loss_window
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank = dist.get_rank(group) if multi else 0
     world = dist.get_world_size(group) if multi else 1
     primitive_reg = bool(config["Training"].get("primitive_reg", True))
     viewpoints = list(viewpoints)
     mine = [viewpoints[i] for i in shard_views(list(range(len(viewpoints))), rank, world)]
-    pkgs, losses = render_window(mine, gaussians, pipe, background,
-                                 per_view=lambda k, vp, pkg: mapping_loss(config, pkg["render"], pkg["depth"], pkg["kp_prob"], vp))
+    pkgs, _ = render_window(mine, gaussians, pipe, background)
     pkgs = [p for p in pkgs if p is not None]
-    loss = None
-    for term in losses:
-        if term is not None:
-            loss = term if loss is None else loss + term
+    # the per-view losses carry their own gradients (one fused launch each): ONE backward on the rasterizer's outputs, no
+    # per-view loss nodes / gradient scalings / additions (losses.mapping_loss_window)
+    tensors, grads, loss = mapping_loss_window(config, pkgs, mine)
     if primitive_reg and rank == 0 and gaussians._xyz.shape[0] > 0:
         reg = 0.01 * isotropic_loss(torch.exp(gaussians._scaling), gaussians._marker)
-        loss = reg if loss is None else loss + reg
-    if loss is not None:
-        loss.backward()
+        tensors, grads = tensors + [reg], grads + [None]
+        loss = reg.detach() if loss is None else loss + reg.detach()
+    if tensors:
+        torch.autograd.backward(tensors, grads)
     params = [getattr(gaussians, a) for a in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_kp_score", "_scaling",
                                               "_rotation")]      # `_marker` never receives a gradient in map()
     opt = gaussians.optimizer
