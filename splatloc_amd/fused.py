@@ -257,6 +257,12 @@ def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier
             split = int(colors.shape[1]) == 4
             outs = rasterize_window(settings, xyz, carriers, colors, opacity, scales=scales, rotations=rotations,
                                     split_last=split)
+            # visibility_filter = radii > 0 of every view in ONE launch when the views' radii are rows of one table
+            rbase = outs[0][-1]._base if len(outs) > 1 else None
+            vis_all = None
+            if rbase is not None and rbase.dim() == 2 and rbase.shape[0] == len(outs) and all(
+                    o[-1]._base is rbase and o[-1].data_ptr() == rbase[k].data_ptr() for k, o in enumerate(outs)):
+                vis_all = rbase > 0
             for k, (vp, o) in enumerate(zip(viewpoints, outs)):
                 if split:
                     rgb, kp_prob, depth, alpha, radii = o
@@ -264,7 +270,8 @@ def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier
                     img, depth, alpha, radii = o
                     rgb, kp_prob = img[:3, :, :], img[-1, :, :]
                 pkg = {"render": rgb, "kp_prob": kp_prob, "viewspace_points": carriers[k],
-                       "visibility_filter": radii > 0, "radii": radii, "depth": depth, "opacity": alpha}
+                       "visibility_filter": vis_all[k] if vis_all is not None else radii > 0, "radii": radii, "depth": depth,
+                       "opacity": alpha}
                 pkgs.append(pkg)
                 extra.append(per_view(k, vp, pkg) if per_view is not None else None)
             return pkgs, extra

@@ -127,8 +127,8 @@ def mapping_loss_window(config, pkgs, viewpoints, initialization: bool = False):
             if ex is not None:
                 for prm, col in ((vp.exposure_a, 2), (vp.exposure_b, 3)):
                     if isinstance(prm, torch.Tensor) and prm.requires_grad:
-                        gpart = table[v, col:col + 1].reshape(prm.shape)
-                        prm.grad = gpart.clone() if prm.grad is None else prm.grad + gpart
+                        gpart = table[v, col:col + 1].reshape(prm.shape)     # (a view of the window's table: no copy launch)
+                        prm.grad = gpart if prm.grad is None else prm.grad + gpart
         value = table[:, :2].sum()
     return tensors, grads, value
 
