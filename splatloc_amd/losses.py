@@ -133,25 +133,39 @@ def mapping_loss_window(config, pkgs, viewpoints, initialization: bool = False):
     return tensors, grads, value
 
 
+def _refinement_loss_launch(image, gt, lam: float):
+    """The fused L1 + SSIM launch: (g_image, out) with out = [L1, SSIM, lam-weighted loss]; g_image = d out[2] / d image."""
+    lib = _native.load()
+    _require_gpu(image, "image")
+    dev = image.device
+    if image.dim() != 3 or tuple(image.shape) != tuple(gt.shape):
+        raise RuntimeError("refinement_loss: expected image and gt of the same [C,H,W] shape")
+    Cn, H, W = (int(v) for v in image.shape)
+    im, g = _prep(image, dev), _prep(gt, dev)
+    g_image = torch.empty((Cn, H, W), dtype=torch.float32, device=dev)
+    out = torch.empty((3,), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib.splatraster_refinement_loss_workspace_bytes(Cn, H, W),), dtype=torch.uint8, device=dev)
+    with _on_device(dev):
+        _native.check(lib.splatraster_refinement_loss(Cn, H, W, C.c_float(lam), _ptr(im), _ptr(g), _ptr(g_image),
+                                                      _ptr(out), _ptr(ws), _stream(dev)), "refinement_loss")
+    return g_image, out
+
+
+def refinement_loss_and_grad(image, gt, lambda_dssim: float = 0.2):
+    """(value, d value / d image) of the colour-refinement loss without an autograd node: the caller runs
+    `image.backward(grad)` (color_refinement_step) — no `g * grad` product for an upstream gradient that is always 1."""
+    with torch.no_grad():
+        g_image, out = _refinement_loss_launch(image.detach(), gt, float(lambda_dssim))
+    return out[2], g_image
+
+
 class _RefinementLoss(torch.autograd.Function):
     """mode 0: (1 - lambda) L1 + lambda (1 - SSIM);  mode 1: SSIM;  mode 2: L1."""
 
     @staticmethod
     def forward(ctx, image, gt, lambda_dssim: float, mode: int):
-        lib = _native.load()
-        _require_gpu(image, "image")
-        dev = image.device
-        if image.dim() != 3 or tuple(image.shape) != tuple(gt.shape):
-            raise RuntimeError("refinement_loss: expected image and gt of the same [C,H,W] shape")
-        Cn, H, W = (int(v) for v in image.shape)
         lam = {0: float(lambda_dssim), 1: 1.0, 2: 0.0}[mode]
-        im, g = _prep(image, dev), _prep(gt, dev)
-        g_image = torch.empty((Cn, H, W), dtype=torch.float32, device=dev)
-        out = torch.empty((3,), dtype=torch.float32, device=dev)
-        ws = torch.empty((lib.splatraster_refinement_loss_workspace_bytes(Cn, H, W),), dtype=torch.uint8, device=dev)
-        with _on_device(dev):
-            _native.check(lib.splatraster_refinement_loss(Cn, H, W, C.c_float(lam), _ptr(im), _ptr(g), _ptr(g_image),
-                                                          _ptr(out), _ptr(ws), _stream(dev)), "refinement_loss")
+        g_image, out = _refinement_loss_launch(image, gt, lam)
         ctx.save_for_backward(g_image)
         ctx.sign = -1.0 if mode == 1 else 1.0     # the kernel's gradient is that of lambda (1 - ssim)
         return out[{0: 2, 1: 1, 2: 0}[mode]]

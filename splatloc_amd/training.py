@@ -12,7 +12,7 @@ import torch
 
 from .densify import add_densification_stats_window
 from .fused import render_window
-from .losses import refinement_loss
+from .losses import refinement_loss_and_grad
 
 
 def expon_lr(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000) -> float:
@@ -58,8 +58,8 @@ def color_refinement_step(viewpoint_cam, gaussians, pipe, background, lambda_dss
         return None
     image, radii = pkg["render"], pkg["radii"]
     gt_image = viewpoint_cam.original_image.to(image.device)
-    loss = refinement_loss(image, gt_image, lambda_dssim)
-    loss.backward()
+    loss, g_image = refinement_loss_and_grad(image, gt_image, lambda_dssim)   # the fused launch holds the gradient: no loss node
+    image.backward(g_image)
     opt = gaussians.optimizer
     with torch.no_grad():
         if primitive_reg:

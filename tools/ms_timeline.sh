@@ -1,10 +1,10 @@
 #!/bin/bash
-# kernel timeline of one map_step (reference layout) under rocprofv3: tools/ms_timeline.sh [workload]
+# kernel timeline of one map_step / refine_step between two fused Adam launches, under rocprofv3: tools/ms_timeline.sh [workload] [stage]
 WL=${1:-S2-ref-layout}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d /tmp/ms -o ms -- python3 $R/bench.py --stage map_step --workload $WL > /tmp/ms.json 2> /tmp/ms.err
+rocprofv3 --kernel-trace -d /tmp/ms -o ms -- python3 $R/bench.py --stage ${2:-map_step} --workload $WL > /tmp/ms.json 2> /tmp/ms.err
 tail -3 /tmp/ms.err
 cd $R
 python3 - <<'PY' > gpurun_out/map_step_timeline.txt 2>&1
