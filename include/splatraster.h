@@ -188,7 +188,7 @@ typedef struct splatraster_window_view {
     float* out_depth;        /* [1,H,W] */
     float* out_alpha;        /* [1,H,W] */
     /* backward only (ignored by the forward calls) */
-    const float* dL_dout_color; /* [C,H,W]; or [C-1,H,W] when color_grad_channels == C - 1 */
+    const float* dL_dout_color; /* [C,H,W]; or [color_grad_channels,H,W] when that is in [1, C) */
     const float* dL_dout_depth; /* [1,H,W] or NULL (= zeros) */
     const float* dL_dout_alpha; /* [1,H,W] or NULL (= zeros) */
     float* dL_dmeans2D;         /* [P,3] output: per view, as GaussianModel.add_densification_stats reads it */
@@ -198,9 +198,11 @@ typedef struct splatraster_window_view {
      * has the two gradients apart passes them apart: color_grad_channels = C - 1 planes behind dL_dout_color and the
      * last channel's plane behind dL_dout_last, or NULL when that channel did not reach the loss (color_refinement:
      * RGB only, train_gaussians.py:283-285) — the backward then skips the channel altogether.  0 = all C planes are
-     * behind dL_dout_color (the plain call). */
+     * behind dL_dout_color (the plain call).  Wider tables ([rgb | features | kp_score]): any g in [1, C) — the first g
+     * planes behind dL_dout_color, the last channel behind dL_dout_last, the channels in between without a gradient
+     * (their planes are neither read nor built).  One value per launch. */
     const float* dL_dout_last;  /* [1,H,W] or NULL */
-    int32_t color_grad_channels; /* 0 (= C) or C - 1 */
+    int32_t color_grad_channels; /* 0 (= C), or g in [1, C) */
 } splatraster_window_view;
 
 size_t splatraster_window_geometry_bytes(int32_t P, int32_t n_views);

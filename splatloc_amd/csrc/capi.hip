@@ -538,8 +538,8 @@ static int window_backward(const splatraster_settings* s, int32_t V, const splat
     grads.gc = C;
     for (int v = 0; v < V; ++v) {
         const int gcv = views[v].color_grad_channels;
-        if (gcv != 0 && gcv != C && gcv != C - 1) return SPLATRASTER_ERR_BAD_ARG;
-        if (gcv == C - 1 && C >= 2) grads.gc = C - 1;
+        if (gcv < 0 || gcv > C) return SPLATRASTER_ERR_BAD_ARG;
+        if (gcv != 0 && gcv < C) grads.gc = gcv;
     }
     for (int v = 0; v < V; ++v) {   // one convention per launch: all views split the last channel off, or none does
         const int gcv = views[v].color_grad_channels ? views[v].color_grad_channels : C;

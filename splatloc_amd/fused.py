@@ -253,8 +253,10 @@ def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier
             carriers = [block[k].requires_grad_(True) for k in range(len(viewpoints))]
             # render = image[:3] and kp_prob = image[-1] leave the rasterizer as separate autograd outputs: their
             # gradients reach the backward kernel as separate planes, and an output the loss never touches costs nothing
-            # (SplatLoc's layout [rgb | kp_score], C = 4; wider feature tables keep the one colour output and its slices)
-            split = int(colors.shape[1]) == 4
+            # (SplatLoc's layout [rgb | kp_score], C = 4; wider tables [rgb | features | kp_score]: the same two outputs, the
+            #  feature channels stay inside the rasterizer — slicing one 35-channel output would cost two zero-filled
+            #  [C,H,W] gradients and an addition per view in autograd)
+            split = 3 if int(colors.shape[1]) >= 4 else False
             outs = rasterize_window(settings, xyz, carriers, colors, opacity, scales=scales, rotations=rotations,
                                     split_last=split)
             # visibility_filter = radii > 0 of every view in ONE launch when the views' radii are rows of one table

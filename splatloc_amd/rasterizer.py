@@ -261,7 +261,9 @@ class _RasterizeWindow(torch.autograd.Function):
     C-1 — SplatLoc's `render` = image[:3] and `kp_prob` = image[-1] (gaussian_renderer/__init__.py:133-135) — so the
     outputs are (rgb_0, last_0, depth_0, alpha_0, radii_0, rgb_1, ...).  Their gradients then reach the kernel as
     separate planes (no zero-padded [C,H,W] copies and no add, which is what slicing one output costs in autograd),
-    and a channel / auxiliary plane that did not reach the loss is skipped by the backward (color_refinement)."""
+    and a channel / auxiliary plane that did not reach the loss is skipped by the backward (color_refinement).
+    `split_last` may also be an integer g in [1, C - 1): the outputs are then (image[:g], image[-1], ...) and the channels
+    in between are not handed out at all (a wide [rgb | features | kp_score] table whose loss reads rgb and kp_score)."""
 
     @staticmethod
     def forward(ctx, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, split_last, *means2D):
@@ -309,8 +311,14 @@ class _RasterizeWindow(torch.autograd.Function):
             _native.check(lib.splatraster_forward_window_render(
                 C.byref(st), V, views, P, R, _ptr(bg), _ptr(col), _ptr(geom), _ptr(binning), _ptr(img), stream),
                 "forward_window_render")
-        split_last = bool(split_last) and Cn >= 2
+        head = 0
+        if split_last is True:
+            head = Cn - 1
+        elif not isinstance(split_last, bool) and split_last:
+            head = int(split_last)
+        split_last = Cn >= 2 and 1 <= head <= Cn - 1
         ctx.split_last = split_last
+        ctx.head = head if split_last else 0
         ctx.st, ctx.V, ctx.R = st, V, [int(r) for r in R]
         ctx.tanfov = [(float(rs.tanfovx), float(rs.tanfovy)) for rs in settings]
         ctx.have = (sca is not None, cov is not None)
@@ -323,7 +331,7 @@ class _RasterizeWindow(torch.autograd.Function):
             rv = radii[v]
             rad.append(rv)
             if split_last:
-                outs += [color[v, :Cn - 1], color[v, Cn - 1], depth[v], alpha[v], rv]
+                outs += [color[v, :head], color[v, Cn - 1], depth[v], alpha[v], rv]
             else:
                 outs += [color[v], depth[v], alpha[v], rv]
         ctx.mark_non_differentiable(*rad)
@@ -388,7 +396,7 @@ class _RasterizeWindow(torch.autograd.Function):
             w.dL_dout_alpha = None if g_alpha is None else g_alpha.data_ptr()
             w.dL_dmeans2D = d_m2[v].data_ptr() if P else None
             w.dL_dout_last = None if g_last is None else g_last.data_ptr()
-            w.color_grad_channels = Cn - 1 if split else 0
+            w.color_grad_channels = ctx.head if split else 0
         R = (C.c_int64 * V)(*ctx.R)
         with _on_device(dev):
             _native.check(lib.splatraster_backward_window(
@@ -407,7 +415,8 @@ def rasterize_window(settings, means3D, means2D, colors_precomp, opacities, scal
     image size / scale modifier / background); `means2D`: one gradient carrier per view.  Returns a list of
     (color, depth, alpha, radii) per view — bit-identical to the per-view calls; the backward sums the views'
     parameter gradients in-kernel (one gradient set per window instead of V sets + V accumulation passes).
-    `split_last`: (rgb [C-1,H,W], last [H,W], depth, alpha, radii) per view instead — see _RasterizeWindow."""
+    `split_last`: (rgb [C-1,H,W], last [H,W], depth, alpha, radii) per view instead (an integer g: (image[:g], image[-1],
+    ...)) — see _RasterizeWindow."""
     settings, means2D = list(settings), list(means2D)
     if colors_precomp is None:
         raise Exception("rasterize_window needs precomputed colors (view-dependent SH colours: per-view calls)")
@@ -422,8 +431,10 @@ def rasterize_window(settings, means3D, means2D, colors_precomp, opacities, scal
     K = _native.MAX_WINDOW_VIEWS
     for a in range(0, len(settings), K):
         flat = _RasterizeWindow.apply(means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                      tuple(settings[a:a + K]), bool(split_last), *means2D[a:a + K])
-        n = 5 if (split_last and int(colors_precomp.shape[1]) >= 2) else 4
+                                      tuple(settings[a:a + K]), split_last, *means2D[a:a + K])
+        Cn = int(colors_precomp.shape[1])
+        head = Cn - 1 if split_last is True else (int(split_last) if split_last else 0)
+        n = 5 if (Cn >= 2 and 1 <= head <= Cn - 1) else 4
         out += [tuple(flat[n * v:n * v + n]) for v in range(len(flat) // n)]
     return out
 

@@ -281,3 +281,48 @@ def test_window_full_size_against_oracle(name, V):
     for k, nm in (("dL_dmeans3D", "means3D"), ("dL_dcolors", "colors"), ("dL_dopacities", "opac"),
                   ("dL_dscales", "scales"), ("dL_drotations", "rots")):
         assert_grad_close(k, Lw[nm].grad.cpu().numpy(), tot[k])
+
+
+def test_head_and_last_outputs_of_a_wide_table():
+    """[rgb | 31 feature channels | kp_score] (C = 35): image[:3] and image[-1] as separate autograd outputs
+    (split_last = 3) give the images and gradients of slicing the one 35-channel output — without the zero-padded
+    [C,H,W] gradients; with only the head reaching the loss the backward runs on 3 channels."""
+    from splatloc_amd import rasterize_window, _native
+    sc = make_scene(1500, 160, 96, 35, seed=11, scale_median=0.1)
+    views = _views(sc, 2, DEV)
+    names = ("means3D", "colors", "opac", "scales", "rots")
+    _native.set_deterministic(True)
+    try:
+        res = {}
+        for mode in ("slice", "split", "slice_head", "split_head"):
+            L = _leaves(sc, DEV)
+            m2s = [torch.zeros_like(L["means3D"], requires_grad=True) for _ in views]
+            split = 3 if mode.startswith("split") else False
+            outs = rasterize_window([rs for _, rs, _ in views], L["means3D"], m2s, L["colors"], L["opac"], scales=L["scales"],
+                                    rotations=L["rots"], split_last=split)
+            loss = 0
+            imgs = []
+            for o, (_, _, g) in zip(outs, views):
+                if split:
+                    rgb, last, depth, alpha, _ = o
+                else:
+                    img, depth, alpha, _ = o
+                    rgb, last = img[:3], img[-1]
+                imgs.append((rgb.detach().clone(), last.detach().clone()))
+                loss = loss + (rgb * g[0][:3]).sum() + (depth * g[1]).sum()
+                if not mode.endswith("head"):
+                    loss = loss + (last * g[0][-1]).sum()
+            loss.backward()
+            res[mode] = (imgs, {n: L[n].grad.clone() for n in names}, [m.grad.clone() for m in m2s])
+    finally:
+        _native.set_deterministic(False)
+    for a, b in (("slice", "split"), ("slice_head", "split_head")):
+        for (r0, l0), (r1, l1) in zip(res[a][0], res[b][0]):
+            assert torch.equal(r0, r1) and torch.equal(l0, l1)
+        for n in names:
+            assert_grad_close(f"{b} {n}", res[b][1][n].cpu().numpy(), res[a][1][n].cpu().numpy(), rtol=2e-5, atol_scale=2e-6)
+        for g0, g1 in zip(res[a][2], res[b][2]):
+            assert_grad_close(f"{b} means2D", g1.cpu().numpy(), g0.cpu().numpy(), rtol=2e-5, atol_scale=2e-6)
+    # feature columns 3..33 received no gradient in any mode; column 34 only when kp_score reached the loss
+    assert float(res["split"][1]["colors"][:, 3:34].abs().max()) == 0.0
+    assert float(res["split_head"][1]["colors"][:, 3:].abs().max()) == 0.0
