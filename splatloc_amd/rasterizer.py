@@ -428,7 +428,9 @@ def rasterize_window(settings, means3D, means2D, colors_precomp, opacities, scal
     if not _window_compatible(settings):
         raise Exception("rasterize_window: the views of a window share image size, scale modifier and background")
     out = []
-    K = _native.MAX_WINDOW_VIEWS
+    # chunks of at most 8 views, and of at most 2^24 (view, Gaussian) rows: the kernels address rows with 24-bit multiplies
+    # and the depth-order words keep the row in 24 bits (a scene of > 2 M Gaussians renders its window in smaller chunks)
+    K = max(1, min(_native.MAX_WINDOW_VIEWS, (1 << 24) // max(int(means3D.shape[0]), 1)))
     for a in range(0, len(settings), K):
         flat = _RasterizeWindow.apply(means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                       tuple(settings[a:a + K]), split_last, *means2D[a:a + K])

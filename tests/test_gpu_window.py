@@ -326,3 +326,24 @@ def test_head_and_last_outputs_of_a_wide_table():
     # feature columns 3..33 received no gradient in any mode; column 34 only when kp_score reached the loss
     assert float(res["split"][1]["colors"][:, 3:34].abs().max()) == 0.0
     assert float(res["split_head"][1]["colors"][:, 3:].abs().max()) == 0.0
+
+
+def test_window_chunks_respect_the_row_limit():
+    """A window's (view, Gaussian) rows are addressed with 24 bits: 8 views of a scene of more than 2^21 Gaussians go out as
+    two launch sequences (7 + 1 views) instead of failing — same images as the per-view calls."""
+    from splatloc_amd import GaussianRasterizer, rasterize_window
+    P = (1 << 21) + 5000
+    sc = make_scene(20000, 96, 64, 3, seed=5, scale_median=0.05)
+    rep = (P + 19999) // 20000
+    big = lambda t: t.repeat((rep,) + (1,) * (t.dim() - 1))[:P].contiguous().to(DEV)  # noqa: E731
+    m3, col, opa, sca, rot = (big(t) for t in (sc.means3D, sc.features, sc.opacities, sc.scales, sc.rotations))
+    m3 = m3 + 0.001 * torch.arange(P, device=DEV, dtype=torch.float32)[:, None] / P       # no exact duplicates
+    views = _views(sc, 8, DEV)
+    with torch.no_grad():
+        outs = rasterize_window([rs for _, rs, _ in views], m3, [torch.zeros_like(m3) for _ in views], col, opa,
+                                scales=sca, rotations=rot)
+        for (_, rs, _), o in zip(views[::3], outs[::3]):
+            c, d, a, r = GaussianRasterizer(raster_settings=rs)(means3D=m3, means2D=torch.zeros_like(m3), shs=None,
+                                                                colors_precomp=col, opacities=opa, scales=sca, rotations=rot,
+                                                                cov3D_precomp=None)
+            assert torch.equal(c, o[0]) and torch.equal(d, o[1]) and torch.equal(a, o[2]) and torch.equal(r, o[3])
