@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 5
+#define SPLATRASTER_ABI_VERSION 6
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 

@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 5   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 6   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 WARN_LOOKBACK_STALL = 5   # splatraster_poll_errors() only; not an error of any frame
