@@ -613,6 +613,32 @@ def bench_refine_step(args, dev):
     }), flush=True)
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) as a FRESH child process —
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <same args>` — and return
+    its exit code; rank 0's JSON line goes straight to the inherited stdout.  Called before anything touches the GPU (this
+    process never initialises HIP: `torch.cuda.device_count()` only counts devices), and it starts a child, it never
+    re-execs.  SPLATLOC_DIST_BACKEND=gloo lets a 1-GPU box drive the N-rank path (tests); with RCCL ("nccl", the default)
+    N ranks need N GPUs and anything less is refused instead of silently measuring fewer."""
+    import socket
+    import subprocess
+    backend = os.environ.get("SPLATLOC_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n:
+        print(f"bench.py --gpus {n}: this node shows {ndev} GPU(s); RCCL needs one GPU per rank "
+              "(SPLATLOC_DIST_BACKEND=gloo runs the N-rank plumbing on fewer GPUs, for tests only)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -633,13 +659,22 @@ def main():
     ap.add_argument("--no-multi-stream", action="store_true", help="skip the secondary legs (per-view loop, multi-stream) (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
-    ap.add_argument("--stage", default="raster", choices=["raster", "activations", "loss", "map_step", "refine_step"],
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of K steps is repeated this many times; value = the MEDIAN region (min / max reported)")
+    ap.add_argument("--stage", default="raster",
+                    choices=["raster", "activations", "loss", "map_step", "refine_step", "scene", "eval_rendering"],
                     help="raster = the BASELINE metric (default); activations = the fused front-end stage alone")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become one (a fresh child process per rank; nothing here has touched the GPU yet)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                         "the JSON line's n_gpus must be what was asked for")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     ndev = torch.cuda.device_count()
@@ -668,7 +703,8 @@ def main():
     from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer, _native, rasterize_window
     from splatloc_amd.camera import PinholeCamera
     from splatloc_amd.densify import add_densification_stats, add_densification_stats_window
-    from splatloc_amd.frame_parallel import allreduce_grads, shard_views, sync_densification_stats
+    from splatloc_amd.frame_parallel import reduce_step, shard_views
+    from splatloc_amd.rasterizer import window_grad_span
     from splatloc_amd.synthetic import WORKLOADS, make_workload
 
     wl = WORKLOADS[args.workload]
@@ -712,14 +748,23 @@ def main():
         # gradients in-kernel, then the per-view densification statistics (train_gaussians.py:238-245)
         block = torch.zeros((len(views),) + tuple(means3D.shape), dtype=means3D.dtype, device=means3D.device)
         carriers = [block[k].requires_grad_(True) for k in range(len(views))]       # render(): screenspace_points per view (one zero fill)
-        outs = rasterize_window([rs for _, _, rs in views], means3D, carriers, colors, opac, scales=scales, rotations=rots)
+        span = [] if world > 1 else None    # N > 1: the backward's gradient allocation ends with a [2, P] tail for the statistics increments
+        outs = rasterize_window([rs for _, _, rs in views], means3D, carriers, colors, opac, scales=scales, rotations=rots,
+                                grad_span=span)
         if record:
             for k in range(0, len(outs), 8):
                 info["R"] += [int(r) for r in outs[k][0].grad_fn.R]
             info["V"] += [int((o[3] > 0).sum().item()) for o in outs]
         if not args.fwd_only:
             torch.autograd.backward([t for o in outs for t in o[:3]], [g for _, gs, _ in views for g in gs])
+            if span is not None and len(span) == 1:
+                # the step's increments of xyz_gradient_accum / denom go into the tail of the gradient allocation: they are
+                # summed over the ranks by the SAME in-place all-reduce as the gradients (frame_parallel.reduce_step)
+                inc = span[0]["tail"]
+                add_densification_stats_window([m2.grad for m2 in carriers], [o[3] for o in outs], inc[0], inc[1], max_radii)
+                return inc
             add_densification_stats_window([m2.grad for m2 in carriers], [o[3] for o in outs], accum, denom, max_radii)
+        return None
 
     def one_view(rast, g_out, record):
         means2D = torch.zeros_like(means3D, requires_grad=True)   # per-view grad carrier (render(): screenspace_points)
@@ -736,11 +781,12 @@ def main():
     def step(record=False):
         for p in params:
             p.grad = None
-        if world > 1:
-            accum.zero_()
+        inc = None
+        if world > 1 and not (mode["window"] and views):
+            accum.zero_()      # the per-view paths accumulate the step's increments here (summed over the ranks below)
             denom.zero_()
         if mode["window"] and views:
-            window_step(record)
+            inc = window_step(record)
         elif side:
             # the views of a window are independent until their gradients are summed: view j runs on HIP stream
             # j % K, so the latency-bound kernels of a small frame overlap with another view's (autograd runs
@@ -757,13 +803,27 @@ def main():
             for rast, g_out, _ in views:   # every frame one forward + one backward, parameter gradients accumulate
                 one_view(rast, g_out, record)
         if not args.fwd_only and world > 1:
-            # ONE SUM all-reduce of the accumulated parameter gradients (a rank without views in strong
-            # mode contributes zeros) + the statistics every replica needs to densify identically
-            for p in params:
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-            info["reduce_path"] = allreduce_grads([p.grad for p in params])
-            sync_densification_stats(accum, denom, max_radii)
+            # TWO collectives per step (frame_parallel.reduce_step): ONE SUM all-reduce over [accumulated parameter gradients |
+            # increments of xyz_gradient_accum, denom] — in place in the backward's own allocation on the window path — and
+            # ONE MAX all-reduce of max_radii2D, so that every replica would take the same optimizer step and densify identically
+            if not views:
+                # a rank without views (strong mode, more ranks than views) contributes zeros in EXACTLY the layout the
+                # other ranks' backward produced
+                z = window_grad_span(P, C, dev, have_scales=True, have_cov=False, tail=True, zero=True)
+                for p, k in zip(params, ("m3", "col", "op", "sca", "rot")):
+                    p.grad = z[k]
+                inc = z["tail"]
+            if inc is not None:
+                _, inc_out, red = reduce_step([p.grad for p in params], sum_extras=[inc[0], inc[1]], max_extras=[max_radii])
+                accum.add_(inc_out[0])
+                denom.add_(inc_out[1])
+            else:   # per-view calls (--no-window / --streams): autograd accumulated into the first view's allocation
+                g_out, inc_out, red = reduce_step([p.grad for p in params], sum_extras=[accum, denom], max_extras=[max_radii])
+                for p, g in zip(params, g_out):
+                    p.grad = g
+                accum.copy_(inc_out[0])
+                denom.copy_(inc_out[1])
+            info["reduce_path"] = red
 
     def barrier():
         if world > 1:
@@ -787,18 +847,21 @@ def main():
     # (2) timed region: only the dominant kernel is bracketed (roofline.achieved is measured live
     #     here, on the launch stream)
     _native.timing_select([dom])
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    regions = []
+    for _ in range(max(args.repeats, 1)):       # every region: barrier + synchronize, EXACTLY K steps, barrier + synchronize
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        regions.append(time.perf_counter() - t0)
     _native.timing_enable(False)
     stages[dom] = _native.timing_collect()[dom]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:       # MAX over the ranks, region by region
+        t = torch.tensor(regions, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        regions = [float(x) for x in t.tolist()]
+    elapsed = sorted(regions)[len(regions) // 2]     # value = the MEDIAN region
 
     # Secondary figure (N = 1): the same step with the window's views spread over K HIP streams
     # (splatloc_amd.fused.render_window does this for the product path).  Not `value`: kernel durations
@@ -876,6 +939,10 @@ def main():
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": {"regions": len(regions), "steps_per_region": args.steps, "value_is": "median region",
+                        "frames_per_s_min": round(frames_per_step * args.steps / max(regions), 3),
+                        "frames_per_s_max": round(frames_per_step * args.steps / min(regions), 3),
+                        "ms_per_step_all": [round(1e3 * r / args.steps, 4) for r in regions]},
             "config": {"workload": f"{args.workload}: P={P} Gaussians, {W}x{H}, C={C} channels "
                                    f"(3 RGB + {C - 3} feature) + depth + alpha, seed {wl['seed']}; "
                                    f"{args.views} different cameras per window",
@@ -887,8 +954,8 @@ def main():
                                        "splatraster_backward_window)") if mode["window"] else "one launch sequence per view",
                        "per_view_densification_stats_in_step": True,
                        "parallelism": f"frame-parallel dp{world}, scene replica per GPU"
-                                      + (", one RCCL SUM all-reduce of the accumulated parameter grads + densification-"
-                                         "statistics sync per step" if world > 1 else "")},
+                                      + (", per step ONE SUM all-reduce over [accumulated parameter grads | densification-statistics "
+                                         "increments] + ONE MAX all-reduce of max_radii2D" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": ("profiles/traffic.json (builder rocprofv3 PMC run of this workload and launch mode; "
@@ -914,7 +981,12 @@ def main():
                            "shared by the 5 views of a step and may be served by the 256-MiB Infinity Cache)",
         }
         if world > 1:
-            out["config"]["grad_allreduce_path"] = info.get("reduce_path")
+            red = info.get("reduce_path") or {}
+            out["rccl_ranks"] = dist.get_world_size()
+            out["dist_backend"] = dist.get_backend()
+            out["reduce_path"] = red.get("sum_path")
+            out["collectives_per_step"] = red.get("collectives")
+            out["config"]["grad_allreduce_path"] = red
         if args.fwd_only:
             out["metric"] = "DEBUG fwd-only frames/s (not the BASELINE metric)"
         if world == 1 and not args.no_cpu_baseline:

@@ -6,13 +6,15 @@ independent views before a single backward / optimizer step (train_gaussians.py:
 gradients is mathematically the reference step.  Every rank holds a full
 replica of the Gaussian scene; there is no collective on the data path of a single frame.
 
-Collectives (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests):
-  * SUM  of the parameter gradients (xyz, features, opacity, scaling, rotation, kp_score)
-  * SUM  of the densification statistics increments (xyz_gradient_accum, denom;
-         gaussian_model.py:677-679)
-  * MAX  of max_radii2D (train_gaussians.py:240-244)
+Collectives (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests) — `reduce_step`, at most
+TWO per optimisation step:
+  * ONE SUM over [parameter gradients (xyz, features, opacity, scaling, rotation, kp_score) |
+         densification statistics increments (xyz_gradient_accum, denom; gaussian_model.py:677-679)]
+  * ONE MAX over [max_radii2D (train_gaussians.py:240-244) | visibility flags of an opacity-reset step
+         (gaussian_model.py:384-392)]
 xGMI is point-to-point (7 links/GPU): the payload (64 B/Gaussian at the reference layout,
-+4 B per extra feature channel) is sent as a few large buffers, never per-parameter-row.
++4 B per extra feature channel) is sent as one large buffer, never per-parameter-row.
+`allreduce_grads` / `sync_densification_stats` are the round-1..3 building blocks (kept: three collectives).
 """
 from __future__ import annotations
 
@@ -132,3 +134,92 @@ def sync_densification_stats(grad_accum_inc: torch.Tensor, denom_inc: torch.Tens
     n = grad_accum_inc.numel()
     grad_accum_inc.copy_(packed[:n].view_as(grad_accum_inc))
     denom_inc.copy_(packed[n:].view_as(denom_inc))
+
+
+_LAYOUT_CHECKED: set = set()
+
+
+def _check_same_layout(numel: int, device, group) -> None:
+    """A SUM over buffers of different lengths is undefined behaviour in RCCL (and silently wrong sums when the
+    lengths agree but the piece order does not).  The first time a buffer length is reduced, every rank checks that
+    all ranks are about to reduce the same length (one tiny MAX collective, then never again for that length)."""
+    key = (id(group), int(numel))
+    if key in _LAYOUT_CHECKED:
+        return
+    t = torch.tensor([numel, -numel], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    lo, hi = -int(t[1]), int(t[0])
+    if lo != hi:
+        raise RuntimeError(f"frame_parallel.reduce_step: ranks disagree on the reduce buffer ({lo} .. {hi} elements); "
+                           "every rank must hold the same replica and use the same gradient layout")
+    _LAYOUT_CHECKED.add(key)
+
+
+def reduce_step(grads: Sequence[torch.Tensor], sum_extras: Sequence[torch.Tensor] = (),
+                max_extras: Sequence[torch.Tensor] = (), group=None):
+    """Everything one frame-parallel optimisation step exchanges, in at most TWO collectives:
+
+      (1) ONE SUM all-reduce over [grads | sum_extras] — the parameter gradients and the increments of
+          xyz_gradient_accum / denom;
+      (2) ONE MAX all-reduce over [max_extras] — max_radii2D and, on an opacity-reset step, the visibility flags
+          (float32 tensors; updated in place).
+
+    (1) runs IN PLACE, with no staging copy, when `grads` and `sum_extras` are adjacent pieces of one allocation — the
+    layout `rasterize_window(..., grad_span=[])` produces: the window's summed parameter gradients followed by a
+    [2, P] tail the statistics kernel writes its increments into.  Anything else (gradients that went through further
+    autograd nodes, e.g. the fused activations of `training.map_step`) is packed by ONE `torch.cat`, reduced, and handed
+    back as views of the reduced buffer (no copy back).  Every rank must pass the same shapes in the same order; the
+    buffer length is verified across ranks the first time it is seen.
+
+    Returns (grads_out, sum_extras_out, info): tensors holding the reduced values (the inputs themselves on the in-place
+    path) and info = {"collectives", "sum_path": "in-place span" | "packed", "sum_bytes", "max_bytes"}.
+    Single process / no process group: returns the inputs unchanged, info["collectives"] = 0."""
+    grads, sum_extras, max_extras = list(grads), list(sum_extras), list(max_extras)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return grads, sum_extras, {"collectives": 0, "sum_path": None, "sum_bytes": 0, "max_bytes": 0}
+    info = {"collectives": 0, "sum_path": None, "sum_bytes": 0, "max_bytes": 0}
+    pending = []
+    members = [t for t in grads + sum_extras if t.numel()]
+    packed = None
+    if members:
+        with torch.no_grad():
+            spans, rest = _shared_spans(members) if len(members) > 1 else ([], members)
+            if len(spans) == 1 and not rest:
+                buf = spans[0]
+                info["sum_path"] = "in-place span"
+            elif len(members) == 1 and members[0].is_contiguous():
+                buf = members[0].view(-1)
+                info["sum_path"] = "in-place span"
+            else:
+                buf = packed = torch.cat([t.reshape(-1) for t in members])
+                info["sum_path"] = "packed"
+        _check_same_layout(buf.numel(), buf.device, group)
+        info["sum_bytes"] = buf.numel() * buf.element_size()
+        pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        info["collectives"] += 1
+    mx = [t for t in max_extras if t.numel()]
+    mbuf = None
+    if mx:
+        with torch.no_grad():
+            mbuf = mx[0].view(-1) if (len(mx) == 1 and mx[0].is_contiguous()) else torch.cat([t.reshape(-1) for t in mx])
+        _check_same_layout(mbuf.numel(), mbuf.device, group)
+        info["max_bytes"] = mbuf.numel() * mbuf.element_size()
+        pending.append(dist.all_reduce(mbuf, op=dist.ReduceOp.MAX, group=group, async_op=True))
+        info["collectives"] += 1
+    for w in pending:
+        w.wait()
+    with torch.no_grad():
+        if mbuf is not None and not (len(mx) == 1 and mx[0].is_contiguous()):
+            off = 0
+            for t in mx:
+                n = t.numel()
+                t.copy_(mbuf[off:off + n].view_as(t))
+                off += n
+        if packed is None:
+            return grads, sum_extras, info
+        outs, off = [], 0
+        for t in grads + sum_extras:
+            n = t.numel()
+            outs.append(packed[off:off + n].view(t.shape) if n else t)
+            off += n
+    return outs[:len(grads)], outs[len(grads):], info

@@ -238,6 +238,8 @@ def render_window(viewpoints, pc, pipe, bg_color: torch.Tensor, scaling_modifier
     Returns (pkgs, per_view results).  batched=False, streams <= 1 is the reference's serial loop."""
     viewpoints = list(viewpoints)
     pkgs, extra = [], []
+    if not viewpoints:      # a rank without work in a frame-parallel step (world size > window size): nothing to launch
+        return pkgs, extra
     dev = pc._xyz.device
     # view-independent activations once per window (on the caller's stream, before the fork)
     shared = shared_activations(pc, pipe) if (share_activations and (len(viewpoints) > 1 or batched) and pc._xyz.shape[0] > 0) else None

@@ -102,6 +102,8 @@ def mapping_loss_window(config, pkgs, viewpoints, initialization: bool = False):
     parameters (when a view has them and they require grad) are accumulated into their `.grad` here."""
     if not pkgs:
         return [], [], None
+    if len(pkgs) != len(viewpoints):
+        raise RuntimeError("mapping_loss_window: one view per render package (filter the two lists together)")
     dev = pkgs[0]["render"].device
     thr = config["Training"]["rgb_boundary_threshold"]
     V = len(pkgs)
@@ -127,8 +129,10 @@ def mapping_loss_window(config, pkgs, viewpoints, initialization: bool = False):
             if ex is not None:
                 for prm, col in ((vp.exposure_a, 2), (vp.exposure_b, 3)):
                     if isinstance(prm, torch.Tensor) and prm.requires_grad:
-                        gpart = table[v, col:col + 1].reshape(prm.shape)     # (a view of the window's table: no copy launch)
-                        prm.grad = gpart if prm.grad is None else prm.grad + gpart
+                        gpart = table[v, col:col + 1].reshape(prm.shape)
+                        # its own two-float storage: an in-place op on one parameter's .grad (clip_grad_norm_, ...) must not
+                        # write into the table the other views' gradients alias
+                        prm.grad = gpart.clone() if prm.grad is None else prm.grad + gpart
         value = table[:, :2].sum()
     return tensors, grads, value
 

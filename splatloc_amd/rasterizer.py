@@ -237,8 +237,45 @@ class _RasterizeGaussians(torch.autograd.Function):
         return d_m3, d_m2, d_sh, d_col, d_op, d_sca, d_rot, d_cov, None, d_view, d_proj, d_cam
 
 
+def window_grad_layout(P: int, Cn: int, have_scales: bool = True, have_cov: bool = False):
+    """Layout of the ONE allocation that holds the summed parameter gradients of a window: 16-byte aligned pieces
+    `m3 [P,3] | op [P,1] | col [P,Cn] | sca [P,3] | rot [P,4] | cov [P,6]`, optionally followed by a `[2, P]` TAIL for the
+    increments of xyz_gradient_accum / denom, so that a frame-parallel replica reduces gradients AND statistics as one
+    in-place SUM (frame_parallel.reduce_step).  Returns (shapes, offsets, total_floats)."""
+    shapes = {"m3": (P, 3), "op": (P, 1), "col": (P, Cn)}
+    if have_scales:
+        shapes["sca"], shapes["rot"] = (P, 3), (P, 4)
+    if have_cov:
+        shapes["cov"] = (P, 6)
+    offs, total = {}, 0
+    for k, shp in shapes.items():
+        offs[k] = total
+        total += (shp[0] * shp[1] + 3) & ~3
+    return shapes, offs, total
+
+
+def window_grad_span(P: int, Cn: int, device, have_scales: bool = True, have_cov: bool = False, tail: bool = True,
+                     zero: bool = False) -> dict:
+    """Allocates the gradient allocation of `window_grad_layout` (+ the statistics tail).  `zero=True`: what a rank
+    WITHOUT views in a frame-parallel step contributes — zero gradients in exactly the layout the other ranks' backward
+    produced, so that every rank reduces the same buffer.  Keys: flat, tail ([2, P, 1] or None), m3, op, col, sca, rot, cov."""
+    shapes, offs, total = window_grad_layout(P, Cn, have_scales, have_cov)
+    n = total + (2 * P if tail else 0)
+    flat = (torch.zeros if zero else torch.empty)((n,), dtype=torch.float32, device=device)
+    out = {"flat": flat, "tail": None}
+    for k in ("m3", "op", "col", "sca", "rot", "cov"):
+        out[k] = flat[offs[k]:offs[k] + shapes[k][0] * shapes[k][1]].view(shapes[k]) if k in shapes else None
+    if tail:
+        out["tail"] = flat[total:total + 2 * P].view(2, P, 1)
+        if not zero:
+            out["tail"].zero_()
+    return out
+
+
 def _window_compatible(settings) -> bool:
     """One launch sequence needs one image size, channel layout, scale modifier and background for all views."""
+    if not settings:
+        return True
     a = settings[0]
     for b in settings[1:]:
         if (int(b.image_height), int(b.image_width)) != (int(a.image_height), int(a.image_width)):
@@ -266,8 +303,10 @@ class _RasterizeWindow(torch.autograd.Function):
     in between are not handed out at all (a wide [rgb | features | kp_score] table whose loss reads rgb and kp_score)."""
 
     @staticmethod
-    def forward(ctx, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, split_last, *means2D):
+    def forward(ctx, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, split_last, grad_span,
+                *means2D):
         lib = _native.load()
+        ctx.grad_span = grad_span
         _require_gpu(means3D, "means3D")
         dev = means3D.device
         V = len(settings)
@@ -351,19 +390,13 @@ class _RasterizeWindow(torch.autograd.Function):
         P, Cn = int(m3.shape[0]), st.channels
         f32 = dict(dtype=torch.float32, device=dev)
         # the summed parameter gradients of the window: 16-byte aligned pieces of ONE allocation, like the per-view
-        # call, so a frame-parallel replica all-reduces them in place as a single RCCL call
-        shapes = {"m3": (P, 3), "op": (P, 1), "col": (P, Cn)}
-        if sca is not None:
-            shapes["sca"], shapes["rot"] = (P, 3), (P, 4)
-        if cov is not None:
-            shapes["cov"] = (P, 6)
-        offs, total = {}, 0
-        for k, shp in shapes.items():
-            offs[k] = total
-            total += (shp[0] * shp[1] + 3) & ~3
-        flat = torch.empty((total,), **f32)
-        piece = lambda k: flat[offs[k]:offs[k] + shapes[k][0] * shapes[k][1]].view(shapes[k]) if k in shapes else None  # noqa: E731
-        d_m3, d_op, d_col, d_sca, d_rot, d_cov = (piece(k) for k in ("m3", "op", "col", "sca", "rot", "cov"))
+        # call, so a frame-parallel replica all-reduces them in place as a single RCCL call; with `grad_span` the
+        # allocation ends with a zeroed [2, P] tail for the statistics increments, which then ride in the same call
+        span = window_grad_span(P, Cn, dev, have_scales=sca is not None, have_cov=cov is not None,
+                                tail=ctx.grad_span is not None)
+        if ctx.grad_span is not None:
+            ctx.grad_span.append(span)
+        d_m3, d_op, d_col, d_sca, d_rot, d_cov = (span[k] for k in ("m3", "op", "col", "sca", "rot", "cov"))
         d_m2 = torch.empty((V, P, 3), **f32)
         views = (_native.WindowView * V)()
         keep = []
@@ -404,20 +437,26 @@ class _RasterizeWindow(torch.autograd.Function):
                 _ptr(binning), _ptr(img), _ptr(d_m3), _ptr(d_col), _ptr(d_op), _ptr(d_sca), _ptr(d_rot), _ptr(d_cov),
                 _stream(dev)), "backward_window")
         del keep
-        # (means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, split_last, *means2D)
-        return (d_m3, d_col, d_op, d_sca, d_rot, d_cov, None, None) + tuple(d_m2[v] for v in range(V))
+        # (means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, split_last, grad_span, *means2D)
+        return (d_m3, d_col, d_op, d_sca, d_rot, d_cov, None, None, None) + tuple(d_m2[v] for v in range(V))
 
 
 def rasterize_window(settings, means3D, means2D, colors_precomp, opacities, scales=None, rotations=None,
-                     cov3D_precomp=None, split_last: bool = False):
+                     cov3D_precomp=None, split_last: bool = False, grad_span: Optional[list] = None):
     """`[GaussianRasterizer(s)(means3D, m2, opacities, colors_precomp=..., ...) for s, m2 in zip(settings, means2D)]`
     as one launch sequence per chunk of <= 8 views.  `settings`: GaussianRasterizationSettings per view (same
     image size / scale modifier / background); `means2D`: one gradient carrier per view.  Returns a list of
     (color, depth, alpha, radii) per view — bit-identical to the per-view calls; the backward sums the views'
     parameter gradients in-kernel (one gradient set per window instead of V sets + V accumulation passes).
     `split_last`: (rgb [C-1,H,W], last [H,W], depth, alpha, radii) per view instead (an integer g: (image[:g], image[-1],
-    ...)) — see _RasterizeWindow."""
+    ...)) — see _RasterizeWindow.
+    `grad_span`: a list; every chunk's backward appends its gradient allocation (`window_grad_span`: flat, the pieces and a
+    zeroed [2, P, 1] tail for the xyz_gradient_accum / denom increments) — the frame-parallel step reduces gradients and
+    statistics as ONE in-place SUM (frame_parallel.reduce_step).
+    An empty window (no settings) returns []."""
     settings, means2D = list(settings), list(means2D)
+    if not settings and not means2D:
+        return []
     if colors_precomp is None:
         raise Exception("rasterize_window needs precomputed colors (view-dependent SH colours: per-view calls)")
     if ((scales is None or rotations is None) and cov3D_precomp is None) or (
@@ -433,7 +472,7 @@ def rasterize_window(settings, means3D, means2D, colors_precomp, opacities, scal
     K = max(1, min(_native.MAX_WINDOW_VIEWS, (1 << 24) // max(int(means3D.shape[0]), 1)))
     for a in range(0, len(settings), K):
         flat = _RasterizeWindow.apply(means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                      tuple(settings[a:a + K]), split_last, *means2D[a:a + K])
+                                      tuple(settings[a:a + K]), split_last, grad_span, *means2D[a:a + K])
         Cn = int(colors_precomp.shape[1])
         head = Cn - 1 if split_last is True else (int(split_last) if split_last else 0)
         n = 5 if (Cn >= 2 and 1 <= head <= Cn - 1) else 4

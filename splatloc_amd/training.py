@@ -77,6 +77,10 @@ def color_refinement_step(viewpoint_cam, gaussians, pipe, background, lambda_dss
     return loss
 
 
+# what the last multi-GPU map_step exchanged (frame_parallel.reduce_step's info: collectives, path, bytes) — monitoring
+LAST_STEP_INFO: dict = {}
+
+
 def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: int, *, densify=None,
              gaussian_reset: int = 0, seed: int = 0, group=None):
     """One iteration of the loop body of SplatLoc.map (train_gaussians.py:188-267) on the window `viewpoints` (the
@@ -92,16 +96,17 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
         optimizer.step, zero_grad, update_learning_rate(iteration_count)
 
     Frame-parallel data parallelism (torch.distributed initialised, one process per GPU, a full replica of
-    the scene per rank): the views of the window are dealt round-robin to the ranks (frame_parallel.shard_views), the
-    parameter gradients are SUM-all-reduced, the statistics increments SUM / MAX-reduced and the visibility union
-    OR-reduced, so every replica takes the SAME optimizer step and densifies identically (the split noise is
+    the scene per rank): the views of the window are dealt round-robin to the ranks (frame_parallel.shard_views); ONE SUM
+    all-reduce carries the parameter gradients and the statistics increments, ONE MAX all-reduce max_radii2D and (on a
+    reset step) the visibility union — two collectives per step (frame_parallel.reduce_step; a rank without views, world
+    size > window size, contributes zeros) —, so every replica takes the SAME optimizer step and densifies identically (the split noise is
     counter-based: keyed by (seed, iteration_count, source row, copy)) — the replicas stay bit-identical without ever
     broadcasting parameters.  The regulariser is added on rank 0 only (the reduced gradient contains it once).
     `densify`: dict(grad_threshold, min_opacity, extent, size_threshold, every, offset) or None.
     Returns the rank's loss tensor (None on a rank without work)."""
     import torch.distributed as dist
     from .densify import densify_and_prune, reset_opacity_nonvisible
-    from .frame_parallel import allreduce_grads, shard_views, sync_densification_stats
+    from .frame_parallel import reduce_step, shard_views
     from .losses import isotropic_loss, mapping_loss_window
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank = dist.get_rank(group) if multi else 0
@@ -110,7 +115,8 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
     viewpoints = list(viewpoints)
     mine = [viewpoints[i] for i in shard_views(list(range(len(viewpoints))), rank, world)]
     pkgs, _ = render_window(mine, gaussians, pipe, background)
-    pkgs = [p for p in pkgs if p is not None]
+    pairs = [(p, v) for p, v in zip(pkgs, mine) if p is not None]      # views and packages filtered TOGETHER
+    pkgs, mine = [p for p, _ in pairs], [v for _, v in pairs]
     # the per-view losses carry their own gradients (one fused launch each): ONE backward on the rasterizer's outputs, no
     # per-view loss nodes / gradient scalings / additions (losses.mapping_loss_window)
     tensors, grads, loss = mapping_loss_window(config, pkgs, mine)
@@ -126,11 +132,37 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
     with torch.no_grad():
         P = int(gaussians._xyz.shape[0])
         dev = gaussians._xyz.device
+        grads2d = [p["viewspace_points"].grad for p in pkgs]
+        radii = [p["radii"] for p in pkgs]
+        update_gaussian = bool(densify) and iteration_count % int(densify["every"]) == int(densify.get("offset", 0))
+        reset_now = bool(gaussian_reset) and iteration_count % gaussian_reset == 0 and not update_gaussian
+        seen = None
+        if reset_now:       # the union of the window's visibility masks (gaussian_model.py:384-392)
+            seen = torch.zeros(P, dtype=torch.float32, device=dev)
+            for p in pkgs:
+                seen = torch.maximum(seen, p["visibility_filter"].to(torch.float32))
         if multi:
-            for p in params:
-                if p.grad is None:
+            # everything the replicas exchange in this step, in TWO collectives (frame_parallel.reduce_step):
+            #   SUM over [parameter gradients | increments of xyz_gradient_accum, denom]
+            #   MAX over [max_radii2D | visibility flags of a reset step]
+            for p in params:        # a rank without views: zero gradients (incl. the empty `_features_rest` group, so that
+                if p.grad is None:  # every replica's optimizer creates the same state)
                     p.grad = torch.zeros_like(p)
-            allreduce_grads([p.grad for p in params if p.numel()], group=group)
+            live = [p for p in params if p.numel()]
+            inc = torch.zeros((2, P, 1), device=dev)
+            if pkgs:
+                add_densification_stats_window(grads2d, radii, inc[0], inc[1], gaussians.max_radii2D)
+            g_out, inc_out, info = reduce_step([p.grad for p in live], sum_extras=[inc[0], inc[1]],
+                                               max_extras=[gaussians.max_radii2D] + ([seen] if seen is not None else []),
+                                               group=group)
+            for p, g in zip(live, g_out):
+                p.grad = g          # views of the reduced buffer: no copy back
+            gaussians.xyz_gradient_accum += inc_out[0]
+            gaussians.denom += inc_out[1]
+            LAST_STEP_INFO.clear()
+            LAST_STEP_INFO.update(info)
+        elif pkgs:
+            add_densification_stats_window(grads2d, radii, gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D)
         if primitive_reg:
             if hasattr(opt, "set_key_gate"):
                 opt.set_key_gate(gaussians._marker, 0.005)
@@ -138,28 +170,11 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
                 gaussians._xyz.grad[gaussians._marker.detach().squeeze() > 0.005] = 0
         elif hasattr(opt, "set_key_gate"):
             opt.set_key_gate(None)
-        grads2d = [p["viewspace_points"].grad for p in pkgs]
-        radii = [p["radii"] for p in pkgs]
-        if multi:
-            inc_a, inc_d = torch.zeros((P, 1), device=dev), torch.zeros((P, 1), device=dev)
-            if pkgs:
-                add_densification_stats_window(grads2d, radii, inc_a, inc_d, gaussians.max_radii2D)
-            sync_densification_stats(inc_a, inc_d, gaussians.max_radii2D, group=group)
-            gaussians.xyz_gradient_accum += inc_a
-            gaussians.denom += inc_d
-        elif pkgs:
-            add_densification_stats_window(grads2d, radii, gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D)
-        update_gaussian = bool(densify) and iteration_count % int(densify["every"]) == int(densify.get("offset", 0))
         if update_gaussian:
             densify_and_prune(gaussians, densify["grad_threshold"], densify["min_opacity"], densify["extent"],
                               densify["size_threshold"], seed=seed, draw_id=iteration_count)
-        if gaussian_reset and iteration_count % gaussian_reset == 0 and not update_gaussian:
-            seen = torch.zeros(int(gaussians._xyz.shape[0]), dtype=torch.uint8, device=dev)
-            for p in pkgs:
-                seen |= p["visibility_filter"].to(torch.uint8)
-            if multi:
-                dist.all_reduce(seen, op=dist.ReduceOp.MAX, group=group)
-            reset_opacity_nonvisible(gaussians, [seen.bool()])
+        if reset_now:
+            reset_opacity_nonvisible(gaussians, [seen > 0])
         opt.step()
         opt.zero_grad(set_to_none=True)
         update_learning_rate(gaussians, iteration_count)

@@ -92,3 +92,142 @@ def test_single_process_is_a_noop():
     t = torch.ones(4, 3)
     allreduce_grads([t, None])
     assert torch.all(t == 1)
+
+
+def _reduce_step_worker(rank, world, port, out):
+    """frame_parallel.reduce_step: the whole exchange of a step in TWO collectives, in place when the gradients and the
+    statistics tail are one allocation (rasterizer.window_grad_span), packed otherwise; a rank WITHOUT views contributes
+    zeros in the same layout (world size > window size: ranks 5..7 of 8 on a 5-view window)."""
+    from splatloc_amd.frame_parallel import reduce_step
+    from splatloc_amd.rasterizer import window_grad_layout, window_grad_span
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, C = 1001, 4                         # odd P: alignment padding between the pieces
+        shapes, offs, total = window_grad_layout(P, C)
+        assert list(shapes) == ["m3", "op", "col", "sca", "rot"] and total % 4 == 0
+        calls = []
+        real = dist.all_reduce
+
+        def counting(*a, **k):
+            calls.append(k.get("op", a[1] if len(a) > 1 else None))
+            return real(*a, **k)
+
+        dist.all_reduce = counting
+        try:
+            # rank 0 "rendered" (values 1..), rank 1 had no views: zeros in the same layout
+            sp = window_grad_span(P, C, "cpu", tail=True, zero=(rank == 1))
+            assert sp["flat"].numel() == total + 2 * P and sp["tail"].shape == (2, P, 1)
+            assert sp["tail"].data_ptr() == sp["flat"].data_ptr() + 4 * total
+            if rank == 0:
+                for k in ("m3", "op", "col", "sca", "rot"):
+                    sp[k].fill_(2.0)
+                sp["tail"][0].fill_(0.5)
+                sp["tail"][1].fill_(1.0)
+            grads = [sp[k] for k in ("m3", "col", "op", "sca", "rot")]
+            max_r = torch.full((P,), float(rank * 7))
+            seen = torch.zeros(P)
+            seen[rank::2] = 1.0
+            reduce_step(grads, [sp["tail"][0], sp["tail"][1]], [max_r], None)       # first call: + the one-off layout checks
+            n_first = len(calls)
+            calls.clear()
+            for k in ("m3", "op", "col", "sca", "rot"):
+                sp[k].fill_(2.0 if rank == 0 else 0.0)
+            sp["tail"][0].fill_(0.5 if rank == 0 else 0.0)
+            sp["tail"][1].fill_(1.0 if rank == 0 else 0.0)
+            g, e, info = reduce_step(grads, [sp["tail"][0], sp["tail"][1]], [max_r, seen], None)
+            assert info["collectives"] == 2 and info["sum_path"] == "in-place span", info
+            assert len(calls) == 3 and n_first >= 3, (calls, n_first)   # SUM + MAX (+ one layout check: [max_r | seen] is a new length)
+            assert all(a is b for a, b in zip(g, grads))
+            assert all(torch.all(t == 2.0) for t in g) and torch.all(e[0] == 0.5) and torch.all(e[1] == 1.0)
+            assert torch.all(max_r == 7.0) and torch.all(seen == 1.0)
+            assert info["sum_bytes"] == 4 * (total + 2 * P)
+            calls.clear()
+            # gradients that are NOT one allocation (map_step: they went through the fused activations' backward) are
+            # packed by one cat and handed back as views of the reduced buffer
+            gs = [torch.full((P, 3), float(rank + 1)), torch.full((P, 1, 3), float(rank + 1)), torch.zeros(P, 0, 3),
+                  torch.full((P, 1), float(rank + 1))]
+            inc = torch.full((2, P, 1), float(rank))
+            g2, e2, info2 = reduce_step(gs, [inc[0], inc[1]], [max_r], None)
+            assert info2["collectives"] == 2 and info2["sum_path"] == "packed"
+            assert all(torch.all(t == 3.0) for t in g2 if t.numel()) and g2[2].shape == (P, 0, 3)
+            assert g2[1].shape == (P, 1, 3) and torch.all(e2[0] == 1.0)
+            assert g2[0].untyped_storage().data_ptr() == g2[3].untyped_storage().data_ptr()
+            # ranks that disagree on the layout are refused, not summed
+            bad = [torch.zeros(10 + rank)]
+            try:
+                reduce_step(bad, [], [], None)
+                raised = False
+            except RuntimeError as ex:
+                raised = "disagree" in str(ex)
+            assert raised
+        finally:
+            dist.all_reduce = real
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reduce_step_two_collectives_gloo_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_reduce_step_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: 1, 1: 1}
+
+
+def test_reduce_step_single_process_is_a_noop():
+    from splatloc_amd.frame_parallel import reduce_step
+    t, e, m = torch.ones(4, 3), torch.ones(4, 1), torch.ones(4)
+    g, x, info = reduce_step([t], [e], [m])
+    assert g[0] is t and x[0] is e and info["collectives"] == 0
+
+
+def test_empty_window_is_not_an_error():
+    """A rank without views (world size > window size) renders nothing: render_window returns ([], []) before any launch
+    and rasterize_window([]) returns [] (round-3 advisor finding: IndexError on settings[0], the other ranks hang in the
+    collective)."""
+    import types
+    from splatloc_amd.fused import render_window
+    from splatloc_amd.rasterizer import _window_compatible, rasterize_window
+    assert _window_compatible([]) is True
+    assert rasterize_window([], torch.zeros(3, 3), [], torch.zeros(3, 4), torch.zeros(3, 1), scales=torch.zeros(3, 3),
+                            rotations=torch.zeros(3, 4)) == []
+    pc = types.SimpleNamespace(_xyz=torch.zeros(3, 3))      # CPU tensors: nothing may be launched (no CPU fallback exists)
+    assert render_window([], pc, types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False),
+                         torch.zeros(3)) == ([], [])
+
+
+def test_bench_gpus_flag_launches_ranks_or_refuses(monkeypatch):
+    """bench.py --gpus N without a launcher starts N ranks as a child process (round-3 verdict: args.gpus was never read);
+    with RCCL and fewer GPUs than ranks it refuses (exit code 2) instead of measuring fewer GPUs than it reports."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, cwd=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=0)
+
+    import types
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("SPLATLOC_DIST_BACKEND", "gloo")
+    assert bench.launch_ranks(2, ["--gpus", "2", "--steps", "3"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("SPLATLOC_DIST_BACKEND", "nccl")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    seen.clear()
+    assert bench.launch_ranks(8, ["--gpus", "8"]) == 2 and not seen
+    # under a launcher whose world size is not what --gpus says, the run is refused
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    monkeypatch.undo()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

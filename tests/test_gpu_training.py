@@ -152,9 +152,49 @@ def test_bench_two_ranks_on_one_gpu_gloo(scaling):
     assert out["config"]["frames_per_step"] == (4 if scaling == "weak" else 3)
     assert out["config"]["views_on_rank0_per_step"] == 2          # weak: its own 2; strong: views 0 and 2 of 3
     path = out["config"]["grad_allreduce_path"]
-    assert path["spans"] == 1 and path["buckets"] == 0, path     # the gradients were reduced where the backward left them
+    # the gradients AND the statistics increments were reduced where the backward left them, as ONE SUM; + ONE MAX
+    assert path["sum_path"] == "in-place span" and path["collectives"] == 2, path
+    assert out["rccl_ranks"] == 2 and out["collectives_per_step"] == 2 and out["reduce_path"] == "in-place span"
+    assert out["repeats"]["regions"] == 5 and len(out["repeats"]["ms_per_step_all"]) == 5
     assert out["value"] > 0 and out["steps"] == 3 and "roofline" in out and "cpu_baseline" not in out
     assert len(set(out["config"]["tile_instances_R_per_view"])) == 2   # different cameras -> different lists
+
+
+def test_bench_gpus_flag_alone_launches_the_ranks():
+    """`python bench.py --gpus 2` — the form of the driver's command, NO launcher around it — must start 2 ranks itself
+    (round-3 verdict: `--gpus` was parsed and never read; the run printed n_gpus: 1).  gloo, both ranks on cuda:0.  One view in
+    strong mode: rank 1 has NO view and contributes zeros in the layout of rank 0's backward (world size > window size)."""
+    env = dict(os.environ, SPLATLOC_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "S0",
+           "--no-cpu-baseline", "--views", "1", "--scaling", "strong", "--repeats", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["frames_per_step"] == 1
+    assert out["collectives_per_step"] == 2 and out["reduce_path"] == "in-place span"
+    assert out["value"] > 0
+
+
+def test_replicas_stay_bit_identical_when_a_rank_has_no_view():
+    """Round-3 advisor finding: with more ranks than views (8 GPUs, 5-view window) a rank without work raised before the
+    collectives and the others hung.  2 ranks, windows of ONE view: rank 1 renders nothing, contributes zeros, takes the same
+    optimizer / densify / reset steps, and ends bit-identical to rank 0."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SPLATLOC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "replica_check.py"), "--steps", "4",
+           "--window", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-2500:])
+    out = json.loads(lines[0])
+    assert out["world"] == 2 and out["identical"] and not out["mismatched"] and out["window"] == 1
+    assert out["collectives_per_step"] == 2
 
 
 def test_replicas_stay_bit_identical_through_map_steps_densify_and_reset():
@@ -174,6 +214,7 @@ def test_replicas_stay_bit_identical_through_map_steps_densify_and_reset():
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-2500:])
     out = json.loads(lines[0])
     assert out["world"] == 2 and out["identical"] and not out["mismatched"]
+    assert out["collectives_per_step"] == 2                             # ONE SUM [grads | statistics] + ONE MAX [radii | seen]
     assert out["rows_per_step"][1] != out["rows_per_step"][0]           # the densification really changed the model
     assert out["tensors_compared"] >= 25
 

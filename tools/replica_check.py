@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--P", type=int, default=20000)
+    ap.add_argument("--window", type=int, default=5, help="views per window (1: every rank but the first has no work)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -37,6 +38,7 @@ def main():
     from splatloc_amd.camera import PinholeCamera
     from splatloc_amd.optim import Adam
     from splatloc_amd.synthetic import make_scene
+    from splatloc_amd import training
     from splatloc_amd.training import map_step
     W, H, P = 320, 240, args.P
     sc = make_scene(P, W, H, 4, seed=77, scale_median=0.03)
@@ -73,11 +75,12 @@ def main():
     pipe = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
     cfg = {"Training": {"rgb_boundary_threshold": 0.01, "primitive_reg": True}}
     dens = dict(grad_threshold=0.0002, min_opacity=0.005, extent=6.0, size_threshold=20, every=3, offset=2)
-    rows = []
+    rows, colls = [], []
     for it in range(1, args.steps + 1):
-        perm = torch.randperm(len(views), generator=torch.Generator().manual_seed(1000 + it))[:5]   # the same draw on every rank
+        perm = torch.randperm(len(views), generator=torch.Generator().manual_seed(1000 + it))[:args.window]   # the same draw on every rank
         map_step([views[i] for i in perm], pc, pipe, bg, cfg, it, densify=dens, gaussian_reset=4, seed=9)
         rows.append(int(pc._xyz.shape[0]))
+        colls.append(training.LAST_STEP_INFO.get("collectives"))
     torch.cuda.synchronize(dev)
     digest = {}
     h = lambda t: hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()  # noqa: E731
@@ -102,7 +105,8 @@ def main():
         bad = []
     if rank == 0:
         print(json.dumps({"world": world, "steps": args.steps, "rows_per_step": rows, "identical": ok, "mismatched": bad,
-                          "tensors_compared": len(digest)}), flush=True)
+                          "tensors_compared": len(digest), "window": args.window,
+                          "collectives_per_step": (max(c for c in colls if c is not None) if world > 1 else 0)}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
