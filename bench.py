@@ -613,6 +613,114 @@ def bench_refine_step(args, dev):
     }), flush=True)
 
 
+def bench_scene(args, dev):
+    """--stage scene: the reference's WHOLE reconstruction schedule as one run (train_gaussians.py:310-355 `do_recon`;
+    splatloc_amd.scene.do_recon): `--keyframes` synthetic RGB-D key-frames at the reference's frame size (640x480, Replica
+    intrinsics) x (extend_from_pcd_seq + 10 map iterations, densify_and_prune every 150 / offset 50), then `--refine`
+    colour-refinement iterations (the reference: 26 000), save_ply, and the forward-only eval_rendering loop with device
+    PSNR / SSIM.  P grows from zero.  Reports wall time per phase next to the figure extrapolated from the per-iteration
+    stage benches.  Secondary figure, not the BASELINE metric."""
+    import tempfile
+    import types
+    from splatloc_amd.evaluation import eval_rendering
+    from splatloc_amd.ply import save_ply
+    from splatloc_amd.scene import DEFAULT_CONFIG, SceneModel, do_recon, synthetic_keyframes
+    K, W, H = args.keyframes, 640, 480
+    t0 = time.perf_counter()
+    frames, _ = synthetic_keyframes(K, W, H, P_truth=200_000, seed=0, device=dev)
+    torch.cuda.synchronize(dev)
+    t_data = time.perf_counter() - t0
+    pipe = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
+    bg = torch.zeros(3, device=dev)
+    model = SceneModel(DEFAULT_CONFIG, dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    t1 = time.perf_counter()
+    stats = do_recon(model, frames, pipe, bg, DEFAULT_CONFIG, refine_iterations=args.refine, seed=0, batched=not args.no_window)
+    t_recon = time.perf_counter() - t1
+    with tempfile.TemporaryDirectory() as td:
+        t2 = time.perf_counter()
+        save_ply(model, os.path.join(td, "point_cloud.ply"))
+        t_ply = time.perf_counter() - t2
+        ply_bytes = os.path.getsize(os.path.join(td, "point_cloud.ply"))
+    t3 = time.perf_counter()
+    ev = eval_rendering(frames, model, [f.original_image for f in frames], pipe, bg, window=5)
+    torch.cuda.synchronize(dev)
+    t_eval = time.perf_counter() - t3
+    map_ms = 1e3 * stats["map_seconds"] / max(stats["map_iterations"], 1)
+    ref_ms = 1e3 * stats["refine_seconds"] / max(stats["refine_iterations"], 1)
+    print(json.dumps({
+        "metric": "SplatLoc.do_recon scenes/hour on synthetic key-frames (whole schedule; secondary figure, NOT the BASELINE metric)",
+        "value": round(3600.0 / t_recon, 3), "unit": "scenes/h", "n_gpus": 1, "steps": 1, "warmup": 0,
+        "ms_per_step": round(1e3 * t_recon, 1), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{K} key-frames {W}x{H} (Replica intrinsics) of a 200k-Gaussian synthetic room; per key-frame "
+                               "extend_from_pcd_seq + 10 map iterations (window 5, densify every 150 offset 50, reset every 2001); "
+                               f"{args.refine} color_refinement iterations; save_ply; eval_rendering",
+                   "launch_mode": "per-view calls" if args.no_window else "window-batched"},
+        "seconds": {"synthetic_keyframes": round(t_data, 2), "map_phase": round(stats["map_seconds"], 2),
+                    "refine_phase": round(stats["refine_seconds"], 2), "save_ply": round(t_ply, 3), "eval_rendering": round(t_eval, 3)},
+        "map_ms_per_iteration": round(map_ms, 3), "refine_ms_per_iteration": round(ref_ms, 4),
+        "refine_26000_iterations_s_extrapolated_from_this_run": round(26000 * ref_ms / 1e3, 1),
+        "rows_after_keyframe": stats["rows_after_keyframe"], "rows_final": stats["rows_final"],
+        "densifications": stats["densify_rows"], "peak_memory_GB": round(stats["peak_memory_bytes"] / 2 ** 30, 3),
+        "ply_bytes": ply_bytes,
+        "eval": {"mean_psnr": round(ev["mean_psnr"], 3), "mean_ssim": round(ev["mean_ssim"], 4), "frames": ev["frames"],
+                 "frames_per_s": round(ev["frames"] / t_eval, 1)},
+    }), flush=True)
+
+
+def bench_eval_rendering(args, dev):
+    """--stage eval_rendering: the reference's eval loop (utils/eval_utils.py:22-72; BASELINE config 4's stand-in)
+    at the 12-Scenes intrinsics (configs/scenes12/base_config.yaml:17-27: 640x480, fx = fy = 572, cx = 320, cy = 240):
+    forward-only renders under no_grad + clamp + PSNR (masked) + SSIM per frame, as windows of 5 frames
+    (splatloc_amd.evaluation.eval_rendering) and frame by frame (the reference's loop), on S2's 500k Gaussians with
+    SplatLoc's [rgb | kp_score] layout.  Secondary figure, not the BASELINE metric."""
+    import types
+    from splatloc_amd.camera import PinholeCamera
+    from splatloc_amd.evaluation import eval_rendering
+    from splatloc_amd.synthetic import make_workload
+    sc = make_workload("S2-ref-layout")
+    P = int(sc.means3D.shape[0])
+    W, H, fx, cx, cy = 640, 480, 572.0, 320.0, 240.0
+    par = lambda t: torch.nn.Parameter(t.to(dev).contiguous())  # noqa: E731
+    pc = types.SimpleNamespace(
+        _xyz=par(sc.means3D.clone()), _features_dc=par(((sc.features[:, :3] - 0.5) / 0.28209479177387814)[:, None, :].contiguous()),
+        _features_rest=par(torch.zeros(P, 0, 3)), _opacity=par(torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4))),
+        _kp_score=par(sc.features[:, 3:4].clone()), _scaling=par(torch.log(sc.scales)), _rotation=par(sc.rotations.clone()),
+        active_sh_degree=0, max_sh_degree=0)
+    g = torch.Generator().manual_seed(21)
+    frames, gts = [], []
+    for k in range(40):
+        ang = torch.tensor(0.015 * (k - 20))
+        R = torch.tensor([[torch.cos(ang), 0, torch.sin(ang)], [0, 1, 0], [-torch.sin(ang), 0, torch.cos(ang)]])
+        frames.append(PinholeCamera(W, H, fx, fx, cx, cy, R, torch.tensor([0.01 * k, 0.0, 0.0])).to(dev))
+        gts.append(torch.rand(3, H, W, generator=g).to(dev))
+    pipe = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
+    bg = torch.zeros(3, device=dev)
+
+    def time_it(window):
+        for _ in range(max(args.warmup, 1)):
+            eval_rendering(frames, pc, gts, pipe, bg, window=window)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = eval_rendering(frames, pc, gts, pipe, bg, window=window)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / args.steps, out
+
+    s5, out5 = time_it(5)
+    s1, out1 = time_it(1)
+    assert out5["psnr"] == out1["psnr"] and out5["ssim"] == out1["ssim"]       # bit-identical images either way
+    print(json.dumps({
+        "metric": "eval_rendering frames/s (forward only + PSNR + SSIM; secondary figure, NOT the BASELINE metric)",
+        "value": round(len(frames) / s5, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * s5, 3), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"P={P} Gaussians, {W}x{H}, fx = fy = {fx} (12-Scenes), C = 4 ([rgb | kp_score]); 40 frames per pass; "
+                               "render under no_grad + clamp + masked PSNR + SSIM per frame; windows of 5 frames"},
+        "frame_by_frame_loop": {"frames_per_s": round(len(frames) / s1, 1), "ms_per_pass": round(1e3 * s1, 3)},
+        "mean_psnr": round(out5["mean_psnr"], 4), "mean_ssim": round(out5["mean_ssim"], 5),
+    }), flush=True)
+
+
 def launch_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) as a FRESH child process —
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <same args>` — and return
@@ -659,6 +767,8 @@ def main():
     ap.add_argument("--no-multi-stream", action="store_true", help="skip the secondary legs (per-view loop, multi-stream) (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
+    ap.add_argument("--keyframes", type=int, default=20, help="--stage scene: key-frames of the synthetic scene")
+    ap.add_argument("--refine", type=int, default=2000, help="--stage scene: color_refinement iterations (the reference: 26000)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of K steps is repeated this many times; value = the MEDIAN region (min / max reported)")
     ap.add_argument("--stage", default="raster",
@@ -691,10 +801,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.stage in ("activations", "loss", "map_step", "refine_step"):
+    if args.stage in ("activations", "loss", "map_step", "refine_step", "scene", "eval_rendering"):
         if rank == 0:
             {"activations": bench_activations, "loss": bench_loss, "map_step": bench_map_step,
-             "refine_step": bench_refine_step}[args.stage](args, dev)
+             "refine_step": bench_refine_step, "scene": bench_scene, "eval_rendering": bench_eval_rendering}[args.stage](args, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -847,14 +957,15 @@ def main():
     # (2) timed region: only the dominant kernel is bracketed (roofline.achieved is measured live
     #     here, on the launch stream)
     _native.timing_select([dom])
-    regions = []
+    regions, regions_unix = [], []
     for _ in range(max(args.repeats, 1)):       # every region: barrier + synchronize, EXACTLY K steps, barrier + synchronize
         barrier()
-        t0 = time.perf_counter()
+        t0, u0 = time.perf_counter(), time.time()
         for _ in range(args.steps):
             step()
         barrier()
         regions.append(time.perf_counter() - t0)
+        regions_unix.append([u0, time.time()])
     _native.timing_enable(False)
     stages[dom] = _native.timing_collect()[dom]
     if world > 1:       # MAX over the ranks, region by region
@@ -943,6 +1054,7 @@ def main():
                         "frames_per_s_min": round(frames_per_step * args.steps / max(regions), 3),
                         "frames_per_s_max": round(frames_per_step * args.steps / min(regions), 3),
                         "ms_per_step_all": [round(1e3 * r / args.steps, 4) for r in regions]},
+            "timed_regions_unix": [[round(a, 3), round(b, 3)] for a, b in regions_unix],   # for tools/clock_trace.py
             "config": {"workload": f"{args.workload}: P={P} Gaussians, {W}x{H}, C={C} channels "
                                    f"(3 RGB + {C - 3} feature) + depth + alpha, seed {wl['seed']}; "
                                    f"{args.views} different cameras per window",

@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 6
+#define SPLATRASTER_ABI_VERSION 7
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
@@ -222,9 +222,11 @@ int splatraster_forward_window_render(const splatraster_settings* s, int32_t n_v
                                       const int64_t* num_rendered, const float* bg, const float* colors_precomp,
                                       void* geometry, void* binning, void* image, void* stream);
 /* Backward of the whole window: the parameter gradients are the SUM over the views (written once, overwritten),
- * dL_dmeans2D per view. */
+ * dL_dmeans2D per view.  `bg`: the background the forward was given (or NULL = zeros); read only by the deterministic /
+ * accurate debug mode, which rebuilds the suffix sum's exact tail T_final (bg . g - g_A) instead of taking it from the
+ * forward's images (splatraster_debug_set_deterministic). */
 int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
-                                int32_t P, const int64_t* num_rendered, const float* means3D,
+                                int32_t P, const int64_t* num_rendered, const float* bg, const float* means3D,
                                 const float* colors_precomp, const float* scales, const float* rotations,
                                 const float* cov3D_precomp, void* geometry, const void* binning, const void* image,
                                 float* dL_dmeans3D,   /* [P,3] */
@@ -449,6 +451,15 @@ int splatraster_refinement_loss(int32_t channels, int32_t height, int32_t width,
                                 const float* image, const float* gt, float* g_image, float* out /* [3] */,
                                 void* workspace, void* stream);
 
+/* Per-frame metrics of eval_rendering (utils/eval_utils.py:45-52): image = clamp(render, 0, 1), mask = gt > 0 per element,
+ *   psnr = 20 log10(1 / sqrt(mean_{mask} (image - gt)^2))   (gaussian_splatting/utils/image_utils.py:19-21)
+ *   ssim = ssim(image, gt)                                  (loss_utils.py:61-102)
+ * render, gt: [C,H,W] (render is clamped on load; nothing is written back).  out[4] = { psnr, ssim, masked mse, mask count }
+ * (device).  LPIPS (a learned network, torchmetrics) is not part of this library. */
+size_t splatraster_eval_metrics_workspace_bytes(int32_t channels, int32_t height, int32_t width);
+int splatraster_eval_metrics(int32_t channels, int32_t height, int32_t width, const float* render, const float* gt,
+                             float* out /* [4] */, void* workspace, void* stream);
+
 /* ---- simple_knn._C.distCUDA2 (gaussian_model.py:206) ---------------------------------- */
 
 size_t splatknn_workspace_bytes(int32_t N);
@@ -498,12 +509,19 @@ int splatraster_poll_errors(void);
 /* test hooks: SOFT spin bound of the look-backs (default 1 << 24; 0 makes every block that has to wait at
  * all report), and y[i] = the device's 2^x (the alpha arithmetic shared with the CPU oracle). */
 int splatraster_debug_set_spin_limit(uint32_t limit);
-/* Deterministic-sum debug mode of the backward (process-wide switch, default off).  The compositing
+/* Deterministic AND accurate debug mode of the backward (process-wide switch, default off).  The compositing
  * backward sums per-(wave, Gaussian) partials into per-Gaussian rows with float atomics, whose arrival
- * order — and therefore the last bits of every gradient — changes from run to run.  With the switch on,
- * each partial is converted to 2^-40 fixed point and accumulated with 64-bit INTEGER atomics (associative:
- * the totals are bit-reproducible; range +-8.4e6, resolution 9.1e-13), then converted back.  ~10 % slower;
- * meant for regression hunting and strict tests (tests/test_gpu_parity.py). */
+ * order — and therefore the last bits of every gradient — changes from run to run; and its front-to-back formulation
+ * carries the suffix sum S_i = S_total - sum_{j<=i} w_j q_j in float32 (an absolute error of ~1e-7 |S_total| that is up to
+ * 1e-3 of the S_i of a Gaussian behind T = 1e-4).  With the switch on,
+ *   (1) each partial is converted to fixed point and accumulated with 64-bit INTEGER atomics (associative: the totals are
+ *       bit-reproducible); the fixed point is chosen PER ELEMENT, 2^-44 of the largest partial the element receives
+ *       (a first pass of the kernel takes that maximum, also an associative reduction);
+ *   (2) S_total is rebuilt in double from the very terms w_j q_j the main pass subtracts again (a replay pass over the
+ *       list inside the kernel) plus the exact tail T_final (bg . g - g_A), and S, dL/dalpha are carried in double.
+ * Every gradient row then agrees with the CPU oracle (double accumulation) to float rounding of the per-pixel terms,
+ * relative to the ROW's own magnitude (tests/test_gpu_window.py, full size).  ~4 x slower: four list traversals.
+ * Meant for regression hunting and strict tests. */
 int splatraster_debug_set_deterministic(int on);
 /* A/B hook: launches of the C = 4..15 backward with at most this many quadrant-waves take the small-layout panel
  * variant; < 0 restores the built-in default. */

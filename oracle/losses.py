@@ -97,3 +97,25 @@ def refinement_loss(image, gt, lambda_dssim: float = 0.2):
     dssim_dx = (_blur(dm_dmu1, w) + 2 * x * _blur(dm_ds1, w) + y * _blur(dm_ds12, w)) / n
     grad = (1.0 - lambda_dssim) * np.sign(x - y) / n - lambda_dssim * dssim_dx
     return dict(l1=l1, ssim=ssim, loss=(1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim), dL_dimage=grad)
+
+
+def eval_metrics(render, gt):
+    """Per-frame metrics of the reference's eval_rendering (utils/eval_utils.py:45-52):
+
+        image = torch.clamp(rendering, 0.0, 1.0);  mask = gt_image > 0                       (per ELEMENT)
+        psnr  = 20 log10(1 / sqrt(mean((image[mask] - gt[mask])^2)))      gaussian_splatting/utils/image_utils.py:19-21
+        ssim  = ssim(image, gt)                                           loss_utils.py:61-102 (11x11 window, zero padding)
+
+    float64 restatement (the window is the reference's float32 window); pinned by tests/golden/eval_rendering.npz, recorded
+    from the reference's own render / psnr / ssim.  Returns dict(psnr, ssim, mse, count)."""
+    x = np.clip(np.asarray(render, np.float64), 0.0, 1.0)
+    y = np.asarray(gt, np.float64)
+    mask = y > 0
+    count = int(mask.sum())
+    mse = float(((x[mask] - y[mask]) ** 2).mean()) if count else float("nan")
+    w = gaussian_window().astype(np.float64)
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    mu1, mu2 = _blur(x, w), _blur(y, w)
+    sig1, sig2, sig12 = _blur(x * x, w) - mu1 * mu1, _blur(y * y, w) - mu2 * mu2, _blur(x * y, w) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + C1) * (2 * sig12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (sig1 + sig2 + C2))
+    return dict(psnr=20.0 * np.log10(1.0 / np.sqrt(mse)) if count else float("nan"), ssim=float(m.mean()), mse=mse, count=count)

@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 6   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 7   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 WARN_LOOKBACK_STALL = 5   # splatraster_poll_errors() only; not an error of any frame
@@ -93,7 +93,7 @@ SYMBOLS = {
     "splatraster_forward_window_render": (C.c_int, [C.POINTER(Settings), _i32, C.POINTER(WindowView), _i32, C.POINTER(_i64)]
                                           + [_vp] * 6),
     "splatraster_backward_window": (C.c_int, [C.POINTER(Settings), _i32, C.POINTER(WindowView), _i32, C.POINTER(_i64)]
-                                    + [_vp] * 15),
+                                    + [_vp] * 16),
     "splatraster_get_window_geometry_layout": (C.c_int, [_i32, _i32, C.POINTER(GeometryLayout)]),
     "splatraster_get_window_binning_layout": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _i32, C.POINTER(BinningLayout)]),
     "splatraster_get_window_image_layout": (C.c_int, [_i32, _i32, _i32, C.POINTER(ImageLayout)]),
@@ -130,6 +130,8 @@ SYMBOLS = {
     "splatraster_mapping_loss": (C.c_int, [_i32] + [_vp] * 6 + [C.c_float] + [_vp] * 7),
     "splatraster_refinement_loss_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "splatraster_refinement_loss": (C.c_int, [_i32, _i32, _i32, C.c_float] + [_vp] * 6),
+    "splatraster_eval_metrics_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "splatraster_eval_metrics": (C.c_int, [_i32, _i32, _i32] + [_vp] * 5),
     "splatraster_error_string": (C.c_char_p, [C.c_int]),
     "splatraster_last_hip_error": (C.c_char_p, []),
     "splatraster_abi_version": (C.c_int, []),

@@ -499,7 +499,7 @@ static int window_render(const splatraster_settings* s, int32_t V, const splatra
 // Backward of the window: one compositing grid over the V views into per-(view, Gaussian) accumulator rows, then
 // ONE per-Gaussian pass that sums the views into a single set of parameter gradients.
 static int window_backward(const splatraster_settings* s, int32_t V, const splatraster_window_view* views, int32_t P,
-                           int64_t R, const float* means3D, const float* shs, const float* colors_precomp,
+                           int64_t R, const float* bg, const float* means3D, const float* shs, const float* colors_precomp,
                            const float* scales, const float* rotations, const float* cov3D_precomp, void* geometry,
                            const void* binning, const void* image, float* dL_dmeans3D, float* dL_dcolors,
                            float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
@@ -562,12 +562,16 @@ static int window_backward(const splatraster_settings* s, int32_t V, const splat
     if (det) {
         SR_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&gacc64), sizeof(long long) * gacc_n, stream));
         SR_HIP_CHECK(hipMemsetAsync(gacc64, 0, sizeof(long long) * gacc_n, stream));
-    } else {
-        SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * gacc_n, stream));
     }
+    SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * gacc_n, stream));
+    grads.bg = bg;
+    grads.bg_channels = bg ? s->bg_channels : 0;
     {
         StageTimer t(SPLATRASTER_STAGE_COMPOSITE_BWD, stream);
-        st = launch_composite_bwd(*s, P, V, R, g, b, im, (C % 4) ? b.featp : feat, C, grads, b.gacc, gacc64, stream);
+        // deterministic mode: the kernel runs twice — per-element max of |partial| (into the zeroed float rows), then the
+        // fixed-point sums scaled by that maximum (composite_bwd.hip acc_add)
+        if (det) st = launch_composite_bwd(*s, P, V, R, g, b, im, (C % 4) ? b.featp : feat, C, grads, b.gacc, gacc64, 0, stream);
+        if (!st) st = launch_composite_bwd(*s, P, V, R, g, b, im, (C % 4) ? b.featp : feat, C, grads, b.gacc, gacc64, 1, stream);
     }
     if (det) {
         if (!st) st = launch_fixed_to_float((int64_t)gacc_n, gacc64, b.gacc, stream);
@@ -625,7 +629,7 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
                          float* dL_drotations, float* dL_dcov3D, float* dL_dshs, float* dL_dviewmatrix,
                          float* dL_dprojmatrix, float* dL_dcampos, void* stream_)
 {
-    (void)bg; (void)opacities; (void)out_alpha;
+    (void)opacities; (void)out_alpha;
     if (!s) return SPLATRASTER_ERR_BAD_ARG;
     splatraster_window_view w{};
     w.viewmatrix = viewmatrix; w.projmatrix = projmatrix; w.campos = campos;
@@ -633,7 +637,7 @@ int splatraster_backward(const splatraster_settings* s, int32_t P, int64_t R, co
     w.out_color = const_cast<float*>(out_color); w.out_depth = const_cast<float*>(out_depth);
     w.dL_dout_color = dL_dout_color; w.dL_dout_depth = dL_dout_depth; w.dL_dout_alpha = dL_dout_alpha;
     w.dL_dmeans2D = dL_dmeans2D;
-    return window_backward(s, 1, &w, P, R, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, geometry, binning,
+    return window_backward(s, 1, &w, P, R, bg, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, geometry, binning,
                            image, dL_dmeans3D, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, dL_dshs,
                            dL_dviewmatrix, dL_dprojmatrix, dL_dcampos, reinterpret_cast<hipStream_t>(stream_));
 }
@@ -662,7 +666,7 @@ int splatraster_forward_window_render(const splatraster_settings* s, int32_t n_v
 }
 
 int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
-                                int32_t P, const int64_t* num_rendered, const float* means3D, const float* colors_precomp,
+                                int32_t P, const int64_t* num_rendered, const float* bg, const float* means3D, const float* colors_precomp,
                                 const float* scales, const float* rotations, const float* cov3D_precomp, void* geometry,
                                 const void* binning, const void* image, float* dL_dmeans3D, float* dL_dcolors,
                                 float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D, void* stream)
@@ -673,7 +677,7 @@ int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, 
         if (num_rendered[v] < 0) return SPLATRASTER_ERR_BAD_ARG;
         R += num_rendered[v];
     }
-    return window_backward(s, n_views, views, P, R, means3D, nullptr, colors_precomp, scales, rotations, cov3D_precomp,
+    return window_backward(s, n_views, views, P, R, bg, means3D, nullptr, colors_precomp, scales, rotations, cov3D_precomp,
                            geometry, binning, image, dL_dmeans3D, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations,
                            dL_dcov3D, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
 }
@@ -898,6 +902,20 @@ int splatraster_refinement_loss(int32_t channels, int32_t height, int32_t width,
     if (!image || !gt || !g_image || !out || !workspace) return SPLATRASTER_ERR_BAD_ARG;
     return launch_refinement_loss(channels, height, width, lambda_dssim, image, gt, g_image, out, workspace,
                                   reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t splatraster_eval_metrics_workspace_bytes(int32_t channels, int32_t height, int32_t width)
+{
+    if (channels <= 0 || height <= 0 || width <= 0) return 0;
+    return eval_metrics_workspace_bytes(channels, height, width);
+}
+
+int splatraster_eval_metrics(int32_t channels, int32_t height, int32_t width, const float* render, const float* gt, float* out,
+                             void* workspace, void* stream)
+{
+    if (channels <= 0 || height <= 0 || width <= 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (!render || !gt || !out || !workspace) return SPLATRASTER_ERR_BAD_ARG;
+    return launch_eval_metrics(channels, height, width, render, gt, out, workspace, reinterpret_cast<hipStream_t>(stream));
 }
 
 int splatknn_debug_set_grid_min(int32_t n)

@@ -81,6 +81,8 @@ struct WinGrad {                     // backward inputs per view
     const float* dL_dlast[MAX_VIEWS];    // gradient plane of channel C - 1 when it travels apart (null = zeros); see gc
     float* dL_dmeans2D[MAX_VIEWS];       // [P,3] output
     int gc;                              // channel planes behind dL_dcolor: C, or C - 1 (then channel C - 1 reads dL_dlast)
+    const float* bg;                     // background (deterministic / accurate mode only: the exact tail of the suffix sum); may be null
+    int bg_channels;
 };
 
 // ---- opaque buffer views (n = V * P rows) -------------------------------------------------
@@ -211,6 +213,7 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int32_t V, in
                          float* gacc /*[V * P, gacc_row_floats(C)]: dL/dfeature | moments sum E dx, E dy, E dx^2,
                                       E dx dy, E dy^2, E, w g_D*/,
                          long long* gacc64 /*non-NULL: deterministic fixed-point accumulation into this buffer*/,
+                         int det_pass /*deterministic mode: 0 = max pass, 1 = sum pass; else ignored*/,
                          hipStream_t stream);
 // test / A-B hook: frames with at most this many quadrant-waves take the small-layout panel variant of the backward
 // (< 0: the built-in default)
@@ -243,6 +246,10 @@ int launch_mapping_loss(int32_t HW, const float* image, const float* depth, cons
 size_t refinement_loss_workspace_bytes(int32_t C, int32_t H, int32_t W);
 int launch_refinement_loss(int32_t C, int32_t H, int32_t W, float lambda, const float* image, const float* gt,
                            float* g_image, float* out, void* workspace, hipStream_t stream);
+
+size_t eval_metrics_workspace_bytes(int32_t C, int32_t H, int32_t W);
+int launch_eval_metrics(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, float* out, void* workspace,
+                        hipStream_t stream);
 
 int knn_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream);
 size_t knn_workspace_bytes(int32_t N);

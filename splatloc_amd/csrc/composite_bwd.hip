@@ -25,6 +25,8 @@
 //     contributing Gaussians: the weights are parked in a 4-KB LDS panel (one ds_write per
 //     step), the dL/dcolor panel lives in registers for the whole tile, and the contraction
 //     runs on the matrix pipe with v_mfma_f32_16x16x4_f32 — exact fp32 (k-ordered fmaf chain).
+#include <type_traits>
+
 #include "composite_common.h"
 
 #ifndef SR_BWD_FS
@@ -147,17 +149,38 @@ struct BwdCfg {
 
 // Gradient accumulation.  Normal mode: float atomics (memory-side adds; the order in which the quadrant-waves
 // of different tiles reach a Gaussian's row varies from run to run, so sums differ in the last bits).
-// DET (splatraster_debug_set_deterministic): every wave-level partial — itself computed in a fixed order — is
-// converted to 2^-40 fixed point and added with a 64-bit INTEGER atomic: integer addition is associative, so
-// the totals are bit-reproducible whatever the arrival order (range +-8.4e6, resolution 9.1e-13).
-constexpr float DET_SCALE = 1099511627776.0f;   // 2^40
-template <bool DET>
-__device__ __forceinline__ void acc_add(float* gacc, long long* gacc64, size_t idx, float v)
+// DET (splatraster_debug_set_deterministic — the reproducible AND accurate debug mode): every wave-level partial — itself
+// computed in a fixed order — is converted to fixed point and added with a 64-bit INTEGER atomic: integer addition is
+// associative, so the totals are bit-reproducible whatever the arrival order.  Round 4: the fixed point is chosen PER
+// ELEMENT from the largest partial that element receives (round 3 used 2^-40 for everything: a resolution of 9e-13,
+// which is 1e-3 of a gradient of 1e-9 — with mean-reduced losses, dL/dout ~ 1 / (H W), most rows of a 500k-Gaussian
+// scene are that small).  The kernel therefore runs TWICE in this mode:
+//   det_pass 0: atomicMax of the bit pattern of |partial| into the (zeroed) float accumulator — max is associative too;
+//   det_pass 1: partial * 2^(170 - biased exponent of that max) added as int64: |partial| * scale < 2^44, and up to 2^18
+//               partials per element (4 quadrant-waves per tile a Gaussian touches) cannot overflow 2^62; the resolution
+//               is 2^-44 of the element's LARGEST partial — twenty bits below a float's;
+//   fixed_to_float_kernel (preprocess_bwd.hip) reads the same exponent and converts back.
+constexpr int DET_HEADROOM_EXP = 170;   // scale exponent = DET_HEADROOM_EXP - biased exponent of max |partial|
+__device__ __forceinline__ int det_scale_exp(unsigned max_bits)
 {
-    if (DET)
-        atomicAdd(reinterpret_cast<unsigned long long*>(gacc64) + idx, (unsigned long long)__float2ll_rn(v * DET_SCALE));
-    else
+    const int eb = (int)((max_bits >> 23) & 0xffu);
+    return DET_HEADROOM_EXP - (eb > 0 ? eb : 1);
+}
+template <bool DET>
+__device__ __forceinline__ void acc_add(float* gacc, long long* gacc64, size_t idx, float v, int det_pass)
+{
+    if (DET) {
+        if (det_pass == 0) {
+            atomicMax(reinterpret_cast<unsigned*>(gacc) + idx, __float_as_uint(fabsf(v)));
+        } else {
+            const unsigned mb = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(gacc) + idx);
+            const double scaled = ldexp((double)v, det_scale_exp(mb));
+            atomicAdd(reinterpret_cast<unsigned long long*>(gacc64) + idx, (unsigned long long)__double2ll_rn(scaled));
+        }
+    } else {
+        (void)det_pass;
         atomicAdd(gacc + idx, v);
+    }
 }
 
 template <int NC, bool SP, bool AUX>
@@ -176,9 +199,12 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      int MO, long long* __restrict__ gacc64 /*[V * P, GROW] fixed point, DET only*/,
                      const float* __restrict__ ckpt_all /*split launches (common.h; gridDim.y == SPLIT_PARTS): the forward's list
                                                           checkpoints [V][SPLIT_PARTS - 1][NC + 2][H * W], else null*/,
-                     const uint32_t* __restrict__ tile_order /*launch order (binning.hip), or null*/)
+                     const uint32_t* __restrict__ tile_order /*launch order (binning.hip), or null*/,
+                     int det_pass /*DET only: 0 = per-element max of |partial|, 1 = fixed-point sums (acc_add)*/)
 {
     using Cfg = BwdCfg<NC, SP, AUX>;
+    // DET: the suffix sum S and everything derived from it in double (see the replay pass below); else float
+    using ST = typename std::conditional<DET, double, float>::type;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
     constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
     constexpr bool MFMA = Cfg::MFMA, XD = Cfg::XD;
@@ -240,7 +266,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     uint32_t beg = ranges[2 * gtile], end0 = ranges[2 * gtile + 1];
     // split launches: wave blockIdx.y of the quadrant takes part blockIdx.y of the tile's list
     const uint32_t list0 = beg;                                // list positions (n_contrib) count from the tile's first entry
-    const bool split = NC <= 4 && ckpt_all != nullptr;
+    const bool split = !DET && NC <= 4 && ckpt_all != nullptr;   // (the accurate mode starts every list at its head)
     const int seg = split ? (int)blockIdx.y : 0;
     const bool second = seg > 0;                               // starts from a checkpoint
     if (split) {
@@ -254,7 +280,12 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 
     // per-pixel constants
     float g[NC];
-    float S = 0.0f;  // running suffix sum
+    ST S = 0;  // running suffix sum
+    // DET: S_total is NOT taken from the forward's images (out_color . g carries the forward's float32 rounding, an ABSOLUTE
+    // error of ~1e-7 |S_total| that stays in every S_i = S_total - prefix_i and is 1e-3 of an S_i behind T = 1e-4); it is
+    // rebuilt below from the same w_j q_j terms the subtraction removes again, in double, plus the exact tail
+    // T_final (bg . g - g_A).  s_end = bg . g - g_A of this pixel (this pass's channels).
+    double s_end = 0.0;
     float gD = 0.0f;
     uint32_t last = 0;
     if (inside) {
@@ -274,15 +305,20 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             float gv = c < gc ? dL_dcolor[(size_t)c * plane + pix] : (dL_dlast ? dL_dlast[pix] : 0.0f);
             if (c >= gc && c != C_total - 1) gv = 0.0f;
             g[ch] = gv;
-            S += out_color[(size_t)c * plane + pix] * gv;
+            if constexpr (DET) {
+                if (grads.bg && c < grads.bg_channels) s_end += (double)grads.bg[c] * (double)gv;
+            } else {
+                S += out_color[(size_t)c * plane + pix] * gv;
+            }
 #endif
         }
         if (AUX && first_pass) {
             gD = dL_ddepth ? dL_ddepth[pix] : 0.0f;
             const float gA = dL_dalpha ? dL_dalpha[pix] : 0.0f;
-            S += out_depth[pix] * gD - final_T[pix] * gA;
+            if constexpr (DET) s_end -= (double)gA;
+            else S += out_depth[pix] * gD - final_T[pix] * gA;
         }
-        if (NC <= 4) {
+        if constexpr (NC <= 4 && !DET) {
             if (second) {   // S_k = S_total - sum_{j < k part} w_j q_j = S_total - C_k . g - D_k g_D
                 const float* ck = ckpt + pix;
 #pragma unroll
@@ -325,7 +361,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     BP_T(tk0);
 #endif
     float T = 1.0f;
-    if (NC <= 4) { if (second && inside) T = ckpt[pix]; }
+    if constexpr (NC <= 4 && !DET) { if (second && inside) T = ckpt[pix]; }
     // wave_reduce_pack leaves total k in lane bitreverse6(k); values [0, KV) belong to the first
     // Gaussian of a pair, [KV, 2 KV) to the second; inside a Gaussian: NV colours then 7 geometric
     const int slotv = (int)(__brev((unsigned)lane) >> 26);
@@ -376,7 +412,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #if SR_BWD_ABLATE_ATOMIC
                     asm volatile("" ::"v"(rowi + col_off), "v"(D[t][r]));
 #else
-                    if (col_ok) acc_add<DET>(gacc, gacc64, (size_t)(rowi + col_off), D[t][r]);
+                    if (col_ok) acc_add<DET>(gacc, gacc64, (size_t)(rowi + col_off), D[t][r], det_pass);
 #endif
                 }
             }
@@ -418,7 +454,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #if SR_BWD_ABLATE_ATOMIC
                 asm volatile("" ::"v"(di), "v"(outv));
 #else
-                acc_add<DET>(gacc, gacc64, di, outv);
+                acc_add<DET>(gacc, gacc64, di, outv, det_pass);
 #endif
             }
             __builtin_amdgcn_wave_barrier();
@@ -441,6 +477,19 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             x1 = irec[2 * (size_t)j + 1];
         }
     };
+    // DET walks the list TWICE: the replay pass (wave-uniform `replay`) only rebuilds S_total = sum_j w_j q_j + T_final s_end in
+    // double from the very terms the main pass subtracts again; the normal kernel has one pass and none of this code.
+    double s_replay = 0.0;
+    bool replay = DET;
+#pragma unroll 1
+    for (int lpass = DET ? 0 : 1; lpass < 2; ++lpass) {
+    if constexpr (DET) {
+        if (lpass == 1) {
+            S = s_replay + (double)T * s_end;     // T is the replayed final transmittance (= final_T bit for bit)
+            T = 1.0f;
+            replay = false;
+        }
+    }
     fetch(beg, reach, gid, a0, a1);
 
 #pragma unroll 1
@@ -558,13 +607,34 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 // rounded __frcp_rn expanded to a 10-instruction division per Gaussian.  T itself follows
                 // the forward's two-rounding transmit() bit for bit.
                 const float w0 = hit0 ? al0 * T : 0.0f;
-                S = fmaf(-w0, qd0, S);
-                const float dA0 = fmaf(T, qd0, -S * __builtin_amdgcn_rcpf(1.0f - al0));   // (finite also for a miss; E = G dA = 0 there)
-                T = hit0 ? transmit(T, al0) : T;
-                const float w1 = hit1 ? al1 * T : 0.0f;
-                S = fmaf(-w1, qd1, S);
-                const float dA1 = fmaf(T, qd1, -S * __builtin_amdgcn_rcpf(1.0f - al1));
-                T = hit1 ? transmit(T, al1) : T;
+                float dA0, dA1;
+                float w1;
+                if constexpr (DET) {
+                    // accurate mode: the suffix sum and dL/dalpha in double
+                    if (replay) {   // (wave-uniform) only the total of the w_j q_j terms and the transmittance chain
+                        s_replay = fma((double)w0, (double)qd0, s_replay);
+                        T = hit0 ? transmit(T, al0) : T;
+                        const float w1r = hit1 ? al1 * T : 0.0f;
+                        s_replay = fma((double)w1r, (double)qd1, s_replay);
+                        T = hit1 ? transmit(T, al1) : T;
+                        return;
+                    }
+                    S = fma(-(double)w0, (double)qd0, S);
+                    dA0 = (float)fma((double)T, (double)qd0, -S / (1.0 - (double)al0));
+                    T = hit0 ? transmit(T, al0) : T;
+                    w1 = hit1 ? al1 * T : 0.0f;
+                    S = fma(-(double)w1, (double)qd1, S);
+                    dA1 = (float)fma((double)T, (double)qd1, -S / (1.0 - (double)al1));
+                    T = hit1 ? transmit(T, al1) : T;
+                } else {
+                    S = fmaf(-w0, qd0, S);
+                    dA0 = fmaf(T, qd0, -S * __builtin_amdgcn_rcpf(1.0f - al0));   // (finite also for a miss; E = G dA = 0 there)
+                    T = hit0 ? transmit(T, al0) : T;
+                    w1 = hit1 ? al1 * T : 0.0f;
+                    S = fmaf(-w1, qd1, S);
+                    dA1 = fmaf(T, qd1, -S * __builtin_amdgcn_rcpf(1.0f - al1));
+                    T = hit1 ? transmit(T, al1) : T;
+                }
                 const float E0 = G0 * dA0, E1 = G1 * dA1;   // (0 for a miss)
                 const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];
 #ifdef SR_BWD_PROFILE
@@ -619,7 +689,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #if SR_BWD_ABLATE_ATOMIC
                         asm volatile("" ::"v"(di), "v"(outv));
 #else
-                        if (slot_ok && (has1 || !slot_second)) acc_add<DET>(gacc, gacc64, di, outv);
+                        if (slot_ok && (has1 || !slot_second)) acc_add<DET>(gacc, gacc64, di, outv, det_pass);
 #endif
                     }
                 }
@@ -728,6 +798,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             }
         }
     }
+    }   // lpass
     if constexpr (TM) { if (nslot - e0 > 0) reduce_e(nslot - e0); }
     if (MFMA && nslot > 0) flush_panel(nslot);
 #ifdef SR_BWD_PROFILE
@@ -761,6 +832,7 @@ struct BwdLaunch {
     int P, V;
     const WinGrad* grads;
     const float* ckpt;   // non-null: split launch — two waves per quadrant, the second from the forward's mid-list checkpoint
+    int det_pass;        // deterministic mode: 0 = per-element max pass, 1 = fixed-point sum pass (acc_add)
 };
 
 template <int NC, bool DET, bool AUX = true>
@@ -779,7 +851,7 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
                        s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, L.V, L.P,      \
                        b.ranges, b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), *L.grads,       \
                        im.final_T, im.n_contrib, gacc, gacc_row_floats(s.channels),                                    \
-                       gacc_moment_offset(s.channels), gacc64, ckpt, use_tile_order(L.V, tiles) ? b.tile_order : nullptr)
+                       gacc_moment_offset(s.channels), gacc64, ckpt, use_tile_order(L.V, tiles) ? b.tile_order : nullptr, L.det_pass)
     if constexpr (NC >= 4 && NC <= 15 && AUX) {   // C = 3 and below: the flush costs what the 8 saved butterfly values gain (A/B: S0 0.036 vs 0.041 ms)
         // per VIEW: small frames (SplatLoc's 640x480) take the panel variant — also as a window of V views (A/B at the
         // reference layout, 5 views: 0.816 vs 0.869 ms); large frames the butterfly variant at full occupancy
@@ -797,13 +869,13 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
 
 int launch_composite_bwd(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g,
                          const BinView& b, const ImgView& im, const float* feat, int feat_stride,
-                         const WinGrad& grads, float* gacc, long long* gacc64, hipStream_t stream)
+                         const WinGrad& grads, float* gacc, long long* gacc64, int det_pass, hipStream_t stream)
 {
     if (R == 0) return SPLATRASTER_OK;
     const bool det = gacc64 != nullptr;
     int C = s.channels;
     const int tiles_v = ((s.image_width + TILE - 1) / TILE) * ((s.image_height + TILE - 1) / TILE);
-    const BwdLaunch L{P, V, &grads, split_lists(s.channels, V, tiles_v) ? b.ckpt : nullptr};
+    const BwdLaunch L{P, V, &grads, (!det && split_lists(s.channels, V, tiles_v)) ? b.ckpt : nullptr, det_pass};
     // Channels and auxiliary planes that did not reach the loss are not computed: when the last channel's gradient
     // travels apart (grads.gc = C - 1) and NO view has one, the launch covers channels [0, C - 1) only — its dL/dfeature
     // column stays at the zero the accumulator rows were cleared to; without any depth / alpha gradient the RGB kernel

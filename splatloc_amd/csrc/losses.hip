@@ -314,6 +314,138 @@ size_t refinement_loss_workspace_bytes(int32_t C, int32_t H, int32_t W)
     return align_up(3 * sizeof(float) * (size_t)C * H * W, 256) + blocks * 2 * sizeof(double);
 }
 
+// ---------------------------------------------------------------------------------------------
+// eval_rendering's per-frame metrics (utils/eval_utils.py:22-72):
+//     image = clamp(render, 0, 1);  mask = gt > 0 (per element)
+//     psnr  = 20 log10(1 / sqrt(mean_{mask} (image - gt)^2))          gaussian_splatting/utils/image_utils.py:19-21
+//     ssim  = ssim(image, gt)                                          loss_utils.py:61-102 (same window as above)
+// one pass over the frame: the tile loader clamps, the SSIM map is summed (its partial derivatives are not needed),
+// and the masked squared error and the mask count ride in the same block partials (double, deterministic).
+// ---------------------------------------------------------------------------------------------
+constexpr int EVAL_SUMS = 3;   // sum ssim map, sum mask (x - y)^2, sum mask
+
+__global__ void __launch_bounds__(RT * RT)
+eval_metrics_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, RefineWindow win,
+                    double* __restrict__ partial /*[blocks][EVAL_SUMS]*/)
+{
+    __shared__ float s_x[RE][RE + 1], s_y[RE][RE + 1];
+    __shared__ float s_h[5][RE][RT + 1];
+    __shared__ double s_red[RT * RT / WAVE][EVAL_SUMS];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * RT, y0 = blockIdx.y * RT;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int e = tid; e < RE * RE; e += RT * RT) {
+        const int r = e / RE, c = e - r * RE;
+        const int gy = y0 + r - RH, gx = x0 + c - RH;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        s_x[r][c] = in ? fminf(fmaxf(img[plane + (size_t)gy * W + gx], 0.0f), 1.0f) : 0.0f;   // torch.clamp(rendering, 0.0, 1.0)
+        s_y[r][c] = in ? gt[plane + (size_t)gy * W + gx] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = tid; e < RE * RT; e += RT * RT) {
+        const int r = e / RT, c = e - r * RT;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+            const float xv = s_x[r][c + k], yv = s_y[r][c + k], wk = win.w[k];
+            a0 += wk * xv;
+            a1 += wk * yv;
+            a2 += wk * (xv * xv);
+            a3 += wk * (yv * yv);
+            a4 += wk * (xv * yv);
+        }
+        s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2; s_h[3][r][c] = a3; s_h[4][r][c] = a4;
+    }
+    __syncthreads();
+    const int ty = tid / RT, tx = tid - ty * RT;
+    const int gy = y0 + ty, gx = x0 + tx;
+    double acc[EVAL_SUMS] = {0.0, 0.0, 0.0};
+    if (gy < H && gx < W) {
+        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+            const float wk = win.w[k];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) v[q] += wk * s_h[q][ty + k][tx];
+        }
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1 = v[0], mu2 = v[1];
+        const float sig1 = v[2] - mu1 * mu1, sig2 = v[3] - mu2 * mu2, sig12 = v[4] - mu1 * mu2;
+        const float A = 2.0f * mu1 * mu2 + C1, B = 2.0f * sig12 + C2;
+        const float Cc = mu1 * mu1 + mu2 * mu2 + C1, D = sig1 + sig2 + C2;
+        acc[0] = (double)(A * B / (Cc * D));
+        const float x = s_x[ty + RH][tx + RH], y = s_y[ty + RH][tx + RH];
+        if (y > 0.0f) {
+            const float d = x - y;
+            acc[1] = (double)(d * d);
+            acc[2] = 1.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < EVAL_SUMS; ++k) {
+        double t = acc[k];
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) t += __shfl_xor(t, d, WAVE);
+        if ((tid & (WAVE - 1)) == 0) s_red[tid / WAVE][k] = t;
+    }
+    __syncthreads();
+    if (tid < EVAL_SUMS) {
+        double t = 0;
+        for (int w = 0; w < RT * RT / WAVE; ++w) t += s_red[w][tid];
+        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[EVAL_SUMS * bid + tid] = t;
+    }
+}
+
+__global__ void __launch_bounds__(LOSS_BLOCK)
+eval_metrics_finish_kernel(int blocks, double n_total, const double* __restrict__ partial,
+                           float* __restrict__ out /*[4] = psnr, ssim, masked mse, mask count*/)
+{
+    __shared__ double s_red[LOSS_BLOCK / WAVE][EVAL_SUMS];
+    double acc[EVAL_SUMS] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < blocks; i += blockDim.x)
+        for (int k = 0; k < EVAL_SUMS; ++k) acc[k] += partial[EVAL_SUMS * (size_t)i + k];
+#pragma unroll
+    for (int k = 0; k < EVAL_SUMS; ++k) {
+        double t = acc[k];
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) t += __shfl_xor(t, d, WAVE);
+        if ((threadIdx.x & (WAVE - 1)) == 0) s_red[threadIdx.x / WAVE][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[EVAL_SUMS];
+        for (int k = 0; k < EVAL_SUMS; ++k) {
+            t[k] = 0;
+            for (int w = 0; w < LOSS_BLOCK / WAVE; ++w) t[k] += s_red[w][k];
+        }
+        const double mse = t[2] > 0 ? t[1] / t[2] : 0.0 / 0.0;     // an empty mask: the reference's mean over nothing is NaN
+        out[0] = (float)(20.0 * log10(1.0 / sqrt(mse)));
+        out[1] = (float)(t[0] / n_total);
+        out[2] = (float)mse;
+        out[3] = (float)t[2];
+    }
+}
+
+size_t eval_metrics_workspace_bytes(int32_t C, int32_t H, int32_t W)
+{
+    const size_t blocks = (size_t)((W + RT - 1) / RT) * ((H + RT - 1) / RT) * (size_t)C;
+    return blocks * EVAL_SUMS * sizeof(double);
+}
+
+int launch_eval_metrics(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, float* out, void* workspace,
+                        hipStream_t stream)
+{
+    const dim3 grid((W + RT - 1) / RT, (H + RT - 1) / RT, C);
+    const int blocks = (int)(grid.x * grid.y * grid.z);
+    double* partial = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(eval_metrics_kernel, grid, dim3(RT * RT), 0, stream, H, W, image, gt, refine_window(), partial);
+    SR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(eval_metrics_finish_kernel, dim3(1), dim3(LOSS_BLOCK), 0, stream, blocks, (double)C * H * W, partial, out);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
 int launch_refinement_loss(int32_t C, int32_t H, int32_t W, float lambda, const float* image, const float* gt,
                            float* g_image, float* out, void* workspace, hipStream_t stream)
 {

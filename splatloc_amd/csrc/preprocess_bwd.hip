@@ -357,11 +357,16 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
 // dL/dcolors [P, C] out of the 64-byte aligned accumulator rows: one thread per element,
 // contiguous reads inside a row, fully coalesced writes.
 // deterministic debug mode: the fixed-point accumulator rows -> the float rows the kernels below read
+// (dst holds, per element, the bit pattern of the largest |partial| that went into src — composite_bwd.hip acc_add:
+//  the fixed point of the element is 2^-(170 - its biased exponent); the same expression is evaluated here)
 __global__ void __launch_bounds__(256)
 fixed_to_float_kernel(int64_t n, const long long* __restrict__ src, float* __restrict__ dst)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) dst[e] = (float)((double)src[e] * (1.0 / 1099511627776.0));
+    if (e >= n) return;
+    const unsigned mb = reinterpret_cast<const unsigned*>(dst)[e];
+    const int eb = (int)((mb >> 23) & 0xffu);
+    dst[e] = (float)ldexp((double)src[e], -(170 - (eb > 0 ? eb : 1)));
 }
 
 int launch_fixed_to_float(int64_t n, const long long* src, float* dst, hipStream_t stream)

@@ -223,3 +223,42 @@ def reduce_step(grads: Sequence[torch.Tensor], sum_extras: Sequence[torch.Tensor
             outs.append(packed[off:off + n].view(t.shape) if n else t)
             off += n
     return outs[:len(grads)], outs[len(grads):], info
+
+
+def broadcast_model(gaussians, src: int = 0, group=None) -> int:
+    """Re-establish bit-identical replicas from rank `src`: every parameter, Adam moment and step counter, the xyz learning
+    rate and the densification statistics, packed into ONE broadcast.  Used after a phase that every rank ran redundantly on
+    its own replica — SplatLoc.color_refinement is one view per step (train_gaussians.py:269-297): it does not shard, and
+    float-atomic rounding makes redundant replicas drift apart in the last bits.  Returns the bytes broadcast (0 when not
+    distributed)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    opt = gaussians.optimizer
+    tensors, scalars = [], []
+    for grp in opt.param_groups:
+        p = grp["params"][0]
+        tensors.append(p.data)
+        st = opt.state.get(p, None)
+        if st and "exp_avg" in st:
+            tensors += [st["exp_avg"], st["exp_avg_sq"]]
+            scalars.append(("step", st))
+        scalars.append(("lr", grp))
+    tensors += [gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D]
+    dev = tensors[0].device
+    vals = torch.tensor([float(o["step"]) if k == "step" else float(o["lr"]) for k, o in scalars], dtype=torch.float64, device=dev)
+    with torch.no_grad():
+        flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+        _check_same_layout(flat.numel(), dev, group)
+        dist.broadcast(flat, src=src, group=group)
+        dist.broadcast(vals, src=src, group=group)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+    for v, (k, o) in zip(vals.tolist(), scalars):
+        if k == "step":
+            o["step"] = torch.tensor(float(v), dtype=torch.float32) if isinstance(o["step"], torch.Tensor) else v
+        else:
+            o["lr"] = float(v)
+    return flat.numel() * 4

@@ -10,8 +10,11 @@ Adam-state surgery in one launch.  Same outputs as the reference (tests/test_gpu
 tests/golden/keyframe.npz, recorded from the reference's own functions).
 
 The reference down-samples the non-key pixels with `np.random.choice(n_points, n_samples)` (host RNG, with
-replacement); here the draw comes from `generator` (a device torch.Generator) or is given as `sample_idx` (tests: the
-recorded draw).  No CPU fallback: tensors must be on the ROCm device.
+replacement); here the draw is given as `sample_idx` (tests: the recorded draw), comes from `generator`, or — the default —
+from a counter-based host generator keyed by `(seed, kf_id)`: every replica of a frame-parallel job (one process per GPU,
+SURVEY.md §8e) draws the SAME indices without a broadcast, like densify's split noise (round-3 advisor finding: the
+device's global RNG differs from rank to rank and the replicas would diverge silently).  No CPU fallback: tensors must be
+on the ROCm device.
 """
 from __future__ import annotations
 
@@ -37,7 +40,27 @@ def _unproject(cam, rgb, depth, scores, mask, fx, fy, cx, cy, C2W):
     return pw, rgb[mask], scores[mask]
 
 
-def create_pcd_from_image_and_depth_score(gaussians, cam, rgb, depth, scores, sample_idx=None, generator=None):
+def _np_median_f32(depth: torch.Tensor) -> torch.Tensor:
+    """np.median of a float32 array: the middle value, or — for an even count — the mean of the two middle values taken in
+    FLOAT32 (numpy's `mean` of a float32 pair), not the float64 midpoint torch.quantile interpolates; any size."""
+    flat = depth.reshape(-1).to(torch.float32)
+    n = int(flat.numel())
+    srt = torch.sort(flat).values
+    if n % 2:
+        return srt[n // 2]
+    return (srt[n // 2 - 1] + srt[n // 2]) * torch.tensor(0.5, dtype=torch.float32, device=flat.device)
+
+
+def _keyed_draw(n_points: int, n_samples: int, seed: int, kf_id: int) -> torch.Tensor:
+    """`n_samples` indices in [0, n_points) with replacement from a host generator keyed by (seed, kf_id): the same on
+    every rank, independent of any global RNG state."""
+    g = torch.Generator()
+    g.manual_seed((int(seed) * 1_000_003 + int(kf_id) * 7919 + 12345) & 0x7FFFFFFFFFFFFFFF)
+    return torch.randint(0, max(n_points, 1), (n_samples,), generator=g)
+
+
+def create_pcd_from_image_and_depth_score(gaussians, cam, rgb, depth, scores, sample_idx=None, generator=None, seed: int = 0,
+                                          kf_id: int = -1):
     """gaussian_model.py:170-217.  rgb: uint8 [H,W,3] device tensor; depth: float32 [H,W]; scores: [H,W].
     Returns (fused_point_cloud, features, scales, rots, opacities, markers, kp_scores) like the reference."""
     _require_gpu(depth, "depth")
@@ -46,8 +69,8 @@ def create_pcd_from_image_and_depth_score(gaussians, cam, rgb, depth, scores, sa
     downsample_factor = cfg["pcd_downsample"]
     point_size = cfg["point_size"]
     if cfg.get("adaptive_pointsize", False):
-        # min(0.05, point_size * np.median(depth)): np.median averages the two middle values of an even count
-        med = torch.quantile(depth.reshape(-1).to(torch.float64), 0.5, interpolation="midpoint")
+        # min(0.05, point_size * np.median(depth)): np.median averages the two middle values of an even count IN FLOAT32
+        med = _np_median_f32(depth).to(torch.float64)
         point_size = torch.clamp_max(point_size * med, 0.05)
     rgbf = rgb.to(torch.float64) / 255.0
     scores = scores.to(dev)
@@ -61,8 +84,10 @@ def create_pcd_from_image_and_depth_score(gaussians, cam, rgb, depth, scores, sa
     if downsample_factor > 1:
         n_points = int(nk_xyz.shape[0])
         n_samples = int(n_points // downsample_factor)
-        if sample_idx is None:
-            sample_idx = torch.randint(0, max(n_points, 1), (n_samples,), device=dev, generator=generator)   # with replacement
+        if sample_idx is None and generator is not None:
+            sample_idx = torch.randint(0, max(n_points, 1), (n_samples,), device=generator.device, generator=generator)   # with replacement
+        elif sample_idx is None:
+            sample_idx = _keyed_draw(n_points, n_samples, seed, kf_id)
         sample_idx = torch.as_tensor(sample_idx, device=dev, dtype=torch.long)
         if int(sample_idx.numel()) != n_samples:
             raise RuntimeError(f"create_pcd: sample_idx has {int(sample_idx.numel())} entries, expected {n_samples}")
@@ -88,7 +113,7 @@ def create_pcd_from_image_and_depth_score(gaussians, cam, rgb, depth, scores, sa
     return fused_point_cloud, features, scales, rots, opacities, markers, kp_scores
 
 
-def create_pcd_from_image(gaussians, cam_info, depthmap, sample_idx=None, generator=None):
+def create_pcd_from_image(gaussians, cam_info, depthmap, sample_idx=None, generator=None, seed: int = 0, kf_id: int = -1):
     """gaussian_model.py:118-131: exposure affine, clamp, uint8 colours; `depthmap` float32 [H,W] (device tensor)."""
     cam = cam_info
     image_ab = torch.exp(cam.exposure_a) * cam.original_image + cam.exposure_b
@@ -97,13 +122,15 @@ def create_pcd_from_image(gaussians, cam_info, depthmap, sample_idx=None, genera
     depth = torch.as_tensor(depthmap, device=rgb.device, dtype=torch.float32)
     scores = cam.kp_score
     return create_pcd_from_image_and_depth_score(gaussians, cam, rgb.detach(), depth, scores, sample_idx=sample_idx,
-                                                 generator=generator)
+                                                 generator=generator, seed=seed, kf_id=kf_id)
 
 
 def extend_from_pcd_seq(gaussians, cam_info, kf_id=-1, init=False, scale=2.0, depthmap=None, sample_idx=None,
-                        generator=None) -> int:
-    """GaussianModel.extend_from_pcd_seq (gaussian_model.py:243-248; train_gaussians.py:177) on the device."""
+                        generator=None, seed: int = 0) -> int:
+    """GaussianModel.extend_from_pcd_seq (gaussian_model.py:243-248; train_gaussians.py:177) on the device.  The
+    down-sampling draw: `sample_idx`, else `generator`, else keyed by `(seed, kf_id)` (identical on every replica)."""
     from .densify import extend_from_pcd
     with torch.no_grad():
-        tensors = create_pcd_from_image(gaussians, cam_info, depthmap, sample_idx=sample_idx, generator=generator)
+        tensors = create_pcd_from_image(gaussians, cam_info, depthmap, sample_idx=sample_idx, generator=generator, seed=seed,
+                                        kf_id=kf_id)
     return extend_from_pcd(gaussians, *tensors)

@@ -363,6 +363,7 @@ class _RasterizeWindow(torch.autograd.Function):
         ctx.have = (sca is not None, cov is not None)
         none = _empty(dev)
         flat_cams = [t if t is not None else none for cam in cams for t in cam]
+        ctx.bg = bg     # (a setting, not an autograd input; read by the deterministic / accurate debug mode only)
         ctx.save_for_backward(*[t if t is not None else none for t in (m3, col, opa, sca, rot, cov)], radii, geom, binning,
                               img, color, depth, alpha, *flat_cams)
         outs, rad = [], []
@@ -395,7 +396,9 @@ class _RasterizeWindow(torch.autograd.Function):
         span = window_grad_span(P, Cn, dev, have_scales=sca is not None, have_cov=cov is not None,
                                 tail=ctx.grad_span is not None)
         if ctx.grad_span is not None:
-            ctx.grad_span.append(span)
+            # only the whole allocation and its tail: holding the PIECES here would raise their use count and autograd's
+            # AccumulateGrad would then deep-copy them instead of keeping them as the parameters' .grad
+            ctx.grad_span.append({"flat": span["flat"], "tail": span["tail"]})
         d_m3, d_op, d_col, d_sca, d_rot, d_cov = (span[k] for k in ("m3", "op", "col", "sca", "rot", "cov"))
         d_m2 = torch.empty((V, P, 3), **f32)
         views = (_native.WindowView * V)()
@@ -433,7 +436,7 @@ class _RasterizeWindow(torch.autograd.Function):
         R = (C.c_int64 * V)(*ctx.R)
         with _on_device(dev):
             _native.check(lib.splatraster_backward_window(
-                C.byref(st), V, views, P, R, _ptr(m3), _ptr(col), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(geom),
+                C.byref(st), V, views, P, R, _ptr(ctx.bg), _ptr(m3), _ptr(col), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(geom),
                 _ptr(binning), _ptr(img), _ptr(d_m3), _ptr(d_col), _ptr(d_op), _ptr(d_sca), _ptr(d_rot), _ptr(d_cov),
                 _stream(dev)), "backward_window")
         del keep

@@ -98,3 +98,26 @@ def assert_grad_close(name, got, ref, rtol=2e-3, atol_scale=1e-4, allow_frac=0.0
         return
     assert not bad.any(), (f"{name}: {bad.sum()} / {bad.size} elements off; worst abs err "
                            f"{np.abs(got - ref).max():.3e} (scale {scale:.3e})")
+
+
+def assert_grad_rows_close(name, got, ref, rtol=1e-4, row_atol=1e-3, allow_frac=0.0, outlier_factor=10.0):
+    """Per-ROW bar: |got - ref| <= rtol * |ref| + row_atol * max|ref[row]| elementwise — the absolute term is relative to the
+    Gaussian's OWN gradient row (a [P, k] tensor has P rows; a [P, 1] tensor makes it a purely relative bar), so a row a
+    thousand times smaller than the tensor's maximum cannot hide behind it.  Rows whose reference is exactly zero must be
+    exactly zero.  `allow_frac`: fraction of the ELEMENTS that may miss the bar, by at most `outlier_factor` times the
+    tolerance (cancellation: a row sum that is itself the small difference of large pixel terms)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
+    g2, r2 = got.reshape(got.shape[0], -1), ref.reshape(ref.shape[0], -1)
+    rowmax = np.abs(r2).max(axis=1, keepdims=True) if r2.size else np.zeros((0, 1))
+    tol = rtol * np.abs(r2) + row_atol * rowmax
+    err = np.abs(g2 - r2)
+    bad = err > tol
+    if not bad.any():
+        return
+    frac = bad.mean()
+    worst = (err / np.maximum(tol, 1e-300))[bad].max() if (tol[bad] > 0).all() else np.inf
+    assert frac <= allow_frac and worst <= outlier_factor, (
+        f"{name}: {bad.sum()} / {bad.size} elements ({frac:.2e}) beyond rtol {rtol} + {row_atol} x row max "
+        f"(allowed fraction {allow_frac}); worst {worst:.1f} x the tolerance")

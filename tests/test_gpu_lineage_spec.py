@@ -77,7 +77,7 @@ def test_hip_vs_lineage_literal_oracle_mode(name):
     sc = make_workload(name)
     f, b = _mode1(sc)
     run = HipRun(sc)
-    _check_vs_lineage_literal(run, f, b, grad_frac=2e-3)
+    _check_vs_lineage_literal(run, f, b, grad_frac=1e-3)
 
 
 def _dense_case(P, W, H, C, seed, use_sh=False, deg=0, use_cov=False, mod=1.0):
@@ -146,7 +146,7 @@ def test_hip_vs_dense_fp64_autograd(cfg):
     dd = np.abs(run.np(run.depth) - n(depth))[0]
     assert (dd > IMG_TOL * dscale).mean() <= 2e-3 and dd.max() <= 2 * FLIP_STEP * dscale
     # gradients against torch.autograd of the dense restatement
-    kw = dict(allow_frac=5e-3, outlier_factor=100.0)
+    kw = dict(allow_frac=1e-3, outlier_factor=100.0)
     assert_grad_close("dL_dmeans3D", run.np(run.means3D.grad), n(m3.grad), **kw)
     assert_grad_close("dL_dmeans2D", run.np(run.means2D.grad)[:, :2], n(probe.grad), **kw)
     assert float(run.means2D.grad[:, 2].abs().max()) == 0.0

@@ -61,3 +61,18 @@ def test_refinement_loss_matches_reference(name):
 def test_gaussian_window_is_the_reference_window():
     w = losses.gaussian_window()
     assert w.dtype == np.float32 and abs(float(w.sum()) - 1.0) < 1e-6 and w.argmax() == 5 and len(w) == 11
+
+
+def test_eval_metrics_match_reference_eval_rendering():
+    """oracle.losses.eval_metrics against tests/golden/eval_rendering.npz: the per-frame PSNR / SSIM the reference's own
+    `psnr` / `ssim` produced inside the restated loop body of utils/eval_utils.py:44-52 (clamp, per-element mask)."""
+    d = np.load(os.path.join(GOLD, "eval_rendering.npz"))
+    for k in range(3):
+        o = losses.eval_metrics(d[f"view{k}_render"], d[f"view{k}_gt"])
+        assert o["count"] == int(d[f"view{k}_mask_count"])
+        assert abs(o["psnr"] - d["psnr"][k]) <= 2e-5 * abs(d["psnr"][k]), (k, o["psnr"], d["psnr"][k])
+        # (the reference's ssim runs five float32 convolutions; sigma = E[x^2] - mu^2 cancels in float32)
+        assert abs(o["ssim"] - d["ssim"][k]) <= 1e-5, (k, o["ssim"], d["ssim"][k])
+        assert (d[f"view{k}_render"] > 1.0).any()                  # the clamp matters in this fixture
+        assert (d[f"view{k}_gt"] == 0).any()                       # and so does the mask
+    assert abs(float(d["mean_psnr"]) - d["psnr"].mean()) < 1e-9
