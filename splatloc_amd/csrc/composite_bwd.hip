@@ -32,16 +32,6 @@
 #ifndef SR_BWD_FS
 #define SR_BWD_FS 32  // feature rows staged per round (<= 64)
 #endif
-#ifdef SR_ABLATE_HOT_ROWS  // timing experiment only: every gather hits the same few rows
-#define SR_ABLATE_HOT(x) ((x) & 1023u)
-#else
-#define SR_ABLATE_HOT(x) (x)
-#endif
-#ifdef SR_ABLATE_NO_STAGE  // timing experiment only: the feature gather is skipped (wrong results)
-#define SR_ABLATE_STAGE_N(n) 0
-#else
-#define SR_ABLATE_STAGE_N(n) (n)
-#endif
 #ifndef SR_BWD_STAGE_UNROLL
 #define SR_BWD_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2, 5 cameras: 2: 0.947, 3: 0.914 ms)
 #endif
@@ -53,9 +43,6 @@
 #define SR_BWD_MINW 4  // waves per SIMD the register allocator must allow (A/B on S2: 1.035 vs 1.07 ms at 3)
 #endif
 
-#ifndef SR_BWD_ABLATE_ATOMIC
-#define SR_BWD_ABLATE_ATOMIC 0  // perf experiment only: drop the float atomics (wrong results)
-#endif
 #ifndef SR_BWD_SKIP_BRANCH
 #define SR_BWD_SKIP_BRANCH 0  // 1 = skip a candidate pair that no pixel of the quadrant hits (A/B: slower, more VGPRs)
 #endif
@@ -68,17 +55,9 @@
 #ifndef SR_BWD_DOT_PREFETCH
 #define SR_BWD_DOT_PREFETCH 1  // double-buffered LDS reads in the 4x4x1 dot (A/B on S2: 0.8645 -> 0.860 ms)
 #endif
-// Timing probes only (WRONG results; tools/ablate.py): what would a kernel cost that reduced the geometric moments on the
-// matrix pipe instead of through the moment products + packed butterfly?
-//   SR_BWD_PROBE = 1: the per-pair butterfly + atomic dropped (their inputs stay live)
-//   (probes 2 and 3 of round 3 — E parked in a second 16-column panel, extra MFMA blocks fed from it — are recorded in
-//    profiles/r03_ab_probes.txt; the transposed moment reduction below replaced them)
-//   SR_BWD_PROBE = 4: the 4x4x1 MFMA dot products dropped (q = a cheap stand-in): is the matrix pipe a co-bottleneck?
-//   SR_BWD_PROBE = 5: the flush's 16x16x4 MFMAs dropped (atomics kept)
-//   SR_BWD_PROBE = 6 / 7: the set-up's plane loads dropped (all / the colour planes only)
-#ifndef SR_BWD_PROBE
-#define SR_BWD_PROBE 0
-#endif
+// (The timing probes of rounds 2-3 that produce WRONG results by design — hot-row gathers, skipped staging, dropped atomics /
+//  butterfly / MFMAs / plane loads — are not part of this translation unit: tools/patches/composite_probes.patch adds them
+//  back for tools/ablate.py --patch.)
 #ifndef SR_BWD_TM
 #define SR_BWD_TM 1   // 1 = transposed moment reduction (small-layout panel variant): E = G dL/dalpha parked in an 8-column LDS panel, reduced by lane = (Gaussian, pixel column)
 #endif
@@ -293,13 +272,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
             const int c = c0 + ch;
-#if SR_BWD_PROBE == 6   // timing probe: no gradient / colour plane loads in the set-up
-            g[ch] = 1e-3f * (float)(c + 1) + 1e-5f * (float)lane;
-            S += 0.5f * g[ch];
-#elif SR_BWD_PROBE == 7   // timing probe: the gradient planes only (S_total without the colour planes)
-            g[ch] = c < gc ? dL_dcolor[(size_t)c * plane + pix] : (dL_dlast ? dL_dlast[pix] : 0.0f);
-            S += 0.5f * g[ch];
-#else
             // planes [0, gc) behind dL_dcolor, the LAST channel's plane behind dL_dlast, nothing in between.  Kept as plain
             // selects: with the loads inside branches the 70 plane loads of the set-up no longer overlap (backward + 8 %).
             float gv = c < gc ? dL_dcolor[(size_t)c * plane + pix] : (dL_dlast ? dL_dlast[pix] : 0.0f);
@@ -310,7 +282,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             } else {
                 S += out_color[(size_t)c * plane + pix] * gv;
             }
-#endif
         }
         if (AUX && first_pass) {
             gD = dL_ddepth ? dL_ddepth[pix] : 0.0f;
@@ -389,11 +360,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             const float a = s_w[4 * kk * WS + row];
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
-#if SR_BWD_PROBE == 5
-                D[t][kk & 3] += a * gt[kk][t];
-#else
                 D[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gt[kk][t], D[t], 0, 0, 0);
-#endif
             }
         }
         // column c = 16 t + (l & 15): channel c0 + c below NM, the depth weight (moment slot 6, first pass only) at NM
@@ -409,11 +376,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     const bool full = 16 * t + 16 <= NM;   // every column of the block is a channel
                     const bool col_ok = full || c < NM || (XD && c == NM && first_pass);
                     const uint32_t col_off = (full || c < NM) ? (uint32_t)(c0 + c) : (uint32_t)(MO + 6);
-#if SR_BWD_ABLATE_ATOMIC
-                    asm volatile("" ::"v"(rowi + col_off), "v"(D[t][r]));
-#else
                     if (col_ok) acc_add<DET>(gacc, gacc64, (size_t)(rowi + col_off), D[t][r], det_pass);
-#endif
                 }
             }
         }
@@ -451,11 +414,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             const int vi = ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1);
             if (eg < count && vi < 6) {
                 const size_t di = (size_t)(__umul24(s_gid[e0 + eg], (uint32_t)GROW) + (uint32_t)(MO + vi));
-#if SR_BWD_ABLATE_ATOMIC
-                asm volatile("" ::"v"(di), "v"(outv));
-#else
                 acc_add<DET>(gacc, gacc64, di, outv, det_pass);
-#endif
             }
             __builtin_amdgcn_wave_barrier();
             BP_T(te1);
@@ -543,7 +502,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 const int e = k * WAVE + lane;
                 if (k * WAVE < ncand * PPR && e < ncand * PPR) {
                     const int row = e / PPR, pc = e - row * PPR;
-                    __builtin_amdgcn_global_load_lds(&featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row] - row0), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))],
+                    __builtin_amdgcn_global_load_lds(&featp4[(size_t)(__umul24(s_cgid[row] - row0, (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))],
                                                      reinterpret_cast<float4*>(s_feat) + k * WAVE, 16, 0, 0);
                 }
             }
@@ -551,9 +510,9 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             __builtin_amdgcn_wave_barrier();
 #else
 #pragma unroll SR_BWD_STAGE_UNROLL
-            for (int e = lane; e < SR_ABLATE_STAGE_N(ncand * PPR); e += WAVE) {
+            for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
-                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row] - row0), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];
+                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(s_cgid[row] - row0, (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];
             }
             __builtin_amdgcn_wave_barrier();
 #endif
@@ -671,12 +630,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                         red[KV - 1] = w0 * gD;
                         red[2 * KV - 1] = w1 * gD;
                     }
-#if SR_BWD_PROBE == 1
-                    if (MFMA) {
-#pragma unroll
-                        for (int k = 0; k < 2 * KV; ++k) asm volatile("" ::"v"(red[k]));
-                    } else
-#endif
                     {
                         const float outv = wave_reduce_pack<2 * KV>(red, lane);
 #ifdef SR_BWD_PROFILE
@@ -686,11 +639,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                         BP_ADD(4, tp3 - tp2);
                         const uint32_t gi = slot_second ? gi1 : gi0;
                         const size_t di = (size_t)(__umul24(gi, (uint32_t)GROW) + (uint32_t)slot_off);   // gi < 2^24 (checked on the host)
-#if SR_BWD_ABLATE_ATOMIC
-                        asm volatile("" ::"v"(di), "v"(outv));
-#else
                         if (slot_ok && (has1 || !slot_second)) acc_add<DET>(gacc, gacc64, di, outv, det_pass);
-#endif
                     }
                 }
                 BP_T(tp4);
@@ -780,12 +729,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 float qm[4] = {0.f, 0.f, 0.f, 0.f};
                 BP_T(td0);
                 if (DOTM) {
-#if SR_BWD_PROBE == 4
-                    const float zq = reinterpret_cast<const float*>(&s_rec0[min(slot + (lane & 3), ncand - 1)])[2];
-                    const f32x4 Q = {zq * gD, zq * g[0], zq * g[1], zq * g[2]};
-#else
                     const f32x4 Q = dot4(slot);
-#endif
                     qm[0] = Q[0]; qm[1] = Q[1]; qm[2] = Q[2]; qm[3] = Q[3];
 #ifdef SR_BWD_PROFILE
                     asm volatile("" ::"v"(qm[0]), "v"(qm[3]));

@@ -27,16 +27,7 @@
 #ifndef SR_FWD_FS
 #define SR_FWD_FS 24  // feature rows staged per round (<= 64; A/B on S2, 5 cameras: 12: 0.399, 16: 0.417, 20: 0.411, 24: 0.391, 32: 0.401, 40: 0.417, 48: 0.442 ms)
 #endif
-#ifdef SR_ABLATE_HOT_ROWS  // timing experiment only: every gather hits the same few rows
-#define SR_ABLATE_HOT(x) ((x) & 1023u)
-#else
-#define SR_ABLATE_HOT(x) (x)
-#endif
-#ifdef SR_ABLATE_NO_STAGE  // timing experiment only: the feature gather is skipped (wrong results)
-#define SR_ABLATE_STAGE_N(n) 0
-#else
-#define SR_ABLATE_STAGE_N(n) (n)
-#endif
+// (the wrong-result timing probes of rounds 2-3 live in tools/patches/composite_probes.patch, not here)
 #ifndef SR_FWD_STAGE_UNROLL
 #define SR_FWD_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2: 1: 0.429, 2: 0.456, 3: 0.416, 5: 0.478 ms)
 #endif
@@ -219,7 +210,7 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 const int e = k * WAVE + lane;
                 if (k * WAVE < ncand * PPR && e < ncand * PPR) {
                     const int row = e / PPR, pc = e - row * PPR;
-                    __builtin_amdgcn_global_load_lds(&featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))],
+                    __builtin_amdgcn_global_load_lds(&featp4[(size_t)(__umul24(s_cgid[row], (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))],
                                                      reinterpret_cast<float4*>(s_feat) + k * WAVE, 16, 0, 0);
                 }
             }
@@ -227,9 +218,9 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
             __builtin_amdgcn_wave_barrier();
 #else
 #pragma unroll SR_FWD_STAGE_UNROLL
-            for (int e = lane; e < SR_ABLATE_STAGE_N(ncand * PPR); e += WAVE) {
+            for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
-                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(SR_ABLATE_HOT(s_cgid[row]), (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];   // ids < 2^24: checked on the host
+                reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(s_cgid[row], (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];   // ids < 2^24: checked on the host
             }
             __builtin_amdgcn_wave_barrier();
 #endif
@@ -282,13 +273,8 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                     const float a = s_feat[((lane >> 5) ? s1 : slot) * NCP + (lane & 31)];  // A[i = ch][k = g]
                     float b0 = w0, b1 = w1;
                     swap_halves(b0, b1);  // b0 -> B for pixels 0-31, b1 -> B for pixels 32-63
-#if defined(SR_FWD_PROBE) && SR_FWD_PROBE == 1   // timing probe (wrong colours): the matrix pipe out of the picture
-                    accA[0] += a * b0;
-                    accB[0] += a * b1;
-#else
                     mfma_acc_32x32x2(accA, a, b0);
                     mfma_acc_32x32x2(accB, a, b1);
-#endif
                 }
                 if (__builtin_amdgcn_ballot_w64(active) == 0) { wave_done = true; break; }
             }

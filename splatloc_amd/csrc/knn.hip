@@ -33,8 +33,11 @@ __device__ __forceinline__ void top3_insert(float d, float& b0, float& b1, float
 }
 
 __global__ void __launch_bounds__(KNN_THREADS)
-knn_partial_kernel(int N, int slice_len, const float* __restrict__ pts, float* __restrict__ partial)
+knn_partial_kernel(int N, int slice_len, const float* __restrict__ pts, float* __restrict__ partial,
+                   const uint32_t* __restrict__ gate /*null, or: run only when *gate > gate_limit (fallback of an overloaded grid)*/,
+                   uint32_t gate_limit)
 {
+    if (gate && !(*gate > gate_limit)) return;
     __shared__ float sx[KNN_THREADS], sy[KNN_THREADS], sz[KNN_THREADS];
     const int i = blockIdx.x * KNN_THREADS + threadIdx.x;
     const bool valid = i < N;
@@ -51,7 +54,7 @@ knn_partial_kernel(int N, int slice_len, const float* __restrict__ pts, float* _
         for (int k = 0; k < cnt; ++k) {
             const float dx = sx[k] - x, dy = sy[k] - y, dz = sz[k] - z;
             const float d = (dx * dx + dy * dy) + dz * dz;
-            if (base + k != i) top3_insert(d, b0, b1, b2);
+            if (base + k != i && d < INFINITY) top3_insert(d, b0, b1, b2);
         }
     }
     if (valid) {
@@ -61,8 +64,10 @@ knn_partial_kernel(int N, int slice_len, const float* __restrict__ pts, float* _
 }
 
 __global__ void __launch_bounds__(KNN_THREADS)
-knn_merge_kernel(int N, int slices, const float* __restrict__ partial, float* __restrict__ out)
+knn_merge_kernel(int N, int slices, const float* __restrict__ partial, float* __restrict__ out,
+                 const uint32_t* __restrict__ gate, uint32_t gate_limit)
 {
+    if (gate && !(*gate > gate_limit)) return;
     const int i = blockIdx.x * KNN_THREADS + threadIdx.x;
     if (i >= N) return;
     float b0 = INFINITY, b1 = INFINITY, b2 = INFINITY;
@@ -90,6 +95,16 @@ struct KnnGrid {            // written by knn_grid_setup_kernel, read by the oth
     int nx, ny, nz;
     uint32_t cells;
 };
+// A degenerate cloud (many duplicates, or a few far outliers that inflate the box while everything else falls into a handful
+// of cells) would make every query scan one huge cell serially.  The count pass records the largest cell; beyond
+// knn_overload_limit(N) points in one cell the grid query kernel returns at once and the tiled brute force — launched behind
+// it, returning at once otherwise — produces the (identical) result.  Decided on the device: no host synchronisation.
+// The flag word lives at the END of the workspace, outside both paths' buffers (they alias each other).
+__host__ __device__ static inline uint32_t knn_overload_limit(int N)
+{
+    const uint32_t a = 4096u, b = (uint32_t)N / 64u;
+    return a > b ? a : b;
+}
 constexpr int KNN_BBOX_BLOCKS = 256;
 
 __global__ void __launch_bounds__(KNN_THREADS)
@@ -98,7 +113,10 @@ knn_bbox_kernel(int N, const float* __restrict__ pts, float* __restrict__ part /
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * KNN_THREADS + threadIdx.x; i < N; i += gridDim.x * KNN_THREADS)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { const float v = pts[3 * i + k]; lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+        for (int k = 0; k < 3; ++k) {   // (a non-finite coordinate must not inflate the box: such a point is nobody's neighbour)
+            const float v = pts[3 * i + k];
+            if (isfinite(v)) { lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+        }
     __shared__ float s[KNN_THREADS / WAVE][6];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -150,7 +168,7 @@ __device__ __forceinline__ void knn_cell_of(const KnnGrid& g, float x, float y, 
 
 __global__ void __launch_bounds__(KNN_THREADS)
 knn_count_kernel(int N, const float* __restrict__ pts, const KnnGrid* __restrict__ Gp, uint32_t* __restrict__ cell_of,
-                 uint32_t* __restrict__ count)
+                 uint32_t* __restrict__ count, uint32_t* __restrict__ max_count)
 {
     const int i = blockIdx.x * KNN_THREADS + threadIdx.x;
     if (i >= N) return;
@@ -159,7 +177,8 @@ knn_count_kernel(int N, const float* __restrict__ pts, const KnnGrid* __restrict
     knn_cell_of(g, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], ix, iy, iz);
     const uint32_t c = (uint32_t)ix + (uint32_t)g.nx * ((uint32_t)iy + (uint32_t)g.ny * (uint32_t)iz);
     cell_of[i] = c;
-    atomicAdd(&count[c], 1u);
+    const uint32_t now = atomicAdd(&count[c], 1u) + 1u;
+    if (now > knn_overload_limit(N)) atomicMax(max_count, now);     // (rare: only cells already beyond the limit touch the word)
 }
 
 // sorted[start[c] + k] = (x, y, z, original index) of the k-th point that reached cell c (any order inside a cell)
@@ -178,10 +197,11 @@ knn_scatter_kernel(int N, const float* __restrict__ pts, const uint32_t* __restr
 
 __global__ void __launch_bounds__(KNN_THREADS)
 knn_grid_query_kernel(int N, const float4* __restrict__ sorted, const uint32_t* __restrict__ incl,
-                      const KnnGrid* __restrict__ Gp, float* __restrict__ out)
+                      const KnnGrid* __restrict__ Gp, const uint32_t* __restrict__ max_count, float* __restrict__ out)
 {
     const int s = blockIdx.x * KNN_THREADS + threadIdx.x;   // queries in cell order: neighbouring threads walk neighbouring cells
     if (s >= N) return;
+    if (*max_count > knn_overload_limit(N)) return;          // overloaded grid: the brute force behind this launch answers
     const KnnGrid g = *Gp;
     const float4 q = sorted[s];
     const uint32_t self = __float_as_uint(q.w);
@@ -206,7 +226,7 @@ knn_grid_query_kernel(int N, const float4* __restrict__ sorted, const uint32_t* 
                         const float4 p = sorted[j];
                         const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
                         const float d = (dx * dx + dy * dy) + dz * dz;
-                        if (__float_as_uint(p.w) != self) top3_insert(d, b0, b1, b2);
+                        if (__float_as_uint(p.w) != self && d < INFINITY) top3_insert(d, b0, b1, b2);   // (d < inf: a non-finite point is nobody's neighbour)
                     }
                 }
             }
@@ -260,30 +280,6 @@ static KnnGridWs knn_grid_ws(void* base, int N)
     return w;
 }
 
-static int knn_grid_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream)
-{
-    KnnGridWs w = knn_grid_ws(workspace, N);
-    const uint32_t cells = knn_max_cells(N);
-    const int blocks = (N + KNN_THREADS - 1) / KNN_THREADS;
-    SR_HIP_CHECK(hipMemsetAsync(w.count, 0, w.zero_bytes, stream));
-    hipLaunchKernelGGL(knn_bbox_kernel, dim3(KNN_BBOX_BLOCKS), dim3(KNN_THREADS), 0, stream, N, points, w.part);
-    SR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_grid_setup_kernel, dim3(1), dim3(1), 0, stream, N, KNN_BBOX_BLOCKS, w.part, cells, w.G);
-    SR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_count_kernel, dim3(blocks), dim3(KNN_THREADS), 0, stream, N, points, w.G, w.cell_of, w.count);
-    SR_LAUNCH_CHECK();
-    // the scan covers all `cells` slots (the grid uses a prefix of them; the rest hold zero counts)
-    int st = lookback_error_init();
-    if (st) return st;
-    st = inclusive_scan_u32((int64_t)cells, w.count, nullptr, w.incl, nullptr, w.scan_tmp, stream);
-    if (st) return st;
-    hipLaunchKernelGGL(knn_scatter_kernel, dim3(blocks), dim3(KNN_THREADS), 0, stream, N, points, w.cell_of, w.incl, w.fill, w.sorted);
-    SR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_grid_query_kernel, dim3(blocks), dim3(KNN_THREADS), 0, stream, N, w.sorted, w.incl, w.G, out);
-    SR_LAUNCH_CHECK();
-    return SPLATRASTER_OK;
-}
-
 static int knn_slices(int N)
 {
     const int qblocks = (N + KNN_THREADS - 1) / KNN_THREADS;
@@ -295,28 +291,69 @@ static int knn_slices(int N)
     return s;
 }
 
-size_t knn_workspace_bytes(int32_t N)
+
+// flag word of the grid path (largest overloaded cell, see KnnGrid): the last 256 bytes of the workspace
+static uint32_t* knn_flag_word(void* workspace, int32_t N)
 {
-    const size_t n = (size_t)(N > 0 ? N : 1);
-    const size_t brute = align_up((size_t)knn_slices((int)n) * n * 3 * sizeof(float), 256);
-    const size_t grid = knn_grid_ws(nullptr, (int)n).bytes;
-    return brute > grid ? brute : grid;     // either path may be taken (the threshold is a run-time knob)
+    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + knn_workspace_bytes(N) - 256);
 }
 
-int knn_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream)
+// the tiled brute force; `gate` non-null: every block returns at once unless *gate > gate_limit
+static int knn_brute_dist2(int32_t N, const float* points, float* out, void* workspace, const uint32_t* gate, uint32_t gate_limit,
+                           hipStream_t stream)
 {
-    if (N >= g_knn_grid_min && N >= 8) return knn_grid_dist2(N, points, out, workspace, stream);
     const int slices = knn_slices(N);
     int slice_len = (N + slices - 1) / slices;
     slice_len = (slice_len + KNN_THREADS - 1) / KNN_THREADS * KNN_THREADS;
     const int qblocks = (N + KNN_THREADS - 1) / KNN_THREADS;
     float* partial = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(knn_partial_kernel, dim3(qblocks, slices), dim3(KNN_THREADS), 0, stream, N, slice_len,
-                       points, partial);
+                       points, partial, gate, gate_limit);
     SR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_merge_kernel, dim3(qblocks), dim3(KNN_THREADS), 0, stream, N, slices, partial, out);
+    hipLaunchKernelGGL(knn_merge_kernel, dim3(qblocks), dim3(KNN_THREADS), 0, stream, N, slices, partial, out, gate, gate_limit);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
+}
+
+static int knn_grid_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream)
+{
+    KnnGridWs w = knn_grid_ws(workspace, N);
+    const uint32_t cells = knn_max_cells(N);
+    const int blocks = (N + KNN_THREADS - 1) / KNN_THREADS;
+    SR_HIP_CHECK(hipMemsetAsync(w.count, 0, w.zero_bytes, stream));
+    uint32_t* flag = knn_flag_word(workspace, N);
+    SR_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(KNN_BBOX_BLOCKS), dim3(KNN_THREADS), 0, stream, N, points, w.part);
+    SR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_grid_setup_kernel, dim3(1), dim3(1), 0, stream, N, KNN_BBOX_BLOCKS, w.part, cells, w.G);
+    SR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_count_kernel, dim3(blocks), dim3(KNN_THREADS), 0, stream, N, points, w.G, w.cell_of, w.count, flag);
+    SR_LAUNCH_CHECK();
+    // the scan covers all `cells` slots (the grid uses a prefix of them; the rest hold zero counts)
+    int st = lookback_error_init();
+    if (st) return st;
+    st = inclusive_scan_u32((int64_t)cells, w.count, nullptr, w.incl, nullptr, w.scan_tmp, stream);
+    if (st) return st;
+    hipLaunchKernelGGL(knn_scatter_kernel, dim3(blocks), dim3(KNN_THREADS), 0, stream, N, points, w.cell_of, w.incl, w.fill, w.sorted);
+    SR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_grid_query_kernel, dim3(blocks), dim3(KNN_THREADS), 0, stream, N, w.sorted, w.incl, w.G, flag, out);
+    SR_LAUNCH_CHECK();
+    // an overloaded grid (degenerate cloud) is answered by the brute force instead; otherwise these blocks return at once
+    return knn_brute_dist2(N, points, out, workspace, flag, knn_overload_limit(N), stream);
+}
+
+size_t knn_workspace_bytes(int32_t N)
+{
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    const size_t brute = align_up((size_t)knn_slices((int)n) * n * 3 * sizeof(float), 256);
+    const size_t grid = knn_grid_ws(nullptr, (int)n).bytes;
+    return (brute > grid ? brute : grid) + 256;     // either path may be taken (the threshold is a run-time knob); + the flag word
+}
+
+int knn_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream)
+{
+    if (N >= g_knn_grid_min && N >= 8) return knn_grid_dist2(N, points, out, workspace, stream);
+    return knn_brute_dist2(N, points, out, workspace, nullptr, 0u, stream);
 }
 
 }  // namespace sr
