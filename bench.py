@@ -767,8 +767,8 @@ def main():
     ap.add_argument("--no-multi-stream", action="store_true", help="skip the secondary legs (per-view loop, multi-stream) (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
-    ap.add_argument("--keyframes", type=int, default=20, help="--stage scene: key-frames of the synthetic scene")
-    ap.add_argument("--refine", type=int, default=2000, help="--stage scene: color_refinement iterations (the reference: 26000)")
+    ap.add_argument("--keyframes", type=int, default=60, help="--stage scene: key-frames of the synthetic scene")
+    ap.add_argument("--refine", type=int, default=26000, help="--stage scene: color_refinement iterations (the reference: 26000)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of K steps is repeated this many times; value = the MEDIAN region (min / max reported)")
     ap.add_argument("--stage", default="raster",

@@ -39,16 +39,20 @@ class Adam(torch.optim.Adam):
         entries, keep = [], []
         betas = eps = None
         dev = None
+        f32 = torch.float32
+        gate_spec = self.key_gate
         for grp in self.param_groups:
             if betas is None:
                 betas, eps = grp["betas"], grp["eps"]
             elif betas != grp["betas"] or eps != grp["eps"]:
                 raise RuntimeError("splatloc_amd.optim.Adam: all groups must share betas and eps")
             for p in grp["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
-                _require_gpu(p, "parameter")
-                if p.dtype != torch.float32 or not p.is_contiguous():
+                if not p.is_cuda:
+                    _require_gpu(p, "parameter")
+                if p.dtype is not f32 or not p.is_contiguous():
                     raise RuntimeError("splatloc_amd.optim.Adam: parameters must be contiguous float32")
                 dev = p.device
                 st = self.state[p]
@@ -56,28 +60,38 @@ class Adam(torch.optim.Adam):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                g = p.grad
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    g = g.to(torch.float32).contiguous()
+                # `step` stays a 0-dim CPU tensor (torch.optim.Adam's state layout: the reference's optimizer surgery carries it
+                # over); it is advanced through its numpy view — an in-place tensor op costs ~4 us per group, seven per step
+                stp = st["step"]
+                if stp.is_cuda:
+                    stp += 1
+                    step_val = float(stp)
+                else:
+                    view = stp.numpy()
+                    view += 1
+                    step_val = float(view)
+                if g.dtype is not f32 or not g.is_contiguous():
+                    g = g.to(f32).contiguous()
                 gate = None
-                if self.key_gate is not None and grp.get("name") == self.key_gate[2] and p.numel():
-                    gate = self.key_gate[0].detach()
-                    if gate.dtype != torch.float32 or not gate.is_contiguous():
-                        gate = gate.to(torch.float32).contiguous()
+                if gate_spec is not None and grp.get("name") == gate_spec[2] and p.numel():
+                    gate = gate_spec[0].detach()
+                    if gate.dtype is not f32 or not gate.is_contiguous():
+                        gate = gate.to(f32).contiguous()
                     if gate.numel() != p.shape[0]:
                         raise RuntimeError("splatloc_amd.optim.Adam: key gate needs one value per parameter row")
-                keep += [g, gate]
-                width = int(p.numel() // p.shape[0]) if p.dim() and p.shape[0] else 1
+                keep.append(g)
+                keep.append(gate)
+                n = p.numel()
+                rows = p.shape[0] if p.dim() else 0
+                width = (n // rows) if rows else 1
                 entries.append(_native.AdamGroup(
-                    C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(st["exp_avg"].data_ptr()),
-                    C.c_void_p(st["exp_avg_sq"].data_ptr()), None if gate is None else C.c_void_p(gate.data_ptr()),
-                    p.numel(), max(width, 1), float(grp["lr"]), float(st["step"])))
+                    p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                    None if gate is None else gate.data_ptr(), n, max(width, 1), float(grp["lr"]), step_val))
         if entries:
             if len(entries) > 16:
                 raise RuntimeError("splatloc_amd.optim.Adam: at most 16 parameters per step")
             arr = (_native.AdamGroup * len(entries))(*entries)
-            thr = self.key_gate[1] if self.key_gate is not None else 0.0
+            thr = gate_spec[1] if gate_spec is not None else 0.0
             with _on_device(dev):
                 _native.check(lib.splatraster_adam_step(len(entries), arr, C.c_double(betas[0]), C.c_double(betas[1]),
                                                         C.c_double(eps), C.c_float(thr), _stream(dev)), "adam_step")

@@ -39,6 +39,63 @@ def update_learning_rate(gaussians, iteration) -> float:
     return 0.0
 
 
+def _direct_refine_ok(gaussians, pipe) -> bool:
+    """SplatLoc's own configuration (SH degree 0, colours converted in Python, covariance in the rasterizer) on a non-empty
+    model whose tensors all take gradients: the iteration can run without autograd (below)."""
+    if not bool(pipe.convert_SHs_python) or bool(pipe.compute_cov3D_python) or int(gaussians.active_sh_degree) != 0:
+        return False
+    if int(gaussians._xyz.shape[0]) == 0 or not gaussians._xyz.is_cuda:
+        return False
+    return all(getattr(gaussians, a).requires_grad for a in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_kp_score",
+                                                             "_scaling", "_rotation"))
+
+
+def _color_refinement_step_direct(viewpoint_cam, gaussians, background, lambda_dssim, iteration, primitive_reg):
+    """The iteration of `color_refinement_step` with the SAME forward / backward code (`_ActivatePack`, `_RasterizeWindow`:
+    their static forward / backward called directly with a plain context) but without building an autograd graph: the
+    refinement iteration is HOST-bound at SplatLoc's frame size (tools/refine_idle.py: 0.42 ms of Python per iteration against
+    0.25 - 0.55 ms of kernels), and a third of that host time was the autograd engine handing the two backward nodes to its
+    worker thread.  Gradients land in `.grad` exactly as autograd would leave them: `_xyz` <- dL/dmeans3D, `_features_rest`
+    <- its empty gradient, `_kp_score` <- the zero column, `_marker` <- nothing (tests/test_gpu_refine.py, both paths)."""
+    from .fused import _ActivatePack, _view_settings
+    from .rasterizer import PlainCtx, _RasterizeWindow
+    with torch.no_grad():
+        xyz = gaussians._xyz
+        c_act = PlainCtx()
+        scales, rotations, opacity, colors = _ActivatePack.forward(
+            c_act, xyz, gaussians._features_dc, gaussians._features_rest, gaussians._scaling, gaussians._rotation,
+            gaussians._opacity, gaussians._kp_score, None, 0)
+        settings = _view_settings(viewpoint_cam, gaussians, background, 1.0)
+        c_ras = PlainCtx()
+        rgb, _kp, _depth, _alpha, radii = _RasterizeWindow.forward(c_ras, xyz, colors, opacity, scales, rotations, None, (settings,),
+                                                                 3, None, xyz)     # (means2D is a gradient carrier only)
+        gt_image = viewpoint_cam.original_image
+        if gt_image.device != rgb.device:
+            gt_image = gt_image.to(rgb.device)
+        loss, g_image = refinement_loss_and_grad(rgb, gt_image, lambda_dssim)
+        d = _RasterizeWindow.backward(c_ras, g_image, None, None, None, None)
+        d_m3, d_col, d_op, d_sca, d_rot = d[0], d[1], d[2], d[3], d[4]
+        _dx, d_fd, d_fr, d_sc, d_ro, d_opa, d_ex, _, _ = _ActivatePack.backward(c_act, d_sca, d_rot, d_op, d_col)
+        for p, g in ((gaussians._xyz, d_m3), (gaussians._features_dc, d_fd), (gaussians._features_rest, d_fr),
+                     (gaussians._scaling, d_sc), (gaussians._rotation, d_ro), (gaussians._opacity, d_opa), (gaussians._kp_score, d_ex)):
+            if g is not None:
+                p.grad = g if p.grad is None else p.grad + g
+        opt = gaussians.optimizer
+        if primitive_reg:
+            if hasattr(opt, "set_key_gate"):
+                opt.set_key_gate(gaussians._marker, 0.005)
+            else:
+                key_mask = gaussians._marker.detach().squeeze() > 0.005
+                gaussians._xyz.grad[key_mask] = 0
+        elif hasattr(opt, "set_key_gate"):
+            opt.set_key_gate(None)
+        add_densification_stats_window(None, [radii], None, None, gaussians.max_radii2D)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        update_learning_rate(gaussians, iteration)
+    return loss
+
+
 def color_refinement_step(viewpoint_cam, gaussians, pipe, background, lambda_dssim: float, iteration: int,
                           primitive_reg: bool = True):
     """One iteration of SplatLoc.color_refinement (train_gaussians.py:275-297):
@@ -52,6 +109,8 @@ def color_refinement_step(viewpoint_cam, gaussians, pipe, background, lambda_dss
     convolutions and their autograd backward); the `max_radii2D` line as one launch without boolean-mask indexing
     (the reference: two `nonzero` + a device->host sync); the gate inside the fused Adam launch when the optimizer is
     splatloc_amd.optim.Adam (else the reference's masked assignment).  Returns the loss tensor (no host sync)."""
+    if _direct_refine_ok(gaussians, pipe):
+        return _color_refinement_step_direct(viewpoint_cam, gaussians, background, lambda_dssim, iteration, primitive_reg)
     pkgs, _ = render_window([viewpoint_cam], gaussians, pipe, background, batched=True)
     pkg = pkgs[0]
     if pkg is None:

@@ -291,6 +291,48 @@ def test_dist2_grid_equals_brute_force(n, kind):
     np.testing.assert_allclose(grid.cpu().numpy()[sub], (d[:, 1:] ** 2).mean(1), rtol=2e-4, atol=1e-9)
 
 
+def test_dist2_degenerate_clouds_fall_back_to_the_brute_force():
+    """Round-3 advisor finding: a cloud that collapses into a handful of grid cells (a dense cluster + a few far outliers that
+    inflate the bounding box; mass duplicates) would make every query scan one huge cell serially.  The count pass records the
+    largest cell; beyond max(4096, N / 64) points in one cell the tiled brute force — launched behind the grid query, returning
+    at once otherwise — answers instead, decided on the device.  Same arithmetic: bit-identical to the forced brute force.
+    Non-finite points are nobody's neighbour and do not inflate the box."""
+    from simple_knn._C import distCUDA2
+    from splatloc_amd import _native
+    lib = _native.load()
+    rng = np.random.default_rng(7)
+    n = 30_000
+    cluster = rng.normal(size=(n, 3)) * 1e-3 + np.array([0.3, -0.2, 2.0])
+    cluster[-6:] = rng.normal(size=(6, 3)) * 5e3                 # six outliers: the box is 1e7 x the cluster
+    dup = np.repeat(rng.normal(size=(30, 3)), 1000, axis=0)      # 30 sites x 1000 exact duplicates
+    for name, pts in (("outliers", cluster), ("duplicates", dup)):
+        t = torch.from_numpy(pts.astype(np.float32)).cuda()
+        try:
+            lib.splatknn_debug_set_grid_min(1 << 30)
+            brute = distCUDA2(t)
+            lib.splatknn_debug_set_grid_min(0)
+            grid = distCUDA2(t)
+        finally:
+            lib.splatknn_debug_set_grid_min(-1)
+        assert torch.equal(grid.view(torch.int32), brute.view(torch.int32)), name
+        assert torch.equal(distCUDA2(t), brute), name
+    assert float(distCUDA2(torch.from_numpy(dup.astype(np.float32)).cuda()).max()) == 0.0     # >= 3 duplicates everywhere
+    # non-finite points: skipped as neighbours, their own result is 0, the others' results are those of the cloud without them
+    pts = (rng.random((20_000, 3)) * 4.0).astype(np.float32)
+    bad = pts.copy()
+    bad[[5, 777, 19_999]] = [[np.inf, 0, 0], [np.nan, 1, 2], [0, -np.inf, 1]]
+    good_idx = np.setdiff1d(np.arange(20_000), [5, 777, 19_999])
+    ref = distCUDA2(torch.from_numpy(pts[good_idx]).cuda()).cpu().numpy()
+    for force in (0, 1 << 30):
+        try:
+            lib.splatknn_debug_set_grid_min(force)
+            out = distCUDA2(torch.from_numpy(bad).cuda()).cpu().numpy()
+        finally:
+            lib.splatknn_debug_set_grid_min(-1)
+        assert np.array_equal(out[good_idx].view(np.uint32), ref.view(np.uint32)), force
+        assert np.all(out[[5, 777, 19_999]] == 0.0)
+
+
 def test_full_size_properties():
     """North-star shape (S2: 500k Gaussians, 1920x1080, C = 35): size-independent checks —
     sortedness of the instance list, range table partition, alpha = 1 - final_T,
