@@ -1033,16 +1033,37 @@ def main():
         traffic = prof.get("traffic.json", {}).get(dom)
         valu = prof.get("valu.json")
         roofline_valu = None
+        clk = None
+        cpath = os.path.join(ROOT, "profiles", "clocks.json")
+        if os.path.exists(cpath):
+            try:
+                cj = json.load(open(cpath))
+                a = cj.get("amdsmi_library_20hz") or {}
+                res = a.get("residency_counters_first_last") or {}
+                acc, ppt = res.get("accumulation_counter"), res.get("ppt_residency_acc")
+                clk = {"achieved_sclk_mhz": (a.get("gfxclk_mhz_mean_over_xcds") or {}).get("median"),
+                       "socket_power_w": (a.get("socket_power_w") or {}).get("median"), "power_cap_w": cj.get("power_cap_w"),
+                       "ppt_limit_residency": (round((ppt[1] - ppt[0]) / max(acc[1] - acc[0], 1), 3) if acc and ppt else None)}
+            except Exception:  # noqa: BLE001
+                clk = None
         if valu:
             # the binding bound of the compositing kernels as a fraction: a wave64 VALU instruction occupies its
             # SIMD's issue port for 4 cycles (quad-cycle), 1024 SIMDs: issue fraction = wave-instr x 4 / (1024 x cycles)
             roofline_valu = {"source": "profiles/valu.json (builder rocprofv3 SQ-counter run, same workload and launch mode)",
-                             "bound": "valu-issue", "kernels": {}}
+                             "bound": "valu-issue", "kernels": {},
+                             # measured clock of a >= 10-s loop of this workload (tools/clock_trace.py: amdsmi at ~20 Hz from a separate
+                             # process; a replay of profiles/clocks.json, not live): the SQ fractions below are fractions of ACHIEVED
+                             # cycles (kernel cycles from GRBM_GUI_ACTIVE); `..._at_peak_clock` re-states them against 2.4 GHz
+                             "clock": clk, "peak_sclk_mhz": 2400}
             for k, c in valu.items():
                 if isinstance(c, dict) and c.get("kernel_cycles"):
                     cyc = c["kernel_cycles"]
+                    issue = (c["valu_wave_instructions"] + c.get("mfma_wave_instructions", 0)) * 4
+                    live_ms = dom_avg if k.startswith(dom + "_kernel") else None     # this run's measured duration of the dominant kernel
                     roofline_valu["kernels"][k] = {
-                        "valu_issue_frac": round((c["valu_wave_instructions"] + c.get("mfma_wave_instructions", 0)) * 4 / (1024 * cyc), 4),
+                        "valu_issue_frac": round(issue / (1024 * cyc), 4),
+                        "valu_issue_frac_at_peak_clock": (round(issue / (1024 * live_ms * 1e-3 * 2.4e9), 4) if live_ms else None),
+                        "kernel_cycles_per_live_duration_mhz": (round(cyc / (live_ms * 1e-3) / 1e6, 1) if live_ms else None),
                         "valu_busy": c.get("valu_busy"), "mfma_busy": c.get("mfma_busy"),
                         "salu_per_valu": round(c.get("salu_wave_instructions", 0) / max(c["valu_wave_instructions"], 1), 3)}
         out = {
