@@ -3,15 +3,19 @@
 // Replaces the render-backward stage of the rasterizer extension whose backward is
 // triggered at train_gaussians.py:229 / :286.
 //
-// Formulation (differs from the lineage's back-to-front accum_rec recurrences, same
-// derivative): with w_i = alpha_i T_i, q_i = f_i . g + z_i g_D  (g = dL/dcolor at the pixel)
-//     S_total = out_color . g + out_depth g_D - T_final g_A
-//     S_i     = S_total - sum_{j<=i} w_j q_j            (suffix sum incl. background/alpha terms)
-//     dL/dalpha_i = T_i q_i - S_i / (1 - alpha_i)
-// so the pass runs FRONT-TO-BACK exactly like the forward (same arithmetic for alpha and
-// T, no division T/(1-alpha) to undo transmittance) and needs one dot product per
-// (pixel, Gaussian) instead of three per-channel recurrences.  Everything is linear in
-// (g, g_D, g_A), so channels can be split over several launches (generic C).
+// Formulation (round 4: BACK-TO-FRONT, the lineage's direction; rounds 1-3 walked front to back): with
+// q_i = f_i . g + z_i g_D (g = dL/dcolor at the pixel), T_i the transmittance in front of Gaussian i and
+//     A_i = [ sum_{j>i} alpha_j T_j q_j + T_final (bg . g - g_A) ] / T_{i+1}      (what lies behind i, per unit of light reaching it)
+// the derivative is  dL/dalpha_i = T_i (q_i - A_i)  and the state moves towards the camera by
+//     T_i = T_{i+1} / (1 - alpha_i),     A_{i-1} = A_i + alpha_i (q_i - A_i),
+// started at every pixel's last contributor with T = final_T and A = bg . g - g_A (exact).  One dot product per (pixel, Gaussian),
+// linear in (g, g_D, g_A) — channels can be split over several launches (generic C).  Every quantity is O(1)-scaled: errors stay
+// RELATIVE to the Gaussian's own gradient.  The front-to-back form of rounds 1-3, S_i = S_total - sum_{j<=i} w_j q_j with S_total =
+// out_color . g, carried an ABSOLUTE error of ~1e-7 |S_total| in float32 that was up to 1e-3 of the S_i of a Gaussian behind
+// T = 1e-4 (profiles/r04_grad_bars_before_accurate_mode.json); it also needed the forward's C + 1 colour / depth planes, which
+// this form does not read (except at the boundaries of split launches, below).  alpha itself is evaluated with the forward's
+// arithmetic (composite_common.h), and which entries contribute is the forward's decision (n_contrib), so the two passes agree
+// on every alpha >= 1/255 / T < 1e-4 test.
 //
 // Machine mapping = the forward's (composite_fwd.hip): ONE wave64 = one workgroup = one 8x8
 // quadrant, the tile's list streamed from the per-instance payload (mask byte + record),
@@ -182,7 +186,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      int det_pass /*DET only: 0 = per-element max of |partial|, 1 = fixed-point sums (acc_add)*/)
 {
     using Cfg = BwdCfg<NC, SP, AUX>;
-    // DET: the suffix sum S and everything derived from it in double (see the replay pass below); else float
+    // DET (the accurate mode): the walk's state T, A and everything derived from it in double; else float
     using ST = typename std::conditional<DET, double, float>::type;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, KV = Cfg::KV, FS = Cfg::FS;
     constexpr int WS = Cfg::WS, GROUP = Cfg::GROUP;
@@ -247,54 +251,58 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     const uint32_t list0 = beg;                                // list positions (n_contrib) count from the tile's first entry
     const bool split = !DET && NC <= 4 && ckpt_all != nullptr;   // (the accurate mode starts every list at its head)
     const int seg = split ? (int)blockIdx.y : 0;
-    const bool second = seg > 0;                               // starts from a checkpoint
     if (split) {
         const uint32_t part = split_part(end0 - beg);
         beg += (uint32_t)seg * part;
         if (seg < SPLIT_PARTS - 1) end0 = min(end0, beg + part);
         if (beg >= end0) return;
     }
-    // (the forward wrote C_total + 2 planes per checkpoint: T, its C_total colours, depth — this pass may cover fewer channels)
-    const float* __restrict__ ckpt = ckpt_all + ((size_t)view * (SPLIT_PARTS - 1) + (second ? seg - 1 : 0)) * (C_total + 2) * ((size_t)H * W);
-
+    // (the forward wrote C_total + 2 planes per checkpoint k, taken in front of list entry beg + (k + 1) part: T, its C_total
+    //  colours so far, the depth so far — this pass may cover fewer channels)
     // per-pixel constants
     float g[NC];
-    ST S = 0;  // running suffix sum
-    // DET: S_total is NOT taken from the forward's images (out_color . g carries the forward's float32 rounding, an ABSOLUTE
-    // error of ~1e-7 |S_total| that stays in every S_i = S_total - prefix_i and is 1e-3 of an S_i behind T = 1e-4); it is
-    // rebuilt below from the same w_j q_j terms the subtraction removes again, in double, plus the exact tail
-    // T_final (bg . g - g_A).  s_end = bg . g - g_A of this pixel (this pass's channels).
-    double s_end = 0.0;
+    // state of the back-to-front walk: T = transmittance BEHIND the entry about to be processed, A = what lies behind it per
+    // unit of light (header).  At a pixel's last contributor: T = final_T, A = bg . g - g_A.
+    ST A = 0;
+    ST T = 1;
     float gD = 0.0f;
     uint32_t last = 0;
     if (inside) {
         last = n_contrib[pix];
+        // a split launch's segment that ends in FRONT of this pixel's last contributor starts from the forward's checkpoint at
+        // its upper boundary instead: T_b, and A_b = (S_total - C_b . g - D_b g_D) / T_b with S_total = out_color . g + ...
+        const bool from_ckpt = split && seg < SPLIT_PARTS - 1 && list0 + last > end0;
+        float s_tot = 0.0f;     // only for from_ckpt pixels
+        float s_end = 0.0f;
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
             const int c = c0 + ch;
             // planes [0, gc) behind dL_dcolor, the LAST channel's plane behind dL_dlast, nothing in between.  Kept as plain
-            // selects: with the loads inside branches the 70 plane loads of the set-up no longer overlap (backward + 8 %).
+            // selects: with the loads inside branches the plane loads of the set-up no longer overlap (backward + 8 %).
             float gv = c < gc ? dL_dcolor[(size_t)c * plane + pix] : (dL_dlast ? dL_dlast[pix] : 0.0f);
             if (c >= gc && c != C_total - 1) gv = 0.0f;
             g[ch] = gv;
-            if constexpr (DET) {
-                if (grads.bg && c < grads.bg_channels) s_end += (double)grads.bg[c] * (double)gv;
-            } else {
-                S += out_color[(size_t)c * plane + pix] * gv;
-            }
+            if (grads.bg && c < grads.bg_channels) s_end = fmaf(grads.bg[c], gv, s_end);
+            if constexpr (NC <= 4) { if (from_ckpt) s_tot = fmaf(out_color[(size_t)c * plane + pix], gv, s_tot); }
         }
+        float gA = 0.0f;
         if (AUX && first_pass) {
             gD = dL_ddepth ? dL_ddepth[pix] : 0.0f;
-            const float gA = dL_dalpha ? dL_dalpha[pix] : 0.0f;
-            if constexpr (DET) s_end -= (double)gA;
-            else S += out_depth[pix] * gD - final_T[pix] * gA;
+            gA = dL_dalpha ? dL_dalpha[pix] : 0.0f;
+            s_end -= gA;
         }
-        if constexpr (NC <= 4 && !DET) {
-            if (second) {   // S_k = S_total - sum_{j < k part} w_j q_j = S_total - C_k . g - D_k g_D
-                const float* ck = ckpt + pix;
+        T = (ST)final_T[pix];
+        A = (ST)s_end;
+        if constexpr (NC <= 4) {
+            if (from_ckpt) {
+                const float* ck = ckpt_all + ((size_t)view * (SPLIT_PARTS - 1) + seg) * (C_total + 2) * plane + pix;
+                if (AUX && first_pass) s_tot += out_depth[pix] * gD - final_T[pix] * gA;
 #pragma unroll
-                for (int ch = 0; ch < NC; ++ch) S = fmaf(-ck[(size_t)(1 + ch) * plane], g[ch], S);
-                if (AUX) S = fmaf(-ck[(size_t)(1 + C_total) * plane], gD, S);
+                for (int ch = 0; ch < NC; ++ch) s_tot = fmaf(-ck[(size_t)(1 + ch) * plane], g[ch], s_tot);
+                if (AUX) s_tot = fmaf(-ck[(size_t)(1 + C_total) * plane], gD, s_tot);
+                const float Tb = ck[0];
+                T = (ST)Tb;
+                A = (ST)(s_tot / Tb);        // (T_b >= 1e-4: the pixel was still active at the boundary)
             }
         }
     } else {
@@ -331,8 +339,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     unsigned long long bprof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     BP_T(tk0);
 #endif
-    float T = 1.0f;
-    if constexpr (NC <= 4 && !DET) { if (second && inside) T = ckpt[pix]; }
     // wave_reduce_pack leaves total k in lane bitreverse6(k); values [0, KV) belong to the first
     // Gaussian of a pair, [KV, 2 KV) to the second; inside a Gaussian: NV colours then 7 geometric
     const int slotv = (int)(__brev((unsigned)lane) >> 26);
@@ -341,7 +347,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     const bool slot_col = sv < NV;
     const bool slot_ok = slotv < 2 * KV;
     const int slot_off = slot_col ? (c0 + NM + sv) : (TM ? MO + 6 : MO + sv - NV);  // float offset inside the Gaussian's row
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
     int nslot = 0;  // Gaussians parked in the weight panel (wave-uniform)
     int e0 = 0;     // weight-panel slot of the E panel's column 0 (wave-uniform)
 
@@ -422,37 +427,35 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         }
     };
 
-    // chunk in flight: mask bit, id and record of list entry base + lane
+    // chunk in flight: mask bit and id of list entry base + lane — TWO registers, so that the prefetch really stays in flight
+    // while the current chunk is processed.  (Rounds 1-3 also prefetched the 32-byte record into eight registers; at 128 VGPRs
+    // the compiler spilled them to scratch right behind the loads — `global_load ... s_waitcnt vmcnt(0) ... scratch_store` —
+    // which exposed the whole memory latency once per chunk.  The records of the <= FS candidates are now loaded in the staging
+    // round, together with their feature rows: one latency per round, as before, and only for this quadrant's candidates.)
     bool reach = false;
     uint32_t gid = 0;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    auto fetch = [&](uint32_t base, bool& r_, uint32_t& g_, float4& x0, float4& x1) {
+    auto fetch = [&](uint32_t base, bool& r_, uint32_t& g_) {
         r_ = false;
         if (base + (uint32_t)lane < end) {
             const uint32_t j = base + (uint32_t)lane;
             r_ = (imask[j] >> quad) & 1u;
             g_ = point_list[j];
-            x0 = irec[2 * (size_t)j];
-            x1 = irec[2 * (size_t)j + 1];
         }
     };
-    // DET walks the list TWICE: the replay pass (wave-uniform `replay`) only rebuilds S_total = sum_j w_j q_j + T_final s_end in
-    // double from the very terms the main pass subtracts again; the normal kernel has one pass and none of this code.
-    double s_replay = 0.0;
-    bool replay = DET;
-#pragma unroll 1
-    for (int lpass = DET ? 0 : 1; lpass < 2; ++lpass) {
-    if constexpr (DET) {
-        if (lpass == 1) {
-            S = s_replay + (double)T * s_end;     // T is the replayed final transmittance (= final_T bit for bit)
-            T = 1.0f;
-            replay = false;
-        }
-    }
-    fetch(beg, reach, gid, a0, a1);
+#ifndef SR_BWD_ROW_PREFETCH
+#define SR_BWD_ROW_PREFETCH 0   // n > 0: touch n 128-byte lines of the NEXT chunk's candidate feature rows one chunk ahead (A/B)
+#endif
+    float pf_sink = 0.0f;   // (the touched words are summed into a register nobody reads: the loads just have to be issued)
+    // The list is walked from the quadrant's deepest contributor towards the camera, 64 entries at a time (chunk k = entries
+    // [beg + 64 k, beg + 64 k + 64)), the candidates of a chunk from the highest list position down.
+    if (beg >= end) return;
+    const uint64_t gt_mask = (lane == WAVE - 1) ? 0ull : (~0ull << (lane + 1));   // list positions behind this lane's
+    const int nchunks = (int)((end - beg + (WAVE - 1)) / WAVE);
+    fetch(beg + (uint32_t)(nchunks - 1) * WAVE, reach, gid);
 
 #pragma unroll 1
-    for (uint32_t base = beg; base < end; base += WAVE) {
+    for (int chunk = nchunks - 1; chunk >= 0; --chunk) {
+        const uint32_t base = beg + (uint32_t)chunk * WAVE;
         BP_T(tc0);
         uint64_t cand = __builtin_amdgcn_ballot_w64(reach);
         BP_T(tc1);
@@ -460,37 +463,34 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         BP_ADD(8, 1);
         const uint32_t cur_gid = gid;
         const bool cur_reach = reach;
-        bool first_round = true;
-        if (cand != 0) {
-            // the first <= FS candidates' records go to their staged rows straight from the
-            // registers the prefetch filled
-            const int rank = __popcll(cand & lt_mask);
-            __builtin_amdgcn_wave_barrier();
-            if (cur_reach && rank < FS) {
-                s_rec0[rank] = a0;
-                s_rec1[rank] = a1;
-                s_cgid[rank] = cur_gid;
-            }
+        // the chunk in front: requested now, consumed after this one (the loop's last iteration requests nothing: the guard
+        // is per lane, so there is no wave-uniform branch around the loads)
+        fetch(chunk > 0 ? base - WAVE : 0xFFFFFF00u, reach, gid);
+#if SR_BWD_ROW_PREFETCH > 0
+        asm volatile("" ::"v"(pf_sink));          // the previous chunk's touches have been waited for by now
+        pf_sink = 0.0f;
+        if (reach) {
+            const float* row = reinterpret_cast<const float*>(featp4) + (size_t)__umul24(gid - row0, (uint32_t)CP4) * 4u + (uint32_t)c0;
+#pragma unroll
+            for (int k = 0; k < SR_BWD_ROW_PREFETCH; ++k) pf_sink += row[k * 32 < NCP ? k * 32 : NCP - 1];
         }
-        fetch(base + WAVE, reach, gid, a0, a1);  // next chunk, consumed after this one
+#endif
         const uint32_t idx0 = base - list0;
 #pragma unroll 1
         while (cand != 0) {
-            // ---- stage the feature rows of the next <= FS candidates ----
+            // ---- stage the records and feature rows of the LAST <= FS candidates (row 0 = the deepest) ----
             BP_T(ts0);
             const int ncand = min(FS, (int)__popcll(cand));
+            const int rank = __popcll(cand & gt_mask);
+            const bool mine = cur_reach && ((cand >> lane) & 1ull) && rank < FS;
             __builtin_amdgcn_wave_barrier();
-            if (!first_round) {
-                // more than FS candidates in one chunk (rare): the rest re-read their records
-                const int rank = __popcll(cand & lt_mask);
-                if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) {
-                    const size_t j = (size_t)base + lane;
-                    s_rec0[rank] = irec[2 * j];
-                    s_rec1[rank] = irec[2 * j + 1];
-                    s_cgid[rank] = cur_gid;
-                }
+            if (mine) s_cgid[rank] = cur_gid;
+            float4 rec_a = make_float4(0.f, 0.f, 0.f, 0.f), rec_b = rec_a;
+            if (mine) {
+                const size_t j = (size_t)base + lane;
+                rec_a = irec[2 * j];
+                rec_b = irec[2 * j + 1];
             }
-            first_round = false;
             __builtin_amdgcn_wave_barrier();
             // 16-byte pieces of the 16-byte-aligned padded rows
 #if SR_BWD_LDSDMA
@@ -507,22 +507,25 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
 #else
 #pragma unroll SR_BWD_STAGE_UNROLL
             for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
                 reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(s_cgid[row] - row0, (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];
             }
-            __builtin_amdgcn_wave_barrier();
 #endif
+            if (mine) {
+                s_rec0[rank] = rec_a;
+                s_rec1[rank] = rec_b;
+            }
+            __builtin_amdgcn_wave_barrier();
 #ifdef SR_BWD_PROFILE
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
             BP_T(ts1);
             BP_ADD(1, ts1 - ts0);
             BP_ADD(9, 1);
-            // One pair of candidates (list positions j0 < j1, staged rows r0, r1); qm0 / qm1 are
+            // One pair of candidates (list positions j0 > j1: the deeper one first; staged rows r0, r1); qm0 / qm1 are
             // their dot products when the matrix pipe already produced them.
             auto process_pair = [&](int j0, int j1, bool has1, int r0, int r1, float qm0, float qm1) {
                 BP_T(tp0);
@@ -557,42 +560,42 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                         qd1 += f1[ch] * g[ch];
                     }
                     // a round's last pair may have no second member: row r0 + 1 is then stale (or never written: any bit
-                    // pattern), and S = fma(-0, NaN, S) would poison the chain — everything else of that half is masked
+                    // pattern), and d = q - A with q = NaN would poison the chain — everything else of that half is masked
                     qd1 = has1 ? qd1 : 0.0f;
                 }
-                // ---- Gaussian 0, then Gaussian 1 (sequential in T and S) ----
-                // Branch-free: a miss has w = 0 (S unchanged), dA = 0 and keeps T.  1 / (1 - alpha) is the
-                // hardware reciprocal (1 ulp; alpha <= 0.99 keeps the argument >= 0.01): the correctly
-                // rounded __frcp_rn expanded to a 10-instruction division per Gaussian.  T itself follows
-                // the forward's two-rounding transmit() bit for bit.
-                const float w0 = hit0 ? al0 * T : 0.0f;
-                float dA0, dA1;
-                float w1;
+                // ---- Gaussian 0 (the deeper one), then Gaussian 1: sequential in T and A ----
+                // Branch-free: a miss keeps T and A and has w = 0, E = G dA = 0.  T_i = T_{i+1} / (1 - alpha) through the hardware
+                // reciprocal (1 ulp; alpha <= 0.99 keeps the argument >= 0.01) — a relative error per step, harmless; the correctly
+                // rounded division would be 10 instructions per Gaussian.
+                float dA0, dA1, w0, w1;
                 if constexpr (DET) {
-                    // accurate mode: the suffix sum and dL/dalpha in double
-                    if (replay) {   // (wave-uniform) only the total of the w_j q_j terms and the transmittance chain
-                        s_replay = fma((double)w0, (double)qd0, s_replay);
-                        T = hit0 ? transmit(T, al0) : T;
-                        const float w1r = hit1 ? al1 * T : 0.0f;
-                        s_replay = fma((double)w1r, (double)qd1, s_replay);
-                        T = hit1 ? transmit(T, al1) : T;
-                        return;
-                    }
-                    S = fma(-(double)w0, (double)qd0, S);
-                    dA0 = (float)fma((double)T, (double)qd0, -S / (1.0 - (double)al0));
-                    T = hit0 ? transmit(T, al0) : T;
-                    w1 = hit1 ? al1 * T : 0.0f;
-                    S = fma(-(double)w1, (double)qd1, S);
-                    dA1 = (float)fma((double)T, (double)qd1, -S / (1.0 - (double)al1));
-                    T = hit1 ? transmit(T, al1) : T;
+                    const double Ti0 = hit0 ? T / (1.0 - (double)al0) : T;
+                    const double d0 = (double)qd0 - A;
+                    dA0 = (float)(Ti0 * d0);
+                    const double ah0 = hit0 ? (double)al0 : 0.0;
+                    A = fma(ah0, d0, A);
+                    w0 = (float)(ah0 * Ti0);
+                    const double Ti1 = hit1 ? Ti0 / (1.0 - (double)al1) : Ti0;
+                    const double d1 = (double)qd1 - A;
+                    dA1 = (float)(Ti1 * d1);
+                    const double ah1 = hit1 ? (double)al1 : 0.0;
+                    A = fma(ah1, d1, A);
+                    w1 = (float)(ah1 * Ti1);
+                    T = Ti1;
                 } else {
-                    S = fmaf(-w0, qd0, S);
-                    dA0 = fmaf(T, qd0, -S * __builtin_amdgcn_rcpf(1.0f - al0));   // (finite also for a miss; E = G dA = 0 there)
-                    T = hit0 ? transmit(T, al0) : T;
-                    w1 = hit1 ? al1 * T : 0.0f;
-                    S = fmaf(-w1, qd1, S);
-                    dA1 = fmaf(T, qd1, -S * __builtin_amdgcn_rcpf(1.0f - al1));
-                    T = hit1 ? transmit(T, al1) : T;
+                    const float Ti0 = hit0 ? T * __builtin_amdgcn_rcpf(1.0f - al0) : T;
+                    const float d0 = qd0 - A;
+                    dA0 = Ti0 * d0;                               // (finite also for a miss; E = G dA = 0 there)
+                    const float ah0 = hit0 ? al0 : 0.0f;
+                    A = fmaf(ah0, d0, A);
+                    w0 = ah0 * Ti0;
+                    const float Ti1 = hit1 ? Ti0 * __builtin_amdgcn_rcpf(1.0f - al1) : Ti0;
+                    const float d1 = qd1 - A;
+                    dA1 = Ti1 * d1;
+                    const float ah1 = hit1 ? al1 : 0.0f;
+                    A = fmaf(ah1, d1, A);
+                    w1 = ah1 * Ti1;
+                    T = Ti1;
                 }
                 const float E0 = G0 * dA0, E1 = G1 * dA1;   // (0 for a miss)
                 const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];
@@ -716,16 +719,16 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             };
 #pragma unroll 1
             for (int slot = 0; slot < ncand; slot += (DOTM ? 4 : 2)) {
-                // pop the next two (four) candidates; hasK are wave-uniform
+                // pop the next two (four) candidates, deepest first; hasK are wave-uniform
                 const bool has1 = slot + 1 < ncand, has2 = DOTM && slot + 2 < ncand, has3 = DOTM && slot + 3 < ncand;
-                const int j0 = __builtin_ctzll(cand);
-                cand &= cand - 1;
-                const int j1 = has1 ? __builtin_ctzll(cand) : j0;
-                if (has1) cand &= cand - 1;
-                const int j2 = has2 ? __builtin_ctzll(cand) : j1;
-                if (has2) cand &= cand - 1;
-                const int j3 = has3 ? __builtin_ctzll(cand) : j2;
-                if (has3) cand &= cand - 1;
+                const int j0 = 63 - __builtin_clzll(cand);
+                cand &= ~(1ull << j0);
+                const int j1 = has1 ? 63 - __builtin_clzll(cand) : j0;
+                if (has1) cand &= ~(1ull << j1);
+                const int j2 = has2 ? 63 - __builtin_clzll(cand) : j1;
+                if (has2) cand &= ~(1ull << j2);
+                const int j3 = has3 ? 63 - __builtin_clzll(cand) : j2;
+                if (has3) cand &= ~(1ull << j3);
                 float qm[4] = {0.f, 0.f, 0.f, 0.f};
                 BP_T(td0);
                 if (DOTM) {
@@ -742,7 +745,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             }
         }
     }
-    }   // lpass
     if constexpr (TM) { if (nslot - e0 > 0) reduce_e(nslot - e0); }
     if (MFMA && nslot > 0) flush_panel(nslot);
 #ifdef SR_BWD_PROFILE
