@@ -179,7 +179,7 @@ static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t 
     // mid-list checkpoints of the forward for split launches (small frames, narrow layouts): the maximum is reserved
     // whenever the shape qualifies, whatever the run-time knob says
     const bool ck = C <= 4 && 4 * (size_t)tiles <= (size_t)SPLIT_MAX_WAVES;
-    L.ckpt = take(ck ? nv * (size_t)(SPLIT_PARTS - 1) * (size_t)(C + 2) * (size_t)W * (size_t)H * sizeof(float) : 16);
+    L.ckpt = take(ck ? nv * (size_t)SPLIT_PARTS * (size_t)(C + 2) * (size_t)W * (size_t)H * sizeof(float) : 16);
     L.tile_order = take(4 * (tiles > 0 ? tiles : 1));
     L.bytes = o;
     return L;

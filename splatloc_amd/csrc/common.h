@@ -112,7 +112,7 @@ struct BinView {
     uint8_t* imask;       // [R] bit q: the Gaussian may reach quadrant q of its tile
     float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows); shared by the views
     float* gacc;          // [V * P * gacc_row_floats(C)] backward gradient accumulator rows (one per row)
-    float* ckpt;          // [V][SPLIT_PARTS - 1][C + 2][H * W] list checkpoints of the forward (T, colours, depth), split launches only
+    float* ckpt;          // [V][SPLIT_PARTS][C + 2][H * W] segment records of the forward (T in front of the segment, its own colours, depth), split launches only
     uint32_t* tile_order; // [V * tiles] global tile ids, longest list first: the launch order of the compositing kernels
 };
 struct ImgView {
@@ -173,14 +173,20 @@ __host__ __device__ static inline int gacc_row_floats(int C) { return (gacc_mome
 // One small frame alone (SplatLoc's color_refinement: 640x480, one view) is 4 800 quadrant-waves on a machine with room
 // for ~8 000: every wave starts at once and the compositing kernel lasts as long as its LONGEST list.  For such launches
 // (narrow layouts, at most SPLIT_MAX_WAVES quadrant-waves: measured 233 -> 180 us at 4 800 waves, 201 -> 187 us at 12 900,
-// 810 -> 790 us at 24 000, and a LOSS at 64 500: 783 -> 871 us) the forward checkpoints every pixel's state (T, colours, depth) at the quarter
-// points of the tile's list and the backward runs SPLIT_PARTS waves per quadrant, one per quarter of the list: wave k > 0
-// starts from checkpoint k (T_k, S_k = S_total - C_k . g - D_k g_D).  The backward only needs the list up to the quadrant's
+// 810 -> 790 us at 24 000, and a LOSS at 64 500: 783 -> 871 us) the forward records, per quarter of the tile's list, every pixel's
+// transmittance in front of it and the colours / depth that quarter ALONE contributes, and the backward runs SPLIT_PARTS waves
+// per quadrant, one per quarter.  The backward walks back to front (round 4): a wave whose quarter ends in front of a pixel's last
+// contributor starts from the boundary state T_b, A_b = (sum of the LATER quarters' colours . g + depth g_D + T_final (bg . g - g_A)) / T_b
+// — segment sums accumulated from zero, accurate relative to their own magnitude (rounds 1-3 subtracted a prefix from the image:
+// an absolute error of 1e-7 |image| in a remainder of size T_b |image|).  The backward only needs the list up to the quadrant's
 // deepest contributor (63 % of it on average), so quarters balance better than halves.  The forward itself — T chain,
 // n_contrib, final_T, the images — is untouched, so every bit-exact contract holds.  Lists shorter than SPLIT_MIN_LIST
 // are not split.
+// Round 4: the threshold is 6 144 quadrant-waves (one 640x480 frame is 4 800), not 26 000: the segment sums cost the forward
+// 8 % and the back-to-front backward no longer gains from splitting a 24 000-wave window (5 views at 640x480: backward 0.777 ms
+// split vs 0.725 ms whole, forward 0.418 vs 0.393 ms), while one frame alone still does (backward 132 -> 102 us).
 #ifndef SR_SPLIT_MAX_WAVES
-#define SR_SPLIT_MAX_WAVES 26000
+#define SR_SPLIT_MAX_WAVES 6144
 #endif
 constexpr int SPLIT_MAX_WAVES = SR_SPLIT_MAX_WAVES;
 constexpr int SPLIT_MIN_LIST = 256;

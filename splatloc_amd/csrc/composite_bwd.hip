@@ -230,8 +230,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     const int view = (V == 1) ? 0 : gtile / tiles;      // wave-uniform (scalar)
     const int tile = gtile - view * tiles;
     const uint32_t row0 = (uint32_t)view * (uint32_t)P;  // accumulator rows are per (view, Gaussian), feature rows shared
-    const float* __restrict__ out_color = grads.out_color[view];
-    const float* __restrict__ out_depth = grads.out_depth[view];
     const float* __restrict__ dL_dcolor = grads.dL_dcolor[view];
     const float* __restrict__ dL_ddepth = grads.dL_ddepth[view];
     const float* __restrict__ dL_dalpha = grads.dL_dalpha[view];
@@ -269,10 +267,9 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     uint32_t last = 0;
     if (inside) {
         last = n_contrib[pix];
-        // a split launch's segment that ends in FRONT of this pixel's last contributor starts from the forward's checkpoint at
-        // its upper boundary instead: T_b, and A_b = (S_total - C_b . g - D_b g_D) / T_b with S_total = out_color . g + ...
+        // a split launch's segment that ends in FRONT of this pixel's last contributor starts from the boundary state rebuilt
+        // from the forward's segment records (common.h): T_b, and A_b = (what the later segments contribute) / T_b
         const bool from_ckpt = split && seg < SPLIT_PARTS - 1 && list0 + last > end0;
-        float s_tot = 0.0f;     // only for from_ckpt pixels
         float s_end = 0.0f;
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
@@ -283,7 +280,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             if (c >= gc && c != C_total - 1) gv = 0.0f;
             g[ch] = gv;
             if (grads.bg && c < grads.bg_channels) s_end = fmaf(grads.bg[c], gv, s_end);
-            if constexpr (NC <= 4) { if (from_ckpt) s_tot = fmaf(out_color[(size_t)c * plane + pix], gv, s_tot); }
         }
         float gA = 0.0f;
         if (AUX && first_pass) {
@@ -295,14 +291,18 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         A = (ST)s_end;
         if constexpr (NC <= 4) {
             if (from_ckpt) {
-                const float* ck = ckpt_all + ((size_t)view * (SPLIT_PARTS - 1) + seg) * (C_total + 2) * plane + pix;
-                if (AUX && first_pass) s_tot += out_depth[pix] * gD - final_T[pix] * gA;
+                // later segments first (the smallest contributions), this boundary's neighbour last
+                float sfx = final_T[pix] * s_end;
+                const float* rec0 = ckpt_all + (size_t)view * SPLIT_PARTS * (C_total + 2) * plane + pix;
+                for (int k = SPLIT_PARTS - 1; k > seg; --k) {
+                    const float* ck = rec0 + (size_t)k * (C_total + 2) * plane;
 #pragma unroll
-                for (int ch = 0; ch < NC; ++ch) s_tot = fmaf(-ck[(size_t)(1 + ch) * plane], g[ch], s_tot);
-                if (AUX) s_tot = fmaf(-ck[(size_t)(1 + C_total) * plane], gD, s_tot);
-                const float Tb = ck[0];
+                    for (int ch = 0; ch < NC; ++ch) sfx = fmaf(ck[(size_t)(1 + c0 + ch) * plane], g[ch], sfx);
+                    if (AUX) sfx = fmaf(ck[(size_t)(1 + C_total) * plane], gD, sfx);
+                }
+                const float Tb = rec0[(size_t)(seg + 1) * (C_total + 2) * plane];
                 T = (ST)Tb;
-                A = (ST)(s_tot / Tb);        // (T_b >= 1e-4: the pixel was still active at the boundary)
+                A = (ST)(sfx / Tb);        // (T_b >= 1e-4: the pixel was still active at the boundary)
             }
         }
     } else {

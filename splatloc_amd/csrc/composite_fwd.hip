@@ -92,7 +92,7 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                      const uint8_t* __restrict__ imask, const float4* __restrict__ featp4,
                      const float* __restrict__ bg, WinOut outs,
                      float* __restrict__ final_T_all, uint32_t* __restrict__ n_contrib_all,
-                     float* __restrict__ ckpt_all /*split launches (common.h): [V][SPLIT_PARTS - 1][NC + 2][H * W] list checkpoints, else null*/,
+                     float* __restrict__ ckpt_all /*split launches (common.h): [V][SPLIT_PARTS][NC + 2][H * W] segment records, else null*/,
                      const uint32_t* __restrict__ tile_order /*launch order (binning.hip), or null*/)
 {
     using Cfg = FwdCfg<NC>;
@@ -165,22 +165,35 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
     fetch(beg, reach, gid, a0, a1);
 
     bool wave_done = __builtin_amdgcn_ballot_w64(active) == 0;
-    // split launches: wave k > 0 of this quadrant's backward starts at list entry beg + k * part
+    // split launches (common.h): the backward runs SPLIT_PARTS waves per quadrant, one per part of the list.  Segment record k
+    // = { T in front of the segment's first entry, the colours and the depth the segment ALONE contributes } — segment sums
+    // are accumulated from zero, so they are accurate relative to their own (transmittance-scaled) magnitude; the backward
+    // rebuilds "what lies behind a boundary" from the sums of the later segments (a prefix C_k subtracted from the image
+    // would carry the image's rounding, 1e-7 |C|, into a remainder of size T_k |C|).
     const uint32_t part = (NC <= 4 && ckpt_all != nullptr) ? split_part(end - beg) : 0u;
     uint32_t ck_at = part ? beg + part : 0xFFFFFFFFu;
     int ck_k = 0;
+    float sacc[NV > 0 ? NV : 1], sD = 0.0f;     // the current segment's own sums (split launches only)
+#pragma unroll
+    for (int ch = 0; ch < NV; ++ch) sacc[ch] = 0.0f;
+    auto store_segment = [&](int k, bool with_next_T) {
+        if (inside) {
+            const size_t pl = (size_t)H * W;
+            float* ck = ckpt_all + ((size_t)view * SPLIT_PARTS + k) * (NC + 2) * pl + (size_t)py * W + px;
+#pragma unroll
+            for (int ch = 0; ch < NV; ++ch) ck[(size_t)(1 + ch) * pl] = sacc[ch];
+            ck[(size_t)(1 + NV) * pl] = sD;
+            if (with_next_T) ck[(size_t)(NC + 2) * pl] = T;     // plane 0 of record k + 1
+        }
+    };
 #pragma unroll 1
     for (uint32_t base = beg; base < end && !wave_done; base += WAVE) {
         if (NC <= 4) {
-            if (base == ck_at) {   // every pixel's state in front of this entry: T, the colours so far, the depth so far
-                if (inside) {
-                    const size_t pl = (size_t)H * W;
-                    float* ck = ckpt_all + ((size_t)view * (SPLIT_PARTS - 1) + ck_k) * (NC + 2) * pl + (size_t)py * W + px;
-                    ck[0] = T;
+            if (base == ck_at) {   // a segment ends in front of this entry
+                store_segment(ck_k, true);
 #pragma unroll
-                    for (int ch = 0; ch < NV; ++ch) ck[(size_t)(1 + ch) * pl] = acc[ch];
-                    ck[(size_t)(1 + NV) * pl] = D;
-                }
+                for (int ch = 0; ch < NV; ++ch) sacc[ch] = 0.0f;
+                sD = 0.0f;
                 ++ck_k;
                 ck_at = ck_k < SPLIT_PARTS - 1 ? ck_at + part : 0xFFFFFFFFu;
             }
@@ -269,6 +282,13 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 }
                 if (MFMA) D += p0.z * w0 + p1.z * w1;
                 else D = fmaf(p1.z, w1, fmaf(p0.z, w0, D));
+                if constexpr (NC <= 4) {
+                    if (part) {     // (wave-uniform) the segment's own sums: never read by this kernel's images
+#pragma unroll
+                        for (int ch = 0; ch < NV; ++ch) sacc[ch] = fmaf(f1[ch], w1, fmaf(f0[ch], w0, sacc[ch]));
+                        sD = fmaf(p1.z, w1, fmaf(p0.z, w0, sD));
+                    }
+                }
                 if (MFMA) {
                     const float a = s_feat[((lane >> 5) ? s1 : slot) * NCP + (lane & 31)];  // A[i = ch][k = g]
                     float b0 = w0, b1 = w1;
@@ -281,6 +301,15 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
         }
     }
 
+    if constexpr (NC <= 4) {
+        if (part) {
+            store_segment(ck_k, false);
+#pragma unroll
+            for (int ch = 0; ch < NV; ++ch) sacc[ch] = 0.0f;
+            sD = 0.0f;
+            for (int k = ck_k + 1; k < SPLIT_PARTS; ++k) store_segment(k, false);   // segments the wave never reached contribute nothing
+        }
+    }
     const size_t plane = (size_t)H * W;
     if (MFMA) {
         mfma_drain(accA, accB);

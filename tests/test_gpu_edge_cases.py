@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from splatloc_amd.synthetic import make_scene
-from tests.helpers import HipRun, assert_grad_close, oracle_backward, oracle_forward
+from tests.helpers import HipRun, assert_grad_close, assert_grad_rows_close, oracle_backward, oracle_forward
 from tests.test_gpu_parity import _check_backward, _check_forward
 
 pytestmark = pytest.mark.gpu
@@ -229,10 +229,11 @@ def test_empty_scene_backward_zeroes_pose_gradients():
 
 @pytest.mark.parametrize("C,aux", [(4, True), (3, True), (4, False), (1, True)])
 def test_split_backward_matches_unsplit(C, aux):
-    """Small frames of narrow layouts run the backward as FOUR waves per quadrant, one per quarter of the tile's list, the
-    later ones starting from the forward's checkpoints (T_k, S_k = S_total - C_k . g - D_k g_D; common.h).  Same images
-    bit for bit (the forward's arithmetic is untouched) and the same gradients as the one-wave-per-quadrant backward, to
-    float-atomic rounding — and to 1e-5 in the deterministic-sum mode — on deep lists (hundreds of entries per tile)."""
+    """One small frame of a narrow layout runs the backward as FOUR waves per quadrant, one per quarter of the tile's list; a
+    wave whose quarter ends in front of a pixel's last contributor starts from the boundary state rebuilt from the forward's
+    segment records (T_b, A_b = what the later quarters contribute / T_b; common.h).  Same images bit for bit (the forward's
+    image arithmetic is untouched) and the same gradients as the one-wave-per-quadrant backward per gradient ROW, on deep lists
+    (hundreds of entries per tile).  (The deterministic mode never splits: both of its runs are the un-split kernel.)"""
     from splatloc_amd import _native
     lib = _native.load()
     sc = make_scene(40_000, 256, 256, C, seed=90 + C, scale_median=0.05)
@@ -256,7 +257,8 @@ def test_split_backward_matches_unsplit(C, aux):
             if det:
                 assert_grad_close(n, gb, ga, rtol=2e-5, atol_scale=2e-6)
             else:
-                assert_grad_close(n, gb, ga)
+                assert_grad_close(n, gb, ga, rtol=1e-4, atol_scale=2e-5)
+                assert_grad_rows_close("rows " + n, gb, ga, rtol=1e-4, row_atol=1e-3, allow_frac=1e-3, outlier_factor=100.0)
     f = oracle_forward(sc)
     bo = oracle_backward(f, sc, use_depth=aux, use_alpha=aux)
     assert_grad_close("dL_dmeans3D vs oracle", b.np(b.means3D.grad), bo["dL_dmeans3D"])
