@@ -279,7 +279,18 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             float gv = c < gc ? dL_dcolor[(size_t)c * plane + pix] : (dL_dlast ? dL_dlast[pix] : 0.0f);
             if (c >= gc && c != C_total - 1) gv = 0.0f;
             g[ch] = gv;
-            if (grads.bg && c < grads.bg_channels) s_end = fmaf(grads.bg[c], gv, s_end);
+        }
+        {   // s_end = bg . g: AFTER the plane loads and branch-free (clamped index + select) — a conditional scalar load inside the
+            // loop above put a branch between the plane loads and serialised them (measured: backward + 6 % on S2)
+            const float* bgp = grads.bg ? grads.bg : final_T_all;      // (any readable address; nb = 0 selects 0 below)
+            const int nb = grads.bg ? grads.bg_channels : 0;
+            const int hi = nb > 0 ? nb - 1 : 0;
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) {
+                const int c = c0 + ch;
+                const float b = bgp[c < hi ? c : hi];
+                s_end = fmaf(c < nb ? b : 0.0f, g[ch], s_end);
+            }
         }
         float gA = 0.0f;
         if (AUX && first_pass) {
