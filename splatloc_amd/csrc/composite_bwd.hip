@@ -271,14 +271,23 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         // from the forward's segment records (common.h): T_b, and A_b = (what the later segments contribute) / T_b
         const bool from_ckpt = split && seg < SPLIT_PARTS - 1 && list0 + last > end0;
         float s_end = 0.0f;
+        // planes [0, gc) behind dL_dcolor, the LAST channel's plane behind dL_dlast, nothing in between.  Branch-free on purpose:
+        // every channel loads from a valid address chosen by selects (plane 0 when the channel has no gradient) and the value
+        // is selected afterwards — with a branch per channel the set-up is 35 basic blocks and the compiler waits for every
+        // second load before issuing the next (seen in the .s: 21 x s_waitcnt vmcnt(0) between the plane loads, backward + 4 %).
+        float gvals[NC];
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
             const int c = c0 + ch;
-            // planes [0, gc) behind dL_dcolor, the LAST channel's plane behind dL_dlast, nothing in between.  Kept as plain
-            // selects: with the loads inside branches the plane loads of the set-up no longer overlap (backward + 8 %).
-            float gv = c < gc ? dL_dcolor[(size_t)c * plane + pix] : (dL_dlast ? dL_dlast[pix] : 0.0f);
-            if (c >= gc && c != C_total - 1) gv = 0.0f;
-            g[ch] = gv;
+            const bool lastc = c == C_total - 1 && c >= gc && dL_dlast != nullptr;
+            const float* src = lastc ? dL_dlast : dL_dcolor + (size_t)(c < gc ? c : 0) * plane;
+            gvals[ch] = src[pix];
+        }
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            const int c = c0 + ch;
+            const bool take = c < gc || (c == C_total - 1 && dL_dlast != nullptr);
+            g[ch] = take ? gvals[ch] : 0.0f;
         }
         {   // s_end = bg . g: AFTER the plane loads and branch-free (clamped index + select) — a conditional scalar load inside the
             // loop above put a branch between the plane loads and serialised them (measured: backward + 6 % on S2)
