@@ -80,9 +80,11 @@ def actual_bytes(P, V, R, W, H, C, tiles):
         "emit": P * 20 + R * 8,                                # offsets, rect sources in; (tile id, gaussian id) out
         "tile_sort": R * 20 * tile_passes,                     # per pass: histogram 4 + scatter 8 in + 8 out
         "ranges": tiles * 8,
-        "payload": R * (8 + 32 + 33) + ((P * 4 * (C + CP)) if C % 4 else 0),   # ids + gathered records in; records + mask out; padded feature table
-        "composite_fwd": R * 37 + V * 4 * CP + W * H * (4 * C + 16),
-        "composite_bwd": R * 37 + V * 4 * CP + W * H * (8 * C + 20) + 2 * V * 4 * grow,
+        "payload": R * (8 + 32 + 36) + ((P * 4 * (C + CP)) if C % 4 else 0),   # ids + gathered records in; records + packed word out; padded feature table
+        "composite_fwd": R * 36 + V * 4 * CP + W * H * (4 * C + 16),           # packed word + record per entry; staged rows; planes out
+        # round 4: the back-to-front backward reads dL/dout (4 C + 8) + n_contrib, final_T (8) per pixel, NOT the forward's planes;
+        # records only for its quadrant's candidates (upper bound: every entry)
+        "composite_bwd": R * 36 + V * 4 * CP + W * H * (4 * C + 16) + 2 * V * 4 * grow,
         "preprocess_bwd": P * (4 * grow + 44 + 32 + 7) + P * (4 * C + 12 + 12 + 4 + 12 + 16),
     }
 

@@ -222,9 +222,9 @@ int splatraster_forward_window_render(const splatraster_settings* s, int32_t n_v
                                       const int64_t* num_rendered, const float* bg, const float* colors_precomp,
                                       void* geometry, void* binning, void* image, void* stream);
 /* Backward of the whole window: the parameter gradients are the SUM over the views (written once, overwritten),
- * dL_dmeans2D per view.  `bg`: the background the forward was given (or NULL = zeros); read only by the deterministic /
- * accurate debug mode, which rebuilds the suffix sum's exact tail T_final (bg . g - g_A) instead of taking it from the
- * forward's images (splatraster_debug_set_deterministic). */
+ * dL_dmeans2D per view.  `bg`: the background the forward was given (NULL = zeros) — the back-to-front walk starts every pixel
+ * at A = bg . g - g_A (round 4; rounds 1-3 took the background's share from the forward's colour planes, which the backward
+ * no longer reads). */
 int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
                                 int32_t P, const int64_t* num_rendered, const float* bg, const float* means3D,
                                 const float* colors_precomp, const float* scales, const float* rotations,
@@ -509,26 +509,24 @@ int splatraster_poll_errors(void);
 /* test hooks: SOFT spin bound of the look-backs (default 1 << 24; 0 makes every block that has to wait at
  * all report), and y[i] = the device's 2^x (the alpha arithmetic shared with the CPU oracle). */
 int splatraster_debug_set_spin_limit(uint32_t limit);
-/* Deterministic AND accurate debug mode of the backward (process-wide switch, default off).  The compositing
- * backward sums per-(wave, Gaussian) partials into per-Gaussian rows with float atomics, whose arrival
- * order — and therefore the last bits of every gradient — changes from run to run; and its front-to-back formulation
- * carries the suffix sum S_i = S_total - sum_{j<=i} w_j q_j in float32 (an absolute error of ~1e-7 |S_total| that is up to
- * 1e-3 of the S_i of a Gaussian behind T = 1e-4).  With the switch on,
+/* Deterministic debug mode of the backward (process-wide switch, default off).  The compositing backward sums
+ * per-(wave, Gaussian) partials into per-Gaussian rows with float atomics, whose arrival order — and therefore the last bits of
+ * every gradient — changes from run to run.  With the switch on,
  *   (1) each partial is converted to fixed point and accumulated with 64-bit INTEGER atomics (associative: the totals are
  *       bit-reproducible); the fixed point is chosen PER ELEMENT, 2^-44 of the largest partial the element receives
- *       (a first pass of the kernel takes that maximum, also an associative reduction);
- *   (2) S_total is rebuilt in double from the very terms w_j q_j the main pass subtracts again (a replay pass over the
- *       list inside the kernel) plus the exact tail T_final (bg . g - g_A), and S, dL/dalpha are carried in double.
- * Every gradient row then agrees with the CPU oracle (double accumulation) to float rounding of the per-pixel terms,
- * relative to the ROW's own magnitude (tests/test_gpu_window.py, full size).  ~4 x slower: four list traversals.
- * Meant for regression hunting and strict tests. */
+ *       (a first pass of the kernel takes that maximum, also an associative reduction) — round 3's single 2^-40 quantised the
+ *       small rows of a large scene;
+ *   (2) the per-pixel state of the back-to-front walk (T, A) is carried in double; split launches are not used.
+ * Two passes of the kernel (~2.5 x slower).  Meant for regression hunting and the strictest tests.  (The NORMAL path is accurate
+ * per gradient row since round 4 — it walks the lists back to front like the lineage; rounds 1-3 walked front to back and
+ * carried an absolute float32 error in the suffix sum.) */
 int splatraster_debug_set_deterministic(int on);
 /* A/B hook: launches of the C = 4..15 backward with at most this many quadrant-waves take the small-layout panel
  * variant; < 0 restores the built-in default. */
 int splatraster_debug_set_small_panel_max_waves(int waves);
 /* A/B hook: narrow-layout launches (C <= 4) with at most this many quadrant-waves split every list of >= 256 entries in
  * four for the backward (the forward checkpoints every pixel's state at the quarter points of its tile's list).
- * 0 = never, < 0 or > 26000 = the built-in default 26000.  Must not change between a forward and its backward. */
+ * 0 = never, < 0 or > 6144 = the built-in default 6144 (one 640x480 frame).  Must not change between a forward and its backward. */
 int splatraster_debug_set_split_max_waves(int waves);
 /* A/B / test hook: instance count from which the per-instance payload is written with streaming (non-temporal) stores
  * (DESIGN.md §11); < 0 restores the built-in default (8 Mi instances), 0 = always.  Results never depend on it. */

@@ -145,9 +145,9 @@ int launch_ranges_clear(int32_t tiles, uint32_t* ranges, hipStream_t stream)
 // (forward and backward compositing, four quadrant-waves per tile) streams it with coalesced
 // loads instead of chasing id -> record through 16-byte gathers scattered over HBM:
 //   irec[2j] = (pixel x, y, depth, radius) of point_list[j], irec[2j+1] = its conic pre-scaled for
-//   the compositing kernels (payload_conic) and opacity;  imask[j] = reach bits.
+//   the compositing kernels (payload_conic) and opacity;  ipack[j] = point_list[j] | reach bits << 24 (ids < 2^24: checked on the host).
 #ifndef SR_PAYLOAD_NT_MIN
-#define SR_PAYLOAD_NT_MIN (8ll << 20)   // instances from which the payload is written with streaming stores (33 B each: 264 MB)
+#define SR_PAYLOAD_NT_MIN (8ll << 20)   // instances from which the payload is written with streaming stores (36 B each: 288 MB)
 #endif
 static int64_t g_payload_stream_min = SR_PAYLOAD_NT_MIN;
 void set_payload_stream_min(int64_t instances) { g_payload_stream_min = instances < 0 ? (int64_t)SR_PAYLOAD_NT_MIN : instances; }
@@ -156,7 +156,7 @@ template <bool NT>
 __global__ void __launch_bounds__(256)
 payload_kernel(int64_t R, int gx, int tiles_per_view, int V, const uint32_t* __restrict__ point_list,
                const uint32_t* __restrict__ tile_list, const float4* __restrict__ rec,
-               float4* __restrict__ irec, uint8_t* __restrict__ imask, uint32_t* __restrict__ ranges)
+               float4* __restrict__ irec, uint32_t* __restrict__ ipack, uint32_t* __restrict__ ranges)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= R) return;
@@ -167,7 +167,7 @@ payload_kernel(int64_t R, int gx, int tiles_per_view, int V, const uint32_t* __r
     for (int v = 1; v < V && tl >= (uint32_t)tiles_per_view; ++v) tl -= (uint32_t)tiles_per_view;
     const uint32_t ty = tl / (uint32_t)gx, tx = tl - ty * (uint32_t)gx;
     const float4 c1 = payload_conic(a1);   // pre-scaled for gauss_log2 (composite_common.h)
-    const uint8_t m = (uint8_t)quadrant_reach_mask(a0, a1, (float)(tx * TILE), (float)(ty * TILE));
+    const uint32_t m = g | (quadrant_reach_mask(a0, a1, (float)(tx * TILE), (float)(ty * TILE)) << 24);
     if (NT) {
         // Streaming stores for lists larger than the memory-side cache (S2 window: 20 M instances, 657 MB): what is written
         // here is next read after the whole list has gone by, and must not push the 32-byte records this kernel gathers
@@ -177,11 +177,11 @@ payload_kernel(int64_t R, int gx, int tiles_per_view, int V, const uint32_t* __r
         f32x4_t* out = reinterpret_cast<f32x4_t*>(irec) + 2 * j;
         __builtin_nontemporal_store((f32x4_t){a0.x, a0.y, a0.z, a0.w}, out);
         __builtin_nontemporal_store((f32x4_t){c1.x, c1.y, c1.z, c1.w}, out + 1);
-        __builtin_nontemporal_store(m, imask + j);
+        __builtin_nontemporal_store(m, ipack + j);
     } else {
         irec[2 * j] = a0;
         irec[2 * j + 1] = c1;
-        imask[j] = m;
+        ipack[j] = m;
     }
     // per-tile [start, end) of the sorted list (the table was zeroed for the empty tiles)
     if (j == 0 || tile_list[j - 1] != t) ranges[2 * t] = (uint32_t)j;
@@ -194,10 +194,10 @@ int launch_payload(const splatraster_settings& s, int32_t V, int64_t R, const Ge
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
     if (R >= g_payload_stream_min)
         hipLaunchKernelGGL(payload_kernel<true>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, gx * gy, V,
-                           b.point_list, b.tile_list, g.rec, b.irec, b.imask, b.ranges);
+                           b.point_list, b.tile_list, g.rec, b.irec, b.ipack, b.ranges);
     else
         hipLaunchKernelGGL(payload_kernel<false>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, gx, gx * gy, V,
-                           b.point_list, b.tile_list, g.rec, b.irec, b.imask, b.ranges);
+                           b.point_list, b.tile_list, g.rec, b.irec, b.ipack, b.ranges);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

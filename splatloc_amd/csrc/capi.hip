@@ -153,7 +153,7 @@ GeomView geom_view(void* base, int32_t P, int32_t V)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, imask, featp, gacc, ckpt, tile_order, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, ipack, featp, gacc, ckpt, tile_order, bytes;
 };
 static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t H, int32_t C)
 {
@@ -170,7 +170,7 @@ static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t 
     L.ranges = take(8 * (tiles > 0 ? tiles : 1));
     L.sort_tmp = take(sort_tmp_bytes((int64_t)n));
     L.irec = take(32 * n);
-    L.imask = take(n);
+    L.ipack = take(4 * n);
     // padded feature table only when the rows are not already 16-byte aligned (shared by the views)
     L.featp = take((C % 4) ? (size_t)(P > 0 ? P : 1) * padded_channels(C) * sizeof(float) : 16);
     L.gacc = take((size_t)(P > 0 ? P : 1) * nv * gacc_row_floats(C) * sizeof(float));
@@ -197,7 +197,7 @@ BinView bin_view(void* base, int32_t P, int32_t V, int64_t R, int32_t W, int32_t
     v.ranges = reinterpret_cast<uint32_t*>(b + L.ranges);
     v.sort_tmp = b + L.sort_tmp;
     v.irec = reinterpret_cast<float4*>(b + L.irec);
-    v.imask = reinterpret_cast<uint8_t*>(b + L.imask);
+    v.ipack = reinterpret_cast<uint32_t*>(b + L.ipack);
     v.featp = reinterpret_cast<float*>(b + L.featp);
     v.gacc = reinterpret_cast<float*>(b + L.gacc);
     v.ckpt = reinterpret_cast<float*>(b + L.ckpt);

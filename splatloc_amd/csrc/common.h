@@ -81,7 +81,7 @@ struct WinGrad {                     // backward inputs per view
     const float* dL_dlast[MAX_VIEWS];    // gradient plane of channel C - 1 when it travels apart (null = zeros); see gc
     float* dL_dmeans2D[MAX_VIEWS];       // [P,3] output
     int gc;                              // channel planes behind dL_dcolor: C, or C - 1 (then channel C - 1 reads dL_dlast)
-    const float* bg;                     // background (deterministic / accurate mode only: the exact tail of the suffix sum); may be null
+    const float* bg;                     // background: the walk starts at A = bg . g - g_A; may be null (zeros)
     int bg_channels;
 };
 
@@ -109,7 +109,8 @@ struct BinView {
     uint32_t* vals_tmp;   // [R] unsorted rows
     void* sort_tmp;       // radix sort scratch
     float4* irec;         // [2R] per-instance copy of the 32-byte record, in sorted order
-    uint8_t* imask;       // [R] bit q: the Gaussian may reach quadrant q of its tile
+    uint32_t* ipack;      // [R] point_list[j] (a row id < 2^24) | reach bits << 24 (bit q: the Gaussian may reach quadrant q of its tile):
+                          //     ONE word per entry is all a compositing wave prefetches
     float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows); shared by the views
     float* gacc;          // [V * P * gacc_row_floats(C)] backward gradient accumulator rows (one per row)
     float* ckpt;          // [V][SPLIT_PARTS][C + 2][H * W] segment records of the forward (T in front of the segment, its own colours, depth), split launches only

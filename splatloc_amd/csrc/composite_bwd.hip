@@ -173,9 +173,8 @@ template <int NC, bool DET, bool SP, bool AUX>
 __global__ void __launch_bounds__(WAVE, (bwd_min_waves<NC, SP, AUX>()))
 composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass, int tiles /*per view*/, int V,
                      int P /*rows per view*/,
-                     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                     const float4* __restrict__ irec,
-                     const uint8_t* __restrict__ imask, const float4* __restrict__ featp4,
+                     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ ipack /*id | reach bits << 24*/,
+                     const float4* __restrict__ irec, const float4* __restrict__ featp4,
                      WinGrad grads,
                      const float* __restrict__ final_T_all, const uint32_t* __restrict__ n_contrib_all,
                      float* __restrict__ gacc /*[V * P, GROW]*/, int GROW,
@@ -447,54 +446,38 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         }
     };
 
-    // chunk in flight: mask bit and id of list entry base + lane — TWO registers, so that the prefetch really stays in flight
+    // chunk in flight: the packed word (id | reach bits) of list entry base + lane — ONE register, so that the prefetch really stays in flight
     // while the current chunk is processed.  (Rounds 1-3 also prefetched the 32-byte record into eight registers; at 128 VGPRs
     // the compiler spilled them to scratch right behind the loads — `global_load ... s_waitcnt vmcnt(0) ... scratch_store` —
     // which exposed the whole memory latency once per chunk.  The records of the <= FS candidates are now loaded in the staging
     // round, together with their feature rows: one latency per round, as before, and only for this quadrant's candidates.)
-    bool reach = false;
-    uint32_t gid = 0;
-    auto fetch = [&](uint32_t base, bool& r_, uint32_t& g_) {
-        r_ = false;
-        if (base + (uint32_t)lane < end) {
-            const uint32_t j = base + (uint32_t)lane;
-            r_ = (imask[j] >> quad) & 1u;
-            g_ = point_list[j];
-        }
+    // (the word stays RAW — id | reach bits << 24: bit and id are extracted where they are consumed, one chunk later; extracting
+    //  them here made the compiler wait for the load right behind the prefetch, an exposed memory latency per chunk)
+    uint32_t pw = 0;
+    auto fetch = [&](uint32_t base, uint32_t& w_) {
+        w_ = 0u;
+        if (base + (uint32_t)lane < end) w_ = ipack[base + (uint32_t)lane];
     };
-#ifndef SR_BWD_ROW_PREFETCH
-#define SR_BWD_ROW_PREFETCH 0   // n > 0: touch n 128-byte lines of the NEXT chunk's candidate feature rows one chunk ahead (A/B)
-#endif
-    float pf_sink = 0.0f;   // (the touched words are summed into a register nobody reads: the loads just have to be issued)
     // The list is walked from the quadrant's deepest contributor towards the camera, 64 entries at a time (chunk k = entries
     // [beg + 64 k, beg + 64 k + 64)), the candidates of a chunk from the highest list position down.
     if (beg >= end) return;
     const uint64_t gt_mask = (lane == WAVE - 1) ? 0ull : (~0ull << (lane + 1));   // list positions behind this lane's
     const int nchunks = (int)((end - beg + (WAVE - 1)) / WAVE);
-    fetch(beg + (uint32_t)(nchunks - 1) * WAVE, reach, gid);
+    fetch(beg + (uint32_t)(nchunks - 1) * WAVE, pw);
 
 #pragma unroll 1
     for (int chunk = nchunks - 1; chunk >= 0; --chunk) {
         const uint32_t base = beg + (uint32_t)chunk * WAVE;
         BP_T(tc0);
-        uint64_t cand = __builtin_amdgcn_ballot_w64(reach);
+        const bool cur_reach = (pw >> (24 + quad)) & 1u;
+        uint64_t cand = __builtin_amdgcn_ballot_w64(cur_reach);
         BP_T(tc1);
         BP_ADD(0, tc1 - tc0);
         BP_ADD(8, 1);
-        const uint32_t cur_gid = gid;
-        const bool cur_reach = reach;
+        const uint32_t cur_gid = pw & 0xFFFFFFu;
         // the chunk in front: requested now, consumed after this one (the loop's last iteration requests nothing: the guard
         // is per lane, so there is no wave-uniform branch around the loads)
-        fetch(chunk > 0 ? base - WAVE : 0xFFFFFF00u, reach, gid);
-#if SR_BWD_ROW_PREFETCH > 0
-        asm volatile("" ::"v"(pf_sink));          // the previous chunk's touches have been waited for by now
-        pf_sink = 0.0f;
-        if (reach) {
-            const float* row = reinterpret_cast<const float*>(featp4) + (size_t)__umul24(gid - row0, (uint32_t)CP4) * 4u + (uint32_t)c0;
-#pragma unroll
-            for (int k = 0; k < SR_BWD_ROW_PREFETCH; ++k) pf_sink += row[k * 32 < NCP ? k * 32 : NCP - 1];
-        }
-#endif
+        fetch(chunk > 0 ? base - WAVE : 0xFFFFFF00u, pw);
         const uint32_t idx0 = base - list0;
 #pragma unroll 1
         while (cand != 0) {
@@ -815,7 +798,7 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
 #define SR_BWD_LAUNCH(SPV)                                                                                          \
     hipLaunchKernelGGL((composite_bwd_kernel<NC, DET, SPV, AUX>), grid, dim3(WAVE), 0, stream, s.image_width,           \
                        s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, L.V, L.P,      \
-                       b.ranges, b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(feat), *L.grads,       \
+                       b.ranges, b.ipack, b.irec, reinterpret_cast<const float4*>(feat), *L.grads,       \
                        im.final_T, im.n_contrib, gacc, gacc_row_floats(s.channels),                                    \
                        gacc_moment_offset(s.channels), gacc64, ckpt, use_tile_order(L.V, tiles) ? b.tile_order : nullptr, L.det_pass)
     if constexpr (NC >= 4 && NC <= 15 && AUX) {   // C = 3 and below: the flush costs what the 8 saved butterfly values gain (A/B: S0 0.036 vs 0.041 ms)

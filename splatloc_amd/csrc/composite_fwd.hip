@@ -10,7 +10,7 @@
 // cycles waiting.  Here every quadrant walks the tile's list on its own, wave-synchronously,
 // with no __syncthreads anywhere:
 //   * the list is streamed 64 entries at a time from the per-instance payload written by
-//     payload_kernel (binning.hip): reach-mask byte + 32-byte record, contiguous in sorted
+//     payload_kernel (binning.hip): packed word (id | reach mask) + 32-byte record, contiguous in sorted
 //     order -> independent coalesced loads per lane, issued one chunk ahead;
 //   * only entries whose mask says they may reach THIS quadrant become candidates; their
 //     feature rows (4*C bytes) are gathered into LDS, at most FS rows per round;
@@ -87,9 +87,8 @@ template <int NC>
 __global__ void __launch_bounds__(WAVE, (NC <= 4) ? 8 : SR_FWD_MINW)   // narrow layouts stay within 64 registers (8 waves per SIMD)
 composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_aux, int tiles /*per view*/, int V,
                      int P /*rows per view*/,
-                     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                     const float4* __restrict__ irec,
-                     const uint8_t* __restrict__ imask, const float4* __restrict__ featp4,
+                     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ ipack /*id | reach bits << 24*/,
+                     const float4* __restrict__ irec, const float4* __restrict__ featp4,
                      const float* __restrict__ bg, WinOut outs,
                      float* __restrict__ final_T_all, uint32_t* __restrict__ n_contrib_all,
                      float* __restrict__ ckpt_all /*split launches (common.h): [V][SPLIT_PARTS][NC + 2][H * W] segment records, else null*/,
@@ -148,21 +147,21 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
     uint32_t last = 0;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
 
-    // chunk in flight: mask bit, id and record of list entry base + lane
-    bool reach = false;
-    uint32_t gid = 0;
+    // chunk in flight: the packed word (id | reach bits << 24) and the record of list entry base + lane.  The word stays RAW: the
+    // quadrant's bit and the id are extracted where they are consumed, one chunk later (extracting the bit here made the compiler
+    // wait for the load right behind the prefetch — `s_waitcnt vmcnt(3)` — an exposed memory latency per chunk).
+    uint32_t pw = 0;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    auto fetch = [&](uint32_t base, bool& r_, uint32_t& g_, float4& x0, float4& x1) {
-        r_ = false;
+    auto fetch = [&](uint32_t base, uint32_t& w_, float4& x0, float4& x1) {
+        w_ = 0u;
         if (base + (uint32_t)lane < end) {
             const uint32_t j = base + (uint32_t)lane;
-            r_ = (imask[j] >> quad) & 1u;
-            g_ = point_list[j];
+            w_ = ipack[j];
             x0 = irec[2 * (size_t)j];
             x1 = irec[2 * (size_t)j + 1];
         }
     };
-    fetch(beg, reach, gid, a0, a1);
+    fetch(beg, pw, a0, a1);
 
     bool wave_done = __builtin_amdgcn_ballot_w64(active) == 0;
     // split launches (common.h): the backward runs SPLIT_PARTS waves per quadrant, one per part of the list.  Segment record k
@@ -198,16 +197,16 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 ck_at = ck_k < SPLIT_PARTS - 1 ? ck_at + part : 0xFFFFFFFFu;
             }
         }
-        uint64_t cand = __builtin_amdgcn_ballot_w64(reach);
-        const uint32_t cur_gid = gid;
-        const bool cur_reach = reach;
+        const bool cur_reach = (pw >> (24 + quad)) & 1u;
+        uint64_t cand = __builtin_amdgcn_ballot_w64(cur_reach);
+        const uint32_t cur_gid = pw & 0xFFFFFFu;
         if (cand != 0) {
             __builtin_amdgcn_wave_barrier();
             s_rec0[lane] = a0;
             s_rec1[lane] = a1;
         }
         // next chunk: issued now, consumed after this chunk has been composited
-        fetch(base + WAVE, reach, gid, a0, a1);
+        fetch(base + WAVE, pw, a0, a1);
 #pragma unroll 1
         while (cand != 0 && !wave_done) {
             // ---- stage the feature rows of the next <= FS candidates ----
@@ -374,7 +373,7 @@ static int launch_one(const splatraster_settings& s, int c0, int write_aux, cons
     const unsigned blocks = quadrant_blocks(L.V * tiles, gx);  // 4 quadrants per (view, tile) (+ padding of the id space)
     hipLaunchKernelGGL(composite_fwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
                        s.image_height, padded_channels(feat_stride) / 4, c0, s.bg_channels, write_aux, tiles, L.V, L.P, b.ranges,
-                       b.point_list, b.irec, b.imask, reinterpret_cast<const float4*>(featp), bg, *L.outs, im.final_T,
+                       b.ipack, b.irec, reinterpret_cast<const float4*>(featp), bg, *L.outs, im.final_T,
                        im.n_contrib, (NC <= 4 && c0 == 0 && write_aux) ? L.ckpt : nullptr, use_tile_order(L.V, tiles) ? b.tile_order : nullptr);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
