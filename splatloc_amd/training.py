@@ -136,6 +136,62 @@ def color_refinement_step(viewpoint_cam, gaussians, pipe, background, lambda_dss
     return loss
 
 
+def _map_grads_direct(mine, gaussians, pipe, background, config, with_reg: bool):
+    """The gradient part of `map_step` without an autograd graph (same forward / backward code as the graph path: the static
+    `forward` / `backward` of `_ActivatePack`, `_RasterizeWindow`, `_IsotropicLoss` with a plain context; the per-view losses
+    already carry their gradients).  At SplatLoc's frame size a map step is ~2 ms of kernels under ~3 ms of Python (tools/
+    hostprof_steps.py): the engine's hand-off of three backward nodes and its validation of 16 explicit gradient tensors were a
+    third of it.  Leaves the raw-parameter gradients in `.grad`.  Returns (pkgs, loss, [dL/dmeans2D per view]) or None when the
+    configuration needs the general path (view-dependent colours, python covariance, mixed image sizes, an empty model)."""
+    from .fused import _ActivatePack, _view_settings
+    from .losses import _IsotropicLoss, mapping_loss_window
+    from .rasterizer import PlainCtx, _RasterizeWindow, _window_compatible
+    from . import _native
+    if not _direct_refine_ok(gaussians, pipe) or len(mine) > _native.MAX_WINDOW_VIEWS:
+        return None
+    P = int(gaussians._xyz.shape[0])
+    if P * len(mine) > (1 << 24):          # (rasterize_window would chunk the window: general path)
+        return None
+    settings = [_view_settings(vp, gaussians, background, 1.0) for vp in mine]
+    if not _window_compatible(settings):
+        return None
+    with torch.no_grad():
+        xyz = gaussians._xyz
+        c_act = PlainCtx()
+        scales, rotations, opacity, colors = _ActivatePack.forward(
+            c_act, xyz, gaussians._features_dc, gaussians._features_rest, gaussians._scaling, gaussians._rotation,
+            gaussians._opacity, gaussians._kp_score, None, 0)
+        c_ras = PlainCtx()
+        V = len(mine)
+        outs = _RasterizeWindow.forward(c_ras, xyz, colors, opacity, scales, rotations, None, tuple(settings), 3, None,
+                                        *([xyz] * V))
+        pkgs = []
+        for v in range(V):
+            rgb, kp, depth, alpha, radii = outs[5 * v:5 * v + 5]
+            pkgs.append({"render": rgb, "kp_prob": kp, "depth": depth, "opacity": alpha, "radii": radii})
+        _t, g, loss = mapping_loss_window(config, pkgs, mine)      # g = [g_render, g_depth, g_kp] per view
+        gouts = []
+        for v in range(V):
+            gouts += [g[3 * v], g[3 * v + 2], g[3 * v + 1], None, None]      # (rgb, last, depth, alpha, radii)
+        d = _RasterizeWindow.backward(c_ras, *gouts)
+        d_m3, d_col, d_op, d_sca, d_rot = d[0], d[1], d[2], d[3], d[4]
+        grads2d = list(d[9:9 + V])
+        if with_reg:
+            # 0.01 * isotropic regulariser on exp(_scaling) (train_gaussians.py:221-228): its gradient w.r.t. the ACTIVATED scales
+            # joins the rasterizer's before the activation backward multiplies by exp(s)
+            c_reg = PlainCtx()
+            value = _IsotropicLoss.forward(c_reg, scales, gaussians._marker.detach())
+            row_grad, out = c_reg.saved_tensors
+            d_sca = d_sca + ((0.01 * out[1]) * row_grad).view(-1, 1)
+            loss = 0.01 * value if loss is None else loss + 0.01 * value
+        _dx, d_fd, d_fr, d_sc, d_ro, d_opa, d_ex, _, _ = _ActivatePack.backward(c_act, d_sca, d_rot, d_op, d_col)
+        for p, gr in ((gaussians._xyz, d_m3), (gaussians._features_dc, d_fd), (gaussians._features_rest, d_fr),
+                      (gaussians._scaling, d_sc), (gaussians._rotation, d_ro), (gaussians._opacity, d_opa), (gaussians._kp_score, d_ex)):
+            if gr is not None:
+                p.grad = gr if p.grad is None else p.grad + gr
+    return pkgs, loss, grads2d
+
+
 # what the last multi-GPU map_step exchanged (frame_parallel.reduce_step's info: collectives, path, bytes) — monitoring
 LAST_STEP_INFO: dict = {}
 
@@ -173,25 +229,30 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
     primitive_reg = bool(config["Training"].get("primitive_reg", True))
     viewpoints = list(viewpoints)
     mine = [viewpoints[i] for i in shard_views(list(range(len(viewpoints))), rank, world)]
-    pkgs, _ = render_window(mine, gaussians, pipe, background)
-    pairs = [(p, v) for p, v in zip(pkgs, mine) if p is not None]      # views and packages filtered TOGETHER
-    pkgs, mine = [p for p, _ in pairs], [v for _, v in pairs]
-    # the per-view losses carry their own gradients (one fused launch each): ONE backward on the rasterizer's outputs, no
-    # per-view loss nodes / gradient scalings / additions (losses.mapping_loss_window)
-    tensors, grads, loss = mapping_loss_window(config, pkgs, mine)
-    if primitive_reg and rank == 0 and gaussians._xyz.shape[0] > 0:
-        reg = 0.01 * isotropic_loss(torch.exp(gaussians._scaling), gaussians._marker)
-        tensors, grads = tensors + [reg], grads + [None]
-        loss = reg.detach() if loss is None else loss + reg.detach()
-    if tensors:
-        torch.autograd.backward(tensors, grads)
+    direct = _map_grads_direct(mine, gaussians, pipe, background, config, primitive_reg and rank == 0) if mine else None
+    if direct is not None:
+        pkgs, loss, grads2d_direct = direct
+    else:
+        grads2d_direct = None
+        pkgs, _ = render_window(mine, gaussians, pipe, background)
+        pairs = [(p, v) for p, v in zip(pkgs, mine) if p is not None]      # views and packages filtered TOGETHER
+        pkgs, mine = [p for p, _ in pairs], [v for _, v in pairs]
+        # the per-view losses carry their own gradients (one fused launch each): ONE backward on the rasterizer's outputs, no
+        # per-view loss nodes / gradient scalings / additions (losses.mapping_loss_window)
+        tensors, grads, loss = mapping_loss_window(config, pkgs, mine)
+        if primitive_reg and rank == 0 and gaussians._xyz.shape[0] > 0:
+            reg = 0.01 * isotropic_loss(torch.exp(gaussians._scaling), gaussians._marker)
+            tensors, grads = tensors + [reg], grads + [None]
+            loss = reg.detach() if loss is None else loss + reg.detach()
+        if tensors:
+            torch.autograd.backward(tensors, grads)
     params = [getattr(gaussians, a) for a in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_kp_score", "_scaling",
                                               "_rotation")]      # `_marker` never receives a gradient in map()
     opt = gaussians.optimizer
     with torch.no_grad():
         P = int(gaussians._xyz.shape[0])
         dev = gaussians._xyz.device
-        grads2d = [p["viewspace_points"].grad for p in pkgs]
+        grads2d = grads2d_direct if grads2d_direct is not None else [p["viewspace_points"].grad for p in pkgs]
         radii = [p["radii"] for p in pkgs]
         update_gaussian = bool(densify) and iteration_count % int(densify["every"]) == int(densify.get("offset", 0))
         reset_now = bool(gaussian_reset) and iteration_count % gaussian_reset == 0 and not update_gaussian
@@ -199,7 +260,7 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
         if reset_now:       # the union of the window's visibility masks (gaussian_model.py:384-392)
             seen = torch.zeros(P, dtype=torch.float32, device=dev)
             for p in pkgs:
-                seen = torch.maximum(seen, p["visibility_filter"].to(torch.float32))
+                seen = torch.maximum(seen, (p["radii"] > 0).to(torch.float32))      # visibility_filter = radii > 0
         if multi:
             # everything the replicas exchange in this step, in TWO collectives (frame_parallel.reduce_step):
             #   SUM over [parameter gradients | increments of xyz_gradient_accum, denom]
