@@ -35,6 +35,9 @@
 #ifndef SR_FWD_LDSDMA
 #define SR_FWD_LDSDMA 0  // 1 = stage the feature rows with LDS-DMA loads
 #endif
+#ifndef SR_FWD_M4
+#define SR_FWD_M4 1  // leftover channels + depth of a wide layout on v_mfma_f32_4x4x1 (0: VALU pair sums)
+#endif
 #ifndef SR_FWD_MINW
 #define SR_FWD_MINW 4  // waves per SIMD the register allocator must allow
 #endif
@@ -46,6 +49,7 @@ __device__ unsigned long long g_trace_fwd[2 * 40960];
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // In-place half swap: afterwards x = [x.lanes0-31 | y.lanes0-31], y = [x.lanes32-63 | y.lanes32-63].
 // Inline asm on purpose: with ROCm 7.2 hipcc, feeding BOTH results of
@@ -73,6 +77,18 @@ __device__ __forceinline__ void mfma_drain(f32x16& x, f32x16& y)
 {
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(x), "+v"(y));
 }
+// acc[r] += a * b per lane group of 4 (v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products, K = 1).  Lane l supplies
+// A[block l/4][row l%4] and B[block l/4][column l%4]; its four result registers are rows 0-3 of column l%4.  With a = value
+// (l % 4) of a Gaussian's leftover row and b = the lane's own blending weight, register r of lane l accumulates value r for
+// the lane's OWN pixel: four per-pixel FMAs as one matrix-pipe instruction (2 passes) instead of twelve VALU instructions per pair.
+__device__ __forceinline__ void mfma_acc_4x4x1(f32x4& acc, float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_drain4(f32x4& x)
+{
+    asm volatile("s_nop 7" : "+v"(x));
+}
 
 template <int NC>
 struct FwdCfg {
@@ -80,6 +96,8 @@ struct FwdCfg {
     static constexpr int NM = MFMA ? 32 : 0;   // channels accumulated on the matrix pipe
     static constexpr int NV = NC - NM;         // channels accumulated with VALU FMAs
     static constexpr int NCP = (NC + 3) & ~3;  // LDS row stride (floats), 16-B aligned rows
+    // the leftover channels (< 4) and the depth ride a 4x4x1 matrix instruction: the depth takes the staged row's padding slot
+    static constexpr bool M4 = SR_FWD_M4 && MFMA && NV > 0 && NV <= 3 && NM + NV < NCP;
     static constexpr int FS = SR_FWD_FS;             // feature rows staged per round
 };
 
@@ -96,7 +114,7 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
 {
     using Cfg = FwdCfg<NC>;
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, FS = Cfg::FS;
-    constexpr bool MFMA = Cfg::MFMA;
+    constexpr bool MFMA = Cfg::MFMA, M4 = Cfg::M4;
     constexpr int PPR = NCP / 4;  // 16-byte pieces per staged row
     __shared__ __attribute__((aligned(16))) float4 s_rec0[WAVE];
     __shared__ __attribute__((aligned(16))) float4 s_rec1[WAVE];
@@ -144,6 +162,7 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
     f32x16 accA, accB;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accA[r] = 0.0f; accB[r] = 0.0f; }
+    f32x4 acc4 = {0.0f, 0.0f, 0.0f, 0.0f};   // M4: channels NM .. NM + 2 and the depth (register 3) of the lane's own pixel
     uint32_t last = 0;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
 
@@ -236,6 +255,10 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
             }
             __builtin_amdgcn_wave_barrier();
 #endif
+            if constexpr (M4) {   // the candidate's depth into the padding slot of its staged row (after the row's pieces: LDS keeps program order)
+                if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_feat[rank * NCP + NM + 3] = s_rec0[lane].z;
+                __builtin_amdgcn_wave_barrier();
+            }
             // ---- composite them front to back, two at a time ----
 #pragma unroll 1
             for (int slot = 0; slot < ncand; slot += 2) {
@@ -246,6 +269,17 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 if (has1) cand &= cand - 1;
                 const float4 p0 = s_rec0[j0], q0 = s_rec1[j0];
                 const float4 p1 = s_rec0[j1], q1 = s_rec1[j1];
+                const int s1 = has1 ? slot + 1 : slot;
+                // matrix operands of the pair: read NOW, beside the records (left to the scheduler, each read sat right in front
+                // of the instruction that consumes it: an exposed LDS round trip per operand and pair)
+                float a32 = 0.0f, a40 = 0.0f, a41 = 0.0f;
+                if constexpr (MFMA) a32 = s_feat[((lane >> 5) ? s1 : slot) * NCP + (lane & 31)];  // A[i = ch][k = g]
+                if constexpr (M4) {
+                    const int l4 = NM + (lane & 3);
+                    a40 = s_feat[slot * NCP + l4];
+                    a41 = s_feat[s1 * NCP + l4];
+                }
+                if constexpr (MFMA) __builtin_amdgcn_sched_barrier(0);
                 const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
                 const float pw0 = gauss_log2(q0, dx0, dy0), pw1 = gauss_log2(q1, dx1, dy1);  // log2 of the weight
                 const float al0 = fminf(ALPHA_MAX, q0.w * exp2_shared(pw0));
@@ -269,18 +303,22 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 // No "skip if nobody hit" branch here on purpose: with the reach masks ~95 % of the
                 // candidates hit, and a conditional around the accumulation makes hipcc merge the two
                 // paths by copying all 32 accumulator registers per pair (seen in the .s).
-                const int s1 = has1 ? slot + 1 : slot;
                 const float* f0 = &s_feat[slot * NCP + NM];
                 const float* f1 = &s_feat[s1 * NCP + NM];
+                if constexpr (M4) {
+                    mfma_acc_4x4x1(acc4, a40, w0);
+                    mfma_acc_4x4x1(acc4, a41, w1);
+                } else {
 #pragma unroll
-                for (int ch = 0; ch < NV; ++ch) {
-                    // narrow layouts: two FMAs in list order (forward -2.7 % at C = 3 / 4); beside the MFMA accumulation of
-                    // C = 35 the pair-sum form (mul + fma + add) measured FASTER (1.90 vs 1.99 ms per window)
-                    if (MFMA) acc[ch] += f0[ch] * w0 + f1[ch] * w1;
-                    else acc[ch] = fmaf(f1[ch], w1, fmaf(f0[ch], w0, acc[ch]));
+                    for (int ch = 0; ch < NV; ++ch) {
+                        // narrow layouts: two FMAs in list order (forward -2.7 % at C = 3 / 4); beside the MFMA accumulation of
+                        // wide layouts the pair-sum form (mul + fma + add) measured FASTER (1.90 vs 1.99 ms per window)
+                        if (MFMA) acc[ch] += f0[ch] * w0 + f1[ch] * w1;
+                        else acc[ch] = fmaf(f1[ch], w1, fmaf(f0[ch], w0, acc[ch]));
+                    }
+                    if (MFMA) D += p0.z * w0 + p1.z * w1;
+                    else D = fmaf(p1.z, w1, fmaf(p0.z, w0, D));
                 }
-                if (MFMA) D += p0.z * w0 + p1.z * w1;
-                else D = fmaf(p1.z, w1, fmaf(p0.z, w0, D));
                 if constexpr (NC <= 4) {
                     if (part) {     // (wave-uniform) the segment's own sums: never read by this kernel's images
 #pragma unroll
@@ -289,11 +327,10 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                     }
                 }
                 if (MFMA) {
-                    const float a = s_feat[((lane >> 5) ? s1 : slot) * NCP + (lane & 31)];  // A[i = ch][k = g]
                     float b0 = w0, b1 = w1;
                     swap_halves(b0, b1);  // b0 -> B for pixels 0-31, b1 -> B for pixels 32-63
-                    mfma_acc_32x32x2(accA, a, b0);
-                    mfma_acc_32x32x2(accB, a, b1);
+                    mfma_acc_32x32x2(accA, a32, b0);
+                    mfma_acc_32x32x2(accB, a32, b1);
                 }
                 if (__builtin_amdgcn_ballot_w64(active) == 0) { wave_done = true; break; }
             }
@@ -310,6 +347,12 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
         }
     }
     const size_t plane = (size_t)H * W;
+    if constexpr (M4) {
+        mfma_drain4(acc4);
+#pragma unroll
+        for (int ch = 0; ch < NV; ++ch) acc[ch] = acc4[ch];
+        D = acc4[3];
+    }
     if (MFMA) {
         mfma_drain(accA, accB);
         // D[ch][pix]: lane l, register r holds channel (r&3) + 8 (r>>2) + 4 (l>>5) of wave pixel
