@@ -90,6 +90,14 @@ __device__ __forceinline__ void mfma_drain4(f32x4& x)
     asm volatile("s_nop 7" : "+v"(x));
 }
 
+// Index of the lowest set bit; -1 for an empty mask (s_ff1_i32_b64's own convention, which __builtin_ctzll leaves undefined).
+__device__ __forceinline__ int first_bit(uint64_t m)
+{
+    int j;
+    asm("s_ff1_i32_b64 %0, %1" : "=s"(j) : "s"(m));
+    return j;
+}
+
 template <int NC>
 struct FwdCfg {
     static constexpr bool MFMA = NC >= 32;
@@ -116,8 +124,12 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
     constexpr int NCP = Cfg::NCP, NM = Cfg::NM, NV = Cfg::NV, FS = Cfg::FS;
     constexpr bool MFMA = Cfg::MFMA, M4 = Cfg::M4;
     constexpr int PPR = NCP / 4;  // 16-byte pieces per staged row
-    __shared__ __attribute__((aligned(16))) float4 s_rec0[WAVE];
-    __shared__ __attribute__((aligned(16))) float4 s_rec1[WAVE];
+    // records of the chunk at [1 + j]; entry 0 is the ABSENT candidate (opacity 0: alpha = 0, never live): an odd round's last
+    // pair reads it through j1 = -1 (s_ff1 of an empty mask) instead of carrying a wave-uniform "has a second Gaussian" flag
+    // through the pair loop (9 scalar + 4 vector instructions per pair of select / mask algebra)
+    __shared__ __attribute__((aligned(16))) float4 s_rec0[WAVE + 1];
+    __shared__ __attribute__((aligned(16))) float4 s_rec1[WAVE + 1];
+    static_assert(FS % 2 == 0, "pairs: an odd round ends below FS, its zeroed row FS - 1 at most");
     __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
     __shared__ uint32_t s_cgid[FS];
 
@@ -153,6 +165,10 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
     const float fx = (float)px, fy = (float)py;
     const uint32_t beg = ranges[2 * gtile], end = ranges[2 * gtile + 1];
 
+    if (lane == 0) {
+        s_rec0[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_rec1[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     bool active = inside;  // pixel still accumulating
     float T = 1.0f, D = 0.0f;
     float acc[NV > 0 ? NV : 1];
@@ -164,6 +180,7 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
     for (int r = 0; r < 16; ++r) { accA[r] = 0.0f; accB[r] = 0.0f; }
     f32x4 acc4 = {0.0f, 0.0f, 0.0f, 0.0f};   // M4: channels NM .. NM + 2 and the depth (register 3) of the lane's own pixel
     uint32_t last = 0;
+    const int lb32 = (lane >> 5) * NCP + (lane & 31);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
 
     // chunk in flight: the packed word (id | reach bits << 24) and the record of list entry base + lane.  The word stays RAW: the
@@ -221,8 +238,8 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
         const uint32_t cur_gid = pw & 0xFFFFFFu;
         if (cand != 0) {
             __builtin_amdgcn_wave_barrier();
-            s_rec0[lane] = a0;
-            s_rec1[lane] = a1;
+            s_rec0[1 + lane] = a0;
+            s_rec1[1 + lane] = a1;
         }
         // next chunk: issued now, consumed after this chunk has been composited
         fetch(base + WAVE, pw, a0, a1);
@@ -255,25 +272,28 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
             }
             __builtin_amdgcn_wave_barrier();
 #endif
+            if (ncand & 1) {      // the absent candidate's feature row: finite, whatever the LDS held
+                if (lane < PPR) reinterpret_cast<float4*>(s_feat)[ncand * PPR + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                __builtin_amdgcn_wave_barrier();
+            }
             if constexpr (M4) {   // the candidate's depth into the padding slot of its staged row (after the row's pieces: LDS keeps program order)
-                if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_feat[rank * NCP + NM + 3] = s_rec0[lane].z;
+                if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_feat[rank * NCP + NM + 3] = s_rec0[1 + lane].z;
                 __builtin_amdgcn_wave_barrier();
             }
             // ---- composite them front to back, two at a time ----
 #pragma unroll 1
             for (int slot = 0; slot < ncand; slot += 2) {
-                const bool has1 = slot + 1 < ncand;  // wave-uniform
-                const int j0 = __builtin_ctzll(cand);
+                const int j0 = first_bit(cand);
                 cand &= cand - 1;
-                const int j1 = has1 ? __builtin_ctzll(cand) : j0;
-                if (has1) cand &= cand - 1;
-                const float4 p0 = s_rec0[j0], q0 = s_rec1[j0];
-                const float4 p1 = s_rec0[j1], q1 = s_rec1[j1];
-                const int s1 = has1 ? slot + 1 : slot;
+                const int j1 = first_bit(cand);   // -1 in the last pair of an odd round: the absent candidate
+                cand &= cand - 1;                 // (an empty mask stays empty)
+                const float4 p0 = s_rec0[1 + j0], q0 = s_rec1[1 + j0];
+                const float4 p1 = s_rec0[1 + j1], q1 = s_rec1[1 + j1];
+                const int s1 = slot + 1;          // row ncand of an odd round was zeroed while staging
                 // matrix operands of the pair: read NOW, beside the records (left to the scheduler, each read sat right in front
                 // of the instruction that consumes it: an exposed LDS round trip per operand and pair)
                 float a32 = 0.0f, a40 = 0.0f, a41 = 0.0f;
-                if constexpr (MFMA) a32 = s_feat[((lane >> 5) ? s1 : slot) * NCP + (lane & 31)];  // A[i = ch][k = g]
+                if constexpr (MFMA) a32 = s_feat[slot * NCP + lb32];  // A[i = ch][k = g]: lanes 32-63 read the pair's second row
                 if constexpr (M4) {
                     const int l4 = NM + (lane & 3);
                     a40 = s_feat[slot * NCP + l4];
@@ -291,8 +311,8 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 const bool act1 = active && !(live0 && !hit0);  // transmittance exhausted: pixel finished
                 const float w0 = hit0 ? al0 * T : 0.0f;
                 const float T1 = hit0 ? tT0 : T;
-                // Gaussian 1 (absent when !has1)
-                const bool live1 = has1 && act1 && pw1 <= 0.0f && al1 >= ALPHA_MIN;
+                // Gaussian 1 (the absent candidate has alpha = 0)
+                const bool live1 = act1 && pw1 <= 0.0f && al1 >= ALPHA_MIN;
                 const float tT1 = transmit(T1, al1);
                 const bool hit1 = live1 && tT1 >= T_EPS;
                 active = act1 && !(live1 && !hit1);
