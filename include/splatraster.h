@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 7
+#define SPLATRASTER_ABI_VERSION 8
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
@@ -532,6 +532,10 @@ int splatraster_debug_set_split_max_waves(int waves);
  * (DESIGN.md §11); < 0 restores the built-in default (8 Mi instances), 0 = always.  Results never depend on it. */
 int splatraster_debug_set_payload_stream_min(int64_t instances);
 int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
+/* test hook: fills the LDS of every compute unit with `pattern` (e.g. a NaN's bits): enough workgroups of 64 KB each to cover
+ * the whole array.  The compositing kernels read rows of their LDS staging buffers that a round did not write (the absent second
+ * member of a round's last pair); their results must not depend on what the LDS held before the launch. */
+int splatraster_debug_poison_lds(uint32_t pattern, void* stream);
 
 const char* splatraster_error_string(int status);
 /* last HIP error text recorded by this thread (empty string when none). */

@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 7   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 8   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 WARN_LOOKBACK_STALL = 5   # splatraster_poll_errors() only; not an error of any frame
@@ -139,6 +139,7 @@ SYMBOLS = {
     "splatraster_debug_set_spin_limit": (C.c_int, [C.c_uint32]),
     "splatraster_debug_set_deterministic": (C.c_int, [C.c_int]),
     "splatraster_debug_exp2": (C.c_int, [_i64, _vp, _vp, _vp]),
+    "splatraster_debug_poison_lds": (C.c_int, [C.c_uint32, _vp]),
 }
 
 

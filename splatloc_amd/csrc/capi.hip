@@ -733,6 +733,11 @@ int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream)
     return launch_debug_exp2(n, x, y, reinterpret_cast<hipStream_t>(stream));
 }
 
+int splatraster_debug_poison_lds(uint32_t pattern, void* stream)
+{
+    return launch_poison_lds(pattern, reinterpret_cast<hipStream_t>(stream));
+}
+
 size_t splatraster_sort_tmp_bytes(int64_t n)
 {
     const size_t m = (size_t)(n > 0 ? n : 1);

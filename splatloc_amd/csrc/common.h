@@ -29,6 +29,7 @@ int lookback_error_poll();
 int lookback_set_spin_limit(uint32_t limit);
 // test hook: y[i] = exp2_shared(x[i]) (composite_fwd.hip)
 int launch_debug_exp2(int64_t n, const float* x, float* y, hipStream_t stream);
+int launch_poison_lds(uint32_t pattern, hipStream_t stream);
 
 #define SR_HIP_CHECK(expr)                                 \
     do {                                                   \

@@ -412,6 +412,27 @@ __global__ void debug_exp2_kernel(int64_t n, const float* __restrict__ x, float*
     if (i < n) y[i] = exp2_shared(x[i]);
 }
 
+// test hook (splatraster_debug_poison_lds): 64 KB workgroups, two per compute unit resident at a time, several rounds of them
+__global__ void __launch_bounds__(256) poison_lds_kernel(uint32_t pattern, uint32_t* __restrict__ sink)
+{
+    __shared__ uint32_t s_all[16384];
+    for (int i = threadIdx.x; i < 16384; i += 256) s_all[i] = pattern;
+    __syncthreads();
+    // keep the stores: the buffer is read back through a data-dependent index
+    const uint32_t v = s_all[(pattern + threadIdx.x * 61u) & 16383u];
+    if (v != pattern) sink[0] = v;
+    __builtin_amdgcn_s_sleep(64);   // stay resident for a moment so that the blocks spread over every compute unit
+}
+
+int launch_poison_lds(uint32_t pattern, hipStream_t stream)
+{
+    static uint32_t* sink = nullptr;
+    if (!sink && hipMalloc(&sink, 256) != hipSuccess) return SPLATRASTER_ERR_HIP;
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(256 * 2 * 4), dim3(256), 0, stream, pattern, sink);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
 int launch_debug_exp2(int64_t n, const float* x, float* y, hipStream_t stream)
 {
     hipLaunchKernelGGL(debug_exp2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, x, y);

@@ -286,3 +286,29 @@ def test_streaming_payload_stores_change_nothing():
     assert torch.equal(a.color, b.color) and torch.equal(a.depth, b.depth) and torch.equal(a.alpha, b.alpha)
     for n in ("means3D", "means2D", "opacities", "colors", "scales", "rotations"):
         assert torch.equal(getattr(a, n).grad, getattr(b, n).grad), n
+
+
+@pytest.mark.parametrize("C", [3, 4, 8, 35])
+def test_results_do_not_depend_on_what_the_lds_held(C):
+    """The compositing kernels pair the candidates of a staging round; an odd round's last pair has no second member and reads
+    a staged feature row nobody wrote in that round.  The forward zeroes that row (composite_fwd.hip), the backward masks the
+    half (composite_bwd.hip): with every compute unit's LDS pre-filled with NaNs, then with a huge finite pattern, images and
+    (deterministic-sum mode) gradients are the ones of an undisturbed run, bit for bit."""
+    from splatloc_amd import _native
+    lib = _native.load()
+    sc = make_scene(2500, 136, 104, C, seed=123 + C, scale_median=0.08)
+    _native.set_deterministic(True)
+    try:
+        ref = HipRun(sc)
+        runs = []
+        for pattern in (0x7FC00000, 0x7F7FFFFF, 0xFF800000):   # NaN, FLT_MAX, -inf
+            _native.check(lib.splatraster_debug_poison_lds(pattern, None), "poison_lds")
+            torch.cuda.synchronize()
+            runs.append(HipRun(sc))
+    finally:
+        _native.set_deterministic(False)
+    for r in runs:
+        assert torch.equal(ref.color, r.color) and torch.equal(ref.depth, r.depth) and torch.equal(ref.alpha, r.alpha)
+        assert torch.isfinite(r.color).all()
+        for n in ("means3D", "means2D", "opacities", "colors", "scales", "rotations"):
+            assert torch.equal(getattr(ref, n).grad, getattr(r, n).grad), n
