@@ -101,8 +101,8 @@ __device__ __forceinline__ float gauss_log2(const float4& q, float dx, float dy)
 // not reproducible off the GPU; -DSR_EXP2_HW selects it for A/B timing only (cost: DESIGN.md §5).
 constexpr float EXP2_C0 = 1.0f, EXP2_C1 = 0.6931470036506653f, EXP2_C2 = 0.24022242426872253f,
                 EXP2_C3 = 0.05550733581185341f, EXP2_C4 = 0.009671512991189957f, EXP2_C5 = 0.001326472731307149f;
-// The arithmetic without the argument clamp, for the BACKWARD (backward -2 % on S2 / S1; the forward measured no gain and keeps
-// exp2_shared): there the clamp's only job (an argument of -inf or
+// The arithmetic without the argument clamp, for the compositing kernels (backward -2 % on S2 / S1 in round 3; the forward
+// follows in round 4, two instructions per pair fewer, +0.3 % on S2): there the clamp's only job (an argument of -inf or
 // NaN, reachable through an overflowing conic * d^2) is done for free by testing alpha BEFORE the min with 0.99 — NaN fails
 // the >= 1/255 test, the Gaussian is a miss exactly as with the clamped 2^-200 = 0 — and by zeroing G, not dL/dalpha, for a
 // miss in the backward.  For every finite argument the value is the clamped function's, bit for bit: below -200 both flush to

@@ -302,17 +302,19 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
                 if constexpr (MFMA) __builtin_amdgcn_sched_barrier(0);
                 const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
                 const float pw0 = gauss_log2(q0, dx0, dy0), pw1 = gauss_log2(q1, dx1, dy1);  // log2 of the weight
-                const float al0 = fminf(ALPHA_MAX, q0.w * exp2_shared(pw0));
-                const float al1 = fminf(ALPHA_MAX, q1.w * exp2_shared(pw1));
+                // (alpha is tested BEFORE the min with 0.99, like the backward: a NaN from an overflowed power is a miss, which is
+                //  the only thing the argument clamp of exp2_shared was there for — composite_common.h)
+                const float ar0 = q0.w * exp2_core(pw0), ar1 = q1.w * exp2_core(pw1);
+                const float al0 = fminf(ALPHA_MAX, ar0), al1 = fminf(ALPHA_MAX, ar1);
                 // Gaussian 0
-                const bool live0 = active && pw0 <= 0.0f && al0 >= ALPHA_MIN;
+                const bool live0 = active && pw0 <= 0.0f && ar0 >= ALPHA_MIN;
                 const float tT0 = transmit(T, al0);
                 const bool hit0 = live0 && tT0 >= T_EPS;
                 const bool act1 = active && !(live0 && !hit0);  // transmittance exhausted: pixel finished
                 const float w0 = hit0 ? al0 * T : 0.0f;
                 const float T1 = hit0 ? tT0 : T;
                 // Gaussian 1 (the absent candidate has alpha = 0)
-                const bool live1 = act1 && pw1 <= 0.0f && al1 >= ALPHA_MIN;
+                const bool live1 = act1 && pw1 <= 0.0f && ar1 >= ALPHA_MIN;
                 const float tT1 = transmit(T1, al1);
                 const bool hit1 = live1 && tT1 >= T_EPS;
                 active = act1 && !(live1 && !hit1);
