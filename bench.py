@@ -683,6 +683,7 @@ def bench_scene(args, dev):
                     "refine_phase": round(stats["refine_seconds"], 2), "save_ply": round(t_ply, 3), "eval_rendering": round(t_eval, 3)},
         "map_ms_per_iteration": round(map_ms, 3), "refine_ms_per_iteration": round(ref_ms, 4),
         "refine_26000_iterations_s_extrapolated_from_this_run": round(26000 * ref_ms / 1e3, 1),
+        "render_paths_of_the_map_steps": stats.get("render_paths"),
         "rows_after_keyframe": stats["rows_after_keyframe"], "rows_final": stats["rows_final"],
         "densifications": stats["densify_rows"], "peak_memory_GB": round(stats["peak_memory_bytes"] / 2 ** 30, 3),
         "ply_bytes": ply_bytes,

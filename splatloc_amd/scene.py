@@ -29,7 +29,7 @@ import torch
 from .camera import PinholeCamera
 from .densify import ATTR, GROUPS
 from .keyframe import extend_from_pcd_seq
-from .training import color_refinement_step, map_step
+from .training import LAST_STEP_INFO, color_refinement_step, map_step
 
 # configs/replica_nerf/base_config.yaml (the values train_gaussians.py reads)
 DEFAULT_CONFIG = {
@@ -175,8 +175,9 @@ def load_depth(config, viewpoint):
 def do_recon(gaussians, keyframes, pipe=None, background=None, config=None, refine_iterations: int = 26000, seed: int = 0,
              batched: bool = True, group=None, on_event=None) -> dict:
     """SplatLoc.do_recon (train_gaussians.py:310-355) on `keyframes` (the reference: every `kf_interval`-th dataset frame).
-    `batched = False` renders every window as the reference's loop of per-view calls (the literal drop-in path) instead of
-    one launch sequence per window.  The random draws the reference takes from global RNGs (`torch.randperm` of the window,
+    `batched = False` renders every window — and every refinement iteration — as the reference does: one `render()` per view
+    through the drop-in autograd.Function (`render_path="per-view"` of training.map_step / color_refinement_step) instead of
+    one graph-free launch sequence per window; `stats["render_paths"]` records which paths the map steps took.  The random draws the reference takes from global RNGs (`torch.randperm` of the window,
     `random.randint` of the refinement view, `np.random.choice` of the key-frame down-sampling) come from generators seeded
     by `seed`, identical on every rank of a frame-parallel job.  Returns counters and timings; the model is updated in place."""
     cfg = config or gaussians.config
@@ -194,7 +195,8 @@ def do_recon(gaussians, keyframes, pipe=None, background=None, config=None, refi
     stats = {"rows_after_keyframe": [], "densify_rows": [], "map_iterations": 0, "refine_iterations": 0, "resets": 0}
     iteration_count = 0
     t0 = time.perf_counter()
-    step_fn = map_step if batched else _map_step_per_view
+    path = "auto" if batched else "per-view"
+    stats["render_paths"] = set()
     for kf_id, viewpoint in enumerate(keyframes):
         viewpoints[kf_id] = viewpoint
         extend_from_pcd_seq(gaussians, viewpoint, kf_id=kf_id, depthmap=load_depth(cfg, viewpoint), seed=seed)
@@ -204,8 +206,9 @@ def do_recon(gaussians, keyframes, pipe=None, background=None, config=None, refi
             iteration_count += 1
             idx = torch.randperm(len(stack), generator=rng_w)[:tr["window_size"]]          # train_gaussians.py:195
             rows = int(gaussians._xyz.shape[0])
-            step_fn([stack[i] for i in idx], gaussians, pipe, background, cfg, iteration_count, densify=dens,
-                    gaussian_reset=tr["gaussian_reset"], seed=seed, group=group)
+            map_step([stack[i] for i in idx], gaussians, pipe, background, cfg, iteration_count, densify=dens,
+                     gaussian_reset=tr["gaussian_reset"], seed=seed, group=group, render_path=path)
+            stats["render_paths"].add(LAST_STEP_INFO.get("render_path"))
             if int(gaussians._xyz.shape[0]) != rows:
                 stats["densify_rows"].append([iteration_count, rows, int(gaussians._xyz.shape[0])])
             if tr["gaussian_reset"] and iteration_count % tr["gaussian_reset"] == 0:
@@ -220,7 +223,7 @@ def do_recon(gaussians, keyframes, pipe=None, background=None, config=None, refi
     for iteration in range(1, refine_iterations + 1):                                       # train_gaussians.py:269-297
         cam = viewpoints[keys[rng_r.randint(0, len(keys) - 1)]]
         color_refinement_step(cam, gaussians, pipe, background, opt["lambda_dssim"], iteration,
-                              primitive_reg=bool(tr.get("primitive_reg", True)))
+                              primitive_reg=bool(tr.get("primitive_reg", True)), render_path=path)
         if on_event and iteration % 500 == 0:
             on_event("refine", iteration, gaussians)
     if refine_iterations:
@@ -231,29 +234,10 @@ def do_recon(gaussians, keyframes, pipe=None, background=None, config=None, refi
     torch.cuda.synchronize(dev)
     stats["refine_iterations"] = refine_iterations
     stats["refine_seconds"] = time.perf_counter() - t1
+    stats["render_paths"] = sorted(p for p in stats["render_paths"] if p)
     stats["rows_final"] = int(gaussians._xyz.shape[0])
     stats["peak_memory_bytes"] = int(torch.cuda.max_memory_allocated(dev))
     return stats
-
-
-def _map_step_per_view(viewpoints, gaussians, pipe, background, config, iteration_count, *, densify=None, gaussian_reset=0,
-                       seed=0, group=None):
-    """`training.map_step` with the window rendered as the reference's loop of per-view `render()` calls
-    (fused.render_window(batched=False)): what an UNMODIFIED train_gaussians.py issues through the drop-in `diff_gauss`."""
-    from . import fused
-    orig = fused.render_window
-
-    def per_view(vps, pc, pp, bg, *a, **k):
-        k["batched"] = False
-        return orig(vps, pc, pp, bg, *a, **k)
-
-    from . import training
-    training.render_window = per_view
-    try:
-        return map_step(viewpoints, gaussians, pipe, background, config, iteration_count, densify=densify,
-                        gaussian_reset=gaussian_reset, seed=seed, group=group)
-    finally:
-        training.render_window = orig
 
 
 def state_digest(gaussians) -> str:

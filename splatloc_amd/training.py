@@ -97,7 +97,7 @@ def _color_refinement_step_direct(viewpoint_cam, gaussians, background, lambda_d
 
 
 def color_refinement_step(viewpoint_cam, gaussians, pipe, background, lambda_dssim: float, iteration: int,
-                          primitive_reg: bool = True):
+                          primitive_reg: bool = True, render_path: str = "auto"):
     """One iteration of SplatLoc.color_refinement (train_gaussians.py:275-297):
 
         render -> (1 - l) L1 + l (1 - SSIM) on the RGB channels -> backward -> key-primitive gate on xyz.grad ->
@@ -108,11 +108,18 @@ def color_refinement_step(viewpoint_cam, gaussians, pipe, background, lambda_dss
     and no zero-padded gradient images are built; the fused L1 + SSIM loss (two kernels instead of five grouped 11x11
     convolutions and their autograd backward); the `max_radii2D` line as one launch without boolean-mask indexing
     (the reference: two `nonzero` + a device->host sync); the gate inside the fused Adam launch when the optimizer is
-    splatloc_amd.optim.Adam (else the reference's masked assignment).  Returns the loss tensor (no host sync)."""
-    if _direct_refine_ok(gaussians, pipe):
+    splatloc_amd.optim.Adam (else the reference's masked assignment).  Returns the loss tensor (no host sync).
+    `render_path`: "auto" (graph-free when the configuration allows it), "window" (the window-of-one under autograd) or
+    "per-view" (the drop-in `render()` -> `diff_gauss.GaussianRasterizer` call an unmodified train_gaussians.py issues)."""
+    if render_path not in ("auto", "window", "per-view"):
+        raise ValueError(f"color_refinement_step: unknown render_path {render_path!r}")
+    if render_path == "auto" and _direct_refine_ok(gaussians, pipe):
         return _color_refinement_step_direct(viewpoint_cam, gaussians, background, lambda_dssim, iteration, primitive_reg)
-    pkgs, _ = render_window([viewpoint_cam], gaussians, pipe, background, batched=True)
-    pkg = pkgs[0]
+    if render_path == "per-view":
+        from .fused import render
+        pkg = render(viewpoint_cam, gaussians, pipe, background)
+    else:
+        pkg = render_window([viewpoint_cam], gaussians, pipe, background, batched=True)[0][0]
     if pkg is None:
         return None
     image, radii = pkg["render"], pkg["radii"]
@@ -197,7 +204,7 @@ LAST_STEP_INFO: dict = {}
 
 
 def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: int, *, densify=None,
-             gaussian_reset: int = 0, seed: int = 0, group=None):
+             gaussian_reset: int = 0, seed: int = 0, group=None, render_path: str = "auto"):
     """One iteration of the loop body of SplatLoc.map (train_gaussians.py:188-267) on the window `viewpoints` (the
     caller has drawn it: `all_viewpoint_stack[torch.randperm(len(...))[:window_size]]`, :195), with the device-side
     pieces of this package, single- or multi-GPU:
@@ -218,6 +225,9 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
     counter-based: keyed by (seed, iteration_count, source row, copy)) — the replicas stay bit-identical without ever
     broadcasting parameters.  The regulariser is added on rank 0 only (the reduced gradient contains it once).
     `densify`: dict(grad_threshold, min_opacity, extent, size_threshold, every, offset) or None.
+    `render_path`: "auto" (the graph-free window path when the configuration allows it, else the window path under autograd),
+    "window" (always under autograd) or "per-view" (the reference's loop of per-view render() calls through the drop-in
+    autograd.Function — what an unmodified train_gaussians.py issues); LAST_STEP_INFO["render_path"] says which one ran.
     Returns the rank's loss tensor (None on a rank without work)."""
     import torch.distributed as dist
     from .densify import densify_and_prune, reset_opacity_nonvisible
@@ -229,12 +239,18 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
     primitive_reg = bool(config["Training"].get("primitive_reg", True))
     viewpoints = list(viewpoints)
     mine = [viewpoints[i] for i in shard_views(list(range(len(viewpoints))), rank, world)]
-    direct = _map_grads_direct(mine, gaussians, pipe, background, config, primitive_reg and rank == 0) if mine else None
+    if render_path not in ("auto", "window", "per-view"):
+        raise ValueError(f"map_step: unknown render_path {render_path!r}")
+    direct = None
+    if mine and render_path == "auto":
+        direct = _map_grads_direct(mine, gaussians, pipe, background, config, primitive_reg and rank == 0)
+    ran = "direct-window" if direct is not None else ("per-view" if render_path == "per-view" else "window")
     if direct is not None:
         pkgs, loss, grads2d_direct = direct
     else:
         grads2d_direct = None
-        pkgs, _ = render_window(mine, gaussians, pipe, background)
+        per_view = render_path == "per-view"        # the literal loop: one render() per view, each with its own activations
+        pkgs, _ = render_window(mine, gaussians, pipe, background, batched=not per_view, share_activations=not per_view)
         pairs = [(p, v) for p, v in zip(pkgs, mine) if p is not None]      # views and packages filtered TOGETHER
         pkgs, mine = [p for p, _ in pairs], [v for _, v in pairs]
         # the per-view losses carry their own gradients (one fused launch each): ONE backward on the rasterizer's outputs, no
@@ -281,8 +297,11 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
             gaussians.denom += inc_out[1]
             LAST_STEP_INFO.clear()
             LAST_STEP_INFO.update(info)
-        elif pkgs:
-            add_densification_stats_window(grads2d, radii, gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D)
+        else:
+            LAST_STEP_INFO.clear()
+            if pkgs:
+                add_densification_stats_window(grads2d, radii, gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D)
+        LAST_STEP_INFO["render_path"] = ran
         if primitive_reg:
             if hasattr(opt, "set_key_gate"):
                 opt.set_key_gate(gaussians._marker, 0.005)

@@ -109,6 +109,9 @@ def test_per_view_drop_in_path_and_window_path_end_close():
         stats = do_recon(model, frames, pipe, bg, cfg, refine_iterations=300, seed=5, batched=batched)
         out[batched] = (stats, _psnr(model, frames, pipe, bg))
     (sa, pa), (sb, pb) = out[True], out[False]
+    # the two runs really took different paths (round 4's first version patched a function map_step no longer called:
+    # both runs went through the graph-free window path and the comparison was vacuous)
+    assert sa["render_paths"] == ["direct-window"] and sb["render_paths"] == ["per-view"], (sa["render_paths"], sb["render_paths"])
     assert sa["rows_after_keyframe"][:1] == sb["rows_after_keyframe"][:1]
     assert abs(sa["rows_final"] - sb["rows_final"]) <= 0.05 * sa["rows_final"]
     assert abs(pa["mean_psnr"] - pb["mean_psnr"]) <= 0.5, (pa["mean_psnr"], pb["mean_psnr"])
