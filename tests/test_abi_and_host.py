@@ -182,3 +182,19 @@ def test_concurrent_imports_after_a_source_change_build_once_and_all_load():
 def _abi():
     from splatloc_amd import _native
     return _native.ABI_VERSION
+
+
+def test_probe_patches_apply():
+    """The timing probes live as patches beside the sources (tools/patches), not in the shipped translation
+    units — and a patch nobody applies rots with the first kernel change (round 4 found two dead hunks).  Every patch must
+    apply cleanly to the current tree (`patch -p1 --dry-run`; no fuzz, no rejects)."""
+    import glob
+    import shutil
+    import subprocess
+    if not shutil.which("patch"):
+        pytest.skip("patch(1) not installed")
+    patches = sorted(glob.glob(os.path.join(ROOT, "tools", "patches", "*.patch")))
+    assert patches
+    for p in patches:
+        r = subprocess.run(["patch", "-p1", "--dry-run", "--fuzz=0", "-i", p], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0 and "FAILED" not in r.stdout and "fuzz" not in r.stdout, (p, r.stdout[-800:], r.stderr[-400:])
