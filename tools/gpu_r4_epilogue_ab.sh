@@ -1,4 +1,7 @@
 #!/bin/bash
+# A/B of two builds of the library over 10-second clock traces and the default bench (profiles/r04_ab_probes.txt item 12: the forward's
+# epilogue with back-to-back stores vs the shipped one).  $V = the variant library built beforehand with tools/ablate.py (here: the
+# shipped sources as "preep" while the working tree held the candidate); run on the GPU box: bash tools/gpu_r4_epilogue_ab.sh
 V=splatloc_amd/_lib/variants/libsplatraster_preep.so
 mkdir -p gpurun_out/epab
 for i in 1 2; do
