@@ -105,3 +105,33 @@ def test_pose_refinement_converges():
     err1 = float((w.detach() - w_true).norm() + (tr.detach() - t_true).norm())
     assert float(loss) < 0.35 * first, (first, float(loss))
     assert err1 < 0.35 * err0, (err0, err1)
+
+
+def test_refine_pose_recovers_a_perturbed_camera():
+    """splatloc_amd.pose.refine_pose — the loop the reference's utils/optimization_utils.py helpers are meant for (axis-angle +
+    translation -> 4x4 -> viewmatrix -> rasterizer -> photometric + depth loss -> pose gradients): a camera perturbed by
+    ~2 degrees / 6 cm ends within 30 % of its initial pose error, with the loss down by 3x."""
+    from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer, pose
+    dev = torch.device("cuda:0")
+    sc = make_scene(6000, 256, 192, 3, 81, scale_median=0.05).to(dev)
+    cam = PinholeCamera(256, 192, 128.0, 128.0, 127.5, 95.5)
+    cam.to(dev)
+    w_true = torch.tensor([[0.02, -0.03, 0.01]], device=dev)
+    t_true = torch.tensor([[0.03, -0.02, 0.05]], device=dev)
+    W2C_true = pose.at_to_transform_matrix(w_true, t_true)[0]
+    with torch.no_grad():
+        view, proj, campos = pose.camera_tensors(W2C_true, cam.projection_matrix)
+        rs = GaussianRasterizationSettings(192, 256, cam.tanfovx, cam.tanfovy, sc.bg, 1.0, view, proj, 0, campos, False, False)
+        tgt_c, tgt_d, _, _ = GaussianRasterizer(raster_settings=rs)(
+            means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), shs=None, colors_precomp=sc.features,
+            opacities=sc.opacities, scales=sc.scales, rotations=sc.rotations, cov3D_precomp=None)
+    g = dict(means3D=sc.means3D, colors=sc.features, opacities=sc.opacities, scales=sc.scales, rotations=sc.rotations)
+    W2C, hist = pose.refine_pose((tgt_c, tgt_d), g, cam, torch.eye(4, device=dev), iterations=150, background=sc.bg)
+    hist = hist.cpu()
+    assert torch.isfinite(hist).all() and float(hist[-1]) < 0.35 * float(hist[0]), (float(hist[0]), float(hist[-1]))
+
+    def err(M):
+        dR = M[:3, :3] @ W2C_true[:3, :3].T
+        ang = torch.acos(((torch.trace(dR) - 1) / 2).clamp(-1, 1))
+        return float(ang) + float((M[:3, 3] - W2C_true[:3, 3]).norm())
+    assert err(W2C) < 0.35 * err(torch.eye(4, device=dev)), (err(torch.eye(4, device=dev)), err(W2C))
