@@ -754,7 +754,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BP_T(tk1);
     bprof[11] = tk1 - tk0;
-    if (lane == 0) {
+    if (lane == 0 && (blockIdx.x % 61u) == 0) {   // a SAMPLE of the waves: same-address atomics from every wave stall the L2 channel they share
 #pragma unroll
         for (int k = 0; k < 12; ++k) atomicAdd(&g_bwd_prof[k], bprof[k]);
     }

@@ -14,7 +14,7 @@ HipRun(sc, backward=True)
 torch.cuda.synchronize()
 raw.splatraster_debug_bwd_prof(out, 1)
 v = list(out)
-waves = 8160 * 4
+waves = len(range(0, 8160 * 4, 61))   # the probe samples every 61st workgroup
 names = ["fetch-wait", "stage", "alpha-eval", "chain+moments", "butterfly|reduce_e", "park", "flush", "mfma-dot"]
 print("per-wave avg cycles:", {n: round(v[i] / waves) for i, n in enumerate(names)}, "| whole kernel", round(v[11] / waves), "| sum of phases", round(sum(v[:8]) / waves))
 print("per-wave counts: chunks %.1f rounds %.1f hit pairs %.1f" % (v[8] / waves, v[9] / waves, v[10] / waves))
