@@ -138,6 +138,13 @@ def test_window_matches_per_view_calls(cfg):
     _compare(make_scene(**cfg), V)
 
 
+def test_window_of_4k_frames_takes_three_tile_sort_passes():
+    """3840 x 2160 is 32 400 tiles per view: three views are 97 200 (view, tile) keys — 17 bits, so the tile sort runs THREE
+    8-bit passes and ends in the other buffer of its ping-pong pair (every other test stays within 16 bits); one view alone is
+    15 bits.  Same contract: bit-identical to the per-view calls."""
+    _compare(make_scene(5000, 3840, 2160, 4, 407, scale_median=0.02), 3)
+
+
 def test_window_larger_than_one_launch_sequence_is_chunked():
     _compare(make_scene(3000, 200, 120, 4, 406, scale_median=0.04), 11)    # 8 + 3
 
