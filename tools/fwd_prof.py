@@ -23,3 +23,5 @@ print("per-wave avg cycles (100 MHz s_memtime ticks x clock ratio: see readcycle
 print("per-wave counts: chunks %.1f rounds %.1f pairs %.1f" % (v[8] / waves, v[9] / waves, v[10] / waves))
 print("cycles per pair %.0f, per staging round %.0f; epilogue: %.0f until the last store is issued, %.0f waiting for the stores" % (
     v[3] / max(v[10], 1), v[2] / max(v[9], 1), v[5] / waves, (v[4] - v[5]) / waves))
+print("lane utilisation: %.1f of 64 pixels hit per evaluated candidate (%.1f %%); %.1f candidates per wave" % (
+    v[6] / max(v[7], 1), 100.0 * v[6] / max(64 * v[7], 1), v[7] / waves))
