@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 8
+#define SPLATRASTER_ABI_VERSION 9
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
@@ -531,6 +531,12 @@ int splatraster_debug_set_split_max_waves(int waves);
 /* A/B / test hook: instance count from which the per-instance payload is written with streaming (non-temporal) stores
  * (DESIGN.md §11); < 0 restores the built-in default (8 Mi instances), 0 = always.  Results never depend on it. */
 int splatraster_debug_set_payload_stream_min(int64_t instances);
+/* A/B / test hook: which front end orders the tile instances.  -1 (default): the binned front end (counting sort by
+ * (view, tile) + one LDS sort per tile) for windows of at most 6144 (view, tile) lists — SplatLoc's own
+ * 640x480 frames, singly or five at a time — and the two global radix sorts otherwise; 0: the radix sorts always; 1: the
+ * binned front end whenever the shape allows (at most 16 384 tiles per view).  Both produce bit-identical point lists,
+ * ranges and payloads.  Must not change between the geometry and the render stage of a forward. */
+int splatraster_debug_set_front_end(int mode);
 int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
 /* test hook: fills the LDS of every compute unit with `pattern` (e.g. a NaN's bits): enough workgroups of 64 KB each to cover
  * the whole array.  The compositing kernels read rows of their LDS staging buffers that a round did not write (the absent second

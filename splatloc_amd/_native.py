@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 8   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 9   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 WARN_LOOKBACK_STALL = 5   # splatraster_poll_errors() only; not an error of any frame
@@ -99,6 +99,7 @@ SYMBOLS = {
     "splatraster_get_window_image_layout": (C.c_int, [_i32, _i32, _i32, C.POINTER(ImageLayout)]),
     "splatraster_debug_set_small_panel_max_waves": (C.c_int, [C.c_int]),
     "splatraster_debug_set_split_max_waves": (C.c_int, [C.c_int]),
+    "splatraster_debug_set_front_end": (C.c_int, [C.c_int]),
     "splatraster_debug_set_payload_stream_min": (C.c_int, [C.c_int64]),
     "splatraster_mark_visible": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_get_geometry_layout": (C.c_int, [_i32, C.POINTER(GeometryLayout)]),
@@ -179,6 +180,8 @@ def load(build_if_missing: bool = True):
     # A/B knobs for perf experiments (process-wide debug switches of the library; never set in production)
     if os.environ.get("SPLATRASTER_SPLIT_MAX_WAVES"):
         lib.splatraster_debug_set_split_max_waves(int(os.environ["SPLATRASTER_SPLIT_MAX_WAVES"]))
+    if os.environ.get("SPLATRASTER_FRONT_END"):   # -1 auto, 0 radix sorts, 1 binned whenever the shape allows
+        lib.splatraster_debug_set_front_end(int(os.environ["SPLATRASTER_FRONT_END"]))
     if os.environ.get("SPLATRASTER_SMALL_PANEL_MAX_WAVES"):
         lib.splatraster_debug_set_small_panel_max_waves(int(os.environ["SPLATRASTER_SMALL_PANEL_MAX_WAVES"]))
     return lib
@@ -219,6 +222,12 @@ def timing_collect() -> dict:
 def set_deterministic(on: bool) -> None:
     """Deterministic-sum debug mode of the backward (bit-reproducible gradients; see splatraster.h)."""
     check(load().splatraster_debug_set_deterministic(int(bool(on))), "set_deterministic")
+
+
+def set_front_end(mode: int) -> None:
+    """-1: default choice; 0: the two global radix sorts always; 1: the binned front end whenever the shape allows
+    (splatraster_debug_set_front_end; bit-identical results either way)."""
+    check(load().splatraster_debug_set_front_end(int(mode)), "set_front_end")
 
 
 def poll_stall() -> bool:

@@ -35,8 +35,8 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-a
 # (integer outputs derived from them are compared bit-for-bit)
 # extra defines for experiments (tools/ablate.py sets this before build(force=True) into another LIB_DIR)
 EXTRA_FLAGS: list = []
-NO_CONTRACT = {"preprocess.hip", "binning.hip", "knn.hip"}
-SOURCES = ["preprocess.hip", "preprocess_bwd.hip", "scan_sort.hip", "binning.hip", "composite_fwd.hip",
+NO_CONTRACT = {"preprocess.hip", "binning.hip", "binsort.hip", "knn.hip"}
+SOURCES = ["preprocess.hip", "preprocess_bwd.hip", "scan_sort.hip", "binning.hip", "binsort.hip", "composite_fwd.hip",
            "composite_bwd.hip", "knn.hip", "activations.hip", "losses.hip", "densify.hip", "capi.hip"]
 
 

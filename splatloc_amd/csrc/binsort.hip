@@ -1,0 +1,663 @@
+// binsort.hip — the tile-binned front end: counting sort of the tile instances by (view, tile) + one LDS sort per tile.
+//
+// The radix front end (binning.hip) orders the instances with two global sorts: the P rows by depth (4 one-sweep passes),
+// then the R instances by tile id (2 passes) — 14 launches whose chains of look-backs and kernel boundaries are what a small
+// frame pays for (SplatLoc's own 640x480: 170 of the 540 us of a color_refinement iteration, train_gaussians.py:269-297).
+// Here the same (tile, depth bits, row) order comes out of four launches, none of which waits for a predecessor block:
+//   1. bin_walk_kernel<.., false>  one block per chunk of 2048 rows of one view (8192 rows on frames of more than 2048
+//                          tiles, where the table would outgrow the rows): LDS histogram of the tiles its rects cover
+//                          -> table[(view, tile)][chunk] (every entry written: nothing to zero)
+//   2. exclusive scan of the table (scan_sort.hip): entry = first slot of (tile, chunk) in the final list; the grand
+//                          total is R on the device
+//   3. bin_walk_kernel<.., true>   the same walk; an LDS atomic on the (tile, chunk) cursor hands out the slot; writes the 64-bit
+//                          key (depth bits << 32 | row).  The order inside a (tile, chunk) piece is whatever the LDS atomics
+//                          made it — the next kernel fixes it
+//   4. bin_sort_tile_kernel  one block per (view, tile), ceil(n / 1024) of its four waves at work: the list (up to 4096
+//                          keys) is sorted IN REGISTERS by a bitonic network, at most 16 keys per lane — distances below the
+//                          keys-per-lane are compare-exchanges between a lane's own registers, the six distances between lanes
+//                          are DPP / permlane exchanges, only the one to three distances across waves of a list beyond 1024
+//                          keys go through LDS — and written out as the payload the compositing kernels stream (irec, ipack)
+//                          together with point_list, tile_list and the tile's range.
+//                          (History, 1200 lists of ~1000 keys, 640x480: the whole network in LDS 57 us, LDS-bandwidth-bound;
+//                          256 threads x 4 keys in registers 48 - 60 us, VALU-issue-bound at 3 700 instructions per wave x
+//                          4 waves — a wave64 VALU instruction occupies its SIMD for 4 cycles; ONE wave x 32 keys per lane
+//                          73 us: 10 500 instructions per wave, a power-of-two network pads 1030 keys to 2048; this form:
+//                          profiles/r05_ab_probes.txt.)
+// (depth bits, row) is unique inside a tile, so the sorted list is THE (tile, depth, index) order of the lineage's stable
+// 64-bit sort — bit-identical point lists and ranges to the radix front end (tests/test_gpu_binsort.py runs both).
+// Lists of more than 4096 entries go to a work list served by a second launch (1024 threads x 8 or 16 keys in registers;
+// beyond 16 384 keys a normalised network runs on the global buffer: slow, correct).
+//
+// Compiled with -ffp-contract=off like preprocess.hip / binning.hip: the rect arithmetic must round like preprocess's.
+#include "composite_common.h"
+#ifdef SR_BIN_TIMING   // tools/micro/tilesort_bench.hip: s_memtime stamps of every phase of a block
+namespace sr { __device__ unsigned long long* g_bin_dbg = nullptr; }
+#define SR_STAMP(k) do { if (threadIdx.x == 0 && g_bin_dbg) g_bin_dbg[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SR_STAMP(k) do { } while (0)
+#endif
+
+namespace sr {
+
+__device__ __forceinline__ int f2i_sat_c(float v)
+{
+    if (!(v > -1.0e9f)) v = -1.0e9f;
+    if (!(v < 1.0e9f)) v = 1.0e9f;
+    return (int)v;
+}
+
+// tile rect of a row from its preprocess record (pixel x, y, depth, radius) — the arithmetic of preprocess_kernel
+struct Rect { int x0, y0, x1, y1; };
+__device__ __forceinline__ Rect rect_of(const float4 p, int gx, int gy)
+{
+    const float rf = p.w;
+    Rect r;
+    r.x0 = min(gx, max(0, f2i_sat_c((p.x - rf) / (float)TILE)));
+    r.y0 = min(gy, max(0, f2i_sat_c((p.y - rf) / (float)TILE)));
+    r.x1 = min(gx, max(0, f2i_sat_c((p.x + rf + (float)(TILE - 1)) / (float)TILE)));
+    r.y1 = min(gy, max(0, f2i_sat_c((p.y + rf + (float)(TILE - 1)) / (float)TILE)));
+    return r;
+}
+
+__device__ __forceinline__ void wave_order()
+{
+    // LDS operations of one wave execute in issue order; this keeps the compiler from moving them across the point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// grid (chunks, V), 1024 threads, ROWS rows of the view per thread; dynamic LDS: tiles words.  16 waves per block and at most
+// a few dependent steps per thread: the walk is a chain of LDS atomic round trips (the returned slot addresses the store), so
+// it is latency that more resident waves hide, not bandwidth (4 waves x 8 rows per block: 13 / 21 us for count / scatter at
+// 500k rows, 640x480; 16 waves x 2 rows: see profiles/r05_ab_probes.txt).
+template <int ROWS, bool SCATTER>
+__global__ void __launch_bounds__(BIN_THREADS)
+bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __restrict__ rec,
+                uint32_t* __restrict__ table /*[(v * tiles + t) * nchunk + chunk]: COUNT out / exclusive prefix in*/,
+                uint64_t* __restrict__ keys /*SCATTER: [R]*/, uint32_t* __restrict__ big_count /*COUNT: zeroed here*/)
+{
+    extern __shared__ uint32_t s_bin[];
+    const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+    uint32_t* col = table + (size_t)v * tiles * nchunk + chunk;
+    if (!SCATTER && big_count && t == 0 && chunk == 0 && v == 0) *big_count = 0u;
+    const int i0 = chunk * (BIN_THREADS * ROWS);
+    float4 p[ROWS];   // every row's record is requested before the first one is used
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const int i = i0 + k * BIN_THREADS + t;
+        p[k] = i < P ? rec[2 * ((size_t)v * P + i)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int k = t; k < tiles; k += BIN_THREADS) s_bin[k] = SCATTER ? col[(size_t)k * nchunk] : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        if (!(p[k].w > 0.0f)) continue;   // culled rows (and the padding beyond P) carry radius 0
+        const uint32_t g = (uint32_t)v * (uint32_t)P + (uint32_t)(i0 + k * BIN_THREADS + t);
+        const Rect r = rect_of(p[k], gx, gy);
+        const uint64_t key = ((uint64_t)__float_as_uint(p[k].z) << 32) | g;
+        for (int y = r.y0; y < r.y1; ++y)
+            for (int x = r.x0; x < r.x1; ++x) {
+                const uint32_t slot = atomicAdd(&s_bin[y * gx + x], 1u);
+                if (SCATTER) keys[slot] = key;
+            }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (int k = t; k < tiles; k += BIN_THREADS) col[(size_t)k * nchunk] = s_bin[k];
+    }
+}
+
+// ---- per-tile sort -------------------------------------------------------------------------
+// Bitonic network on N = THREADS * E keys held E per thread, "blocked": thread t owns elements t E ... t E + E - 1
+// (pads = ~0).  Element i of a merge of size k sorts ascending iff (i & k) == 0; a step of distance j compares i with
+// i ^ j.  Distances below E are compare-exchanges between a thread's own registers (5 VALU instructions per pair),
+// distances inside a wave move the partner's key with DPP / the gfx950 permlane swaps, distances across waves go through
+// LDS.  A wave64 VALU instruction occupies its SIMD for 4 cycles and the first version of this file (256 threads per list,
+// 4 keys per thread, every distance >= 4 an exchange between lanes: 3 700 VALU instructions per wave, 18 M per frame) was
+// bound by exactly that; one wave per list with 16 - 32 keys per lane keeps most distances inside the registers.
+// Keys are distinct — (depth bits, row) — except the pads, which are interchangeable: "take the partner's key" is (y < x)
+// for the keeper of the minimum and its negation for the keeper of the maximum: one 64-bit compare and a mask xor.
+
+// value of lane (l ^ D) for D = 1, 2, 4, 8, 16, 32: DPP for the distances inside a row of 16 lanes, the permlane swaps of
+// gfx950 for 16 and 32
+template <int D>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
+{
+    const int iv = (int)v;
+    if (D == 1) return (uint32_t)__builtin_amdgcn_mov_dpp(iv, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    if (D == 2) return (uint32_t)__builtin_amdgcn_mov_dpp(iv, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    if (D == 4) {   // banks 0, 2 read lane + 4 (row_ror:12), banks 1, 3 read lane - 4 (row_ror:4)
+        const int a = __builtin_amdgcn_mov_dpp(iv, 0x12C, 0xf, 0x5, true);
+        return (uint32_t)__builtin_amdgcn_update_dpp(a, iv, 0x124, 0xf, 0xA, false);
+    }
+    if (D == 8) return (uint32_t)__builtin_amdgcn_mov_dpp(iv, 0x128, 0xf, 0xf, true);   // row_ror:8
+    if (D == 16) {  // rows 0 <-> 1, 2 <-> 3
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return ((__lane_id() & 16) == 0) ? r[1] : r[0];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return ((__lane_id() & 32) == 0) ? r[1] : r[0];
+}
+template <int D>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v)
+{
+    return ((uint64_t)lane_xor<D>((uint32_t)(v >> 32)) << 32) | lane_xor<D>((uint32_t)v);
+}
+// One distance between lanes.  All partner keys are fetched, then all compares issued, then all selects: a compare writes a lane
+// mask that a scalar xor and two selects consume — written element by element that chain (VALU -> SALU -> VALU) stalls the wave
+// at every link (SQ_WAIT_INST_ANY was as large as the VALU time itself with one or two waves per SIMD).
+template <int E, int D>
+__device__ __forceinline__ void lane_step(uint64_t (&x)[E], bool keep_max)
+{
+    if constexpr (D >= 16) {
+        // the permlane swaps hand BOTH partners' keys to both lanes: L (the lane with bit D clear) and H.  The keeper of the
+        // minimum takes H iff H < L, the keeper of the maximum iff not: one compare, one mask xor, two selects per key
+        uint64_t L[E], H[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t lo = (uint32_t)x[e], hi = (uint32_t)(x[e] >> 32);
+            if constexpr (D == 16) {
+                const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+                const auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+                L[e] = ((uint64_t)c[0] << 32) | a[0];
+                H[e] = ((uint64_t)c[1] << 32) | a[1];
+            } else {
+                const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+                const auto c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+                L[e] = ((uint64_t)c[0] << 32) | a[0];
+                H[e] = ((uint64_t)c[1] << 32) | a[1];
+            }
+        }
+        bool th[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) th[e] = (H[e] < L[e]) != keep_max;
+#pragma unroll
+        for (int e = 0; e < E; ++e) x[e] = th[e] ? H[e] : L[e];
+    } else {
+        uint64_t y[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) y[e] = lane_xor64<D>(x[e]);
+        bool take[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) take[e] = (y[e] < x[e]) != keep_max;
+#pragma unroll
+        for (int e = 0; e < E; ++e) x[e] = take[e] ? y[e] : x[e];
+    }
+}
+__device__ __forceinline__ void cmpx_reg(uint64_t& a, uint64_t& b, bool desc)
+{
+    const bool sw = (a > b) != desc;
+    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+    a = lo;
+    b = hi;
+}
+// one distance J inside the thread: all compares, then all selects
+template <int E, int J>
+__device__ __forceinline__ void reg_step(uint64_t (&x)[E], bool desc)
+{
+    bool sw[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (!(e & J)) sw[e] = (x[e] > x[e | J]) != desc;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (!(e & J)) {
+            const uint64_t a = x[e], b = x[e | J];
+            x[e] = sw[e] ? b : a;
+            x[e | J] = sw[e] ? a : b;
+        }
+}
+
+template <int E, int THREADS>
+__device__ __forceinline__ void sort_regs(uint64_t (&x)[E], uint64_t* s /*LDS [THREADS * min(E, BIN_EX_REGS)], THREADS > 64 only*/)
+{
+    constexpr uint32_t N = (uint32_t)THREADS * E;
+    const uint32_t t = threadIdx.x, i0 = t * E;
+    // merges inside the thread (sizes 2 ... E/2): every direction is a compile-time constant
+#pragma unroll
+    for (int k = 2; k < E; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (!(e & j)) cmpx_reg(x[e], x[e | j], (e & k) != 0);
+        }
+    }
+#pragma unroll 1
+    for (uint32_t k = (E > 1 ? E : 2); k <= N; k <<= 1) {
+        const bool desc = (i0 & k) != 0;   // k >= E: one direction per thread
+#pragma unroll 1
+        for (uint32_t j = k >> 1; j >= (uint32_t)E; j >>= 1) {
+            const uint32_t d = j / E;                           // thread distance
+            const bool keep_max = (((t & d) == 0) == desc);     // the lower partner keeps the minimum of an ascending merge
+            if (THREADS == WAVE || d < (uint32_t)WAVE) {
+                switch (d) {
+                    case 1: lane_step<E, 1>(x, keep_max); break;
+                    case 2: lane_step<E, 2>(x, keep_max); break;
+                    case 4: lane_step<E, 4>(x, keep_max); break;
+                    case 8: lane_step<E, 8>(x, keep_max); break;
+                    case 16: lane_step<E, 16>(x, keep_max); break;
+                    default: lane_step<E, 32>(x, keep_max); break;
+                }
+            } else {   // across waves: through LDS, BIN_EX_REGS registers at a time (element e of thread t at s[(e % G) * THREADS + t])
+                constexpr int G = E < BIN_EX_REGS ? E : BIN_EX_REGS;
+#pragma unroll
+                for (int e0 = 0; e0 < E; e0 += G) {
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < G; ++e) s[e * THREADS + t] = x[e0 + e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < G; ++e) {
+                        const uint64_t y = s[e * THREADS + (t ^ d)];
+                        const bool take = (y < x[e0 + e]) != keep_max;
+                        x[e0 + e] = take ? y : x[e0 + e];
+                    }
+                }
+            }
+        }
+        if (E > 8) reg_step<E, (E > 8 ? 8 : 0)>(x, desc);
+        if (E > 4) reg_step<E, (E > 4 ? 4 : 0)>(x, desc);
+        if (E > 2) reg_step<E, (E > 2 ? 2 : 0)>(x, desc);
+        if (E > 1) reg_step<E, (E > 1 ? 1 : 0)>(x, desc);
+    }
+}
+
+// LDS index of list position i for the rows' transposition (blocked in, striped out): one pad word per 32 keeps both the
+// writes of thread t (positions t E + e) and the reads (positions r THREADS + t) free of bank conflicts
+__device__ __forceinline__ uint32_t pad32(uint32_t i) { return i + (i >> 5); }
+
+// what payload_kernel (binning.hip) writes for the sorted list of one (view, tile), plus the lists themselves; row_at(q) =
+// the row of list position q.  The record gathers of U positions are requested before the first one is used.
+template <int THREADS, typename RowAt>
+__device__ __forceinline__ void write_tile(RowAt row_at, uint32_t n, uint32_t start, uint32_t gt, int gx, int tiles,
+                                           const float4* __restrict__ rec, const BinView& b)
+{
+    constexpr int U = 8;
+    const uint32_t tl = gt % (uint32_t)tiles;
+    const uint32_t ty = tl / (uint32_t)gx, tx = tl - ty * (uint32_t)gx;
+    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+    for (uint32_t q0 = threadIdx.x; q0 < n; q0 += THREADS * U) {
+        uint32_t g[U];
+        float4 a0[U], a1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + u * THREADS;
+            g[u] = row_at(q < n ? q : q0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a0[u] = rec[2 * (size_t)g[u]];
+            a1[u] = rec[2 * (size_t)g[u] + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + u * THREADS;
+            if (q < n) {
+                const size_t j = (size_t)start + q;
+                b.irec[2 * j] = a0[u];
+                b.irec[2 * j + 1] = payload_conic(a1[u]);
+                b.ipack[j] = g[u] | (quadrant_reach_mask(a0[u], a1[u], x0, y0) << 24);
+                b.point_list[j] = g[u];
+                b.tile_list[j] = gt;
+            }
+        }
+    }
+}
+
+// loads the list (blocked), sorts it in registers and leaves the rows in LDS at pad32(list position)
+template <int E, int THREADS>
+__device__ __forceinline__ void sort_list(const uint64_t* __restrict__ keys, uint32_t n, uint64_t* s_ex, uint32_t* s_rows)
+{
+    uint64_t x[E];
+    const uint32_t i0 = threadIdx.x * E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = i0 + e;
+        const uint64_t v = keys[i < n ? i : n - 1];
+        x[e] = i < n ? v : ~0ull;
+    }
+    sort_regs<E, THREADS>(x, s_ex);
+    if (THREADS > WAVE) __syncthreads();   // (s_rows may alias the exchange buffer)
+#pragma unroll
+    for (int e = 0; e < E; ++e) s_rows[pad32(i0 + e)] = (uint32_t)x[e] & 0xFFFFFFu;
+    if (THREADS > WAVE) __syncthreads(); else wave_order();
+}
+
+// Normalised bitonic network on n keys in GLOBAL memory (lists beyond the 16 384 keys the work-list launch holds in
+// registers): merge size k = 2, 4, ...; the first step of a merge pairs i with its MIRROR inside the k-block, the following
+// steps pair i with i + j, j = k/4 ... 1.  Every compare-exchange is ascending (minimum to the lower index), so elements
+// beyond n behave as +infinity without being stored: a pair whose upper index is >= n is skipped.  One block, a workgroup
+// barrier (and with it an L2 round trip) per step: slow, correct, rare.
+template <int THREADS>
+__device__ void bitonic_sort_global(uint64_t* s, uint32_t n)
+{
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    const uint32_t half = N >> 1;
+    auto step = [&](bool mirror, uint32_t kj) {
+        for (uint32_t p = threadIdx.x; p < half; p += THREADS) {
+            uint32_t lo, hi;
+            if (mirror) {
+                const uint32_t h = kj >> 1, blk = p / h, off = p & (h - 1);
+                lo = blk * kj + off;
+                hi = blk * kj + (kj - 1 - off);
+            } else {
+                lo = ((p & ~(kj - 1)) << 1) | (p & (kj - 1));
+                hi = lo | kj;
+            }
+            if (hi < n) {
+                const uint64_t a = s[lo], b = s[hi];
+                if (a > b) { s[lo] = b; s[hi] = a; }
+            }
+        }
+        __syncthreads();
+    };
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        step(true, k);
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) step(false, j);
+    }
+}
+
+__device__ __forceinline__ void tile_span(uint32_t gt, int gtiles, int nchunk, const uint32_t* __restrict__ table,
+                                          const uint32_t* __restrict__ total, uint32_t& start, uint32_t& n)
+{
+    start = table[(size_t)gt * nchunk];
+    const uint32_t end = (gt + 1 < (uint32_t)gtiles) ? table[(size_t)(gt + 1) * nchunk] : total[0];
+    n = end - start;
+}
+
+// ---- the first sort launch: a register-blocked bitonic network on 64-bit keys compared as DOUBLES -----------------------
+// A key is (bits of a positive float depth) << 32 | row.  Read as an IEEE double that is a positive NORMAL number (the
+// double's exponent field is the float's sign and top exponent bits: never 0, never 0x7ff), and positive doubles order like
+// their bit patterns — so v_min_f64 / v_max_f64 are a 64-bit compare-exchange in TWO instructions (the integer form: one
+// compare + four selects, and a scalar xor where the direction varies).  Pads are +infinity.  The network is the NORMALISED
+// bitonic network (every compare-exchange puts the minimum at the lower index: no directions): a merge of size k = 2^m starts
+// with a MIRROR step (i <-> i ^ (k - 1)) followed by half-cleaners of distance k/4 ... 1.  The keys live in LDS; a pass loads 16
+// of them per thread, chosen so that the next (up to) four steps stay inside the thread's registers, and stores them back:
+//   A   the first pass: 16 consecutive keys, merges 2 ... 16 complete (10 steps);
+//   B   start of a merge k >= 32: 8 keys of the lower half of a k-block (stride k/16) and their 8 mirror images: the mirror
+//       step and the half-cleaners k/4, k/8, k/16;
+//   C   16 keys of stride 2^p: half-cleaners 2^(p+3) ... 2^p (the last pass of a merge: the low R <= 4 bits of 16 consecutive keys).
+// 15 passes for 1024 keys: 880 min / max instructions and 480 LDS accesses per wave, where the DPP form issued 5 800 VALU
+// instructions.  LDS index of key i: i + (i >> 4) — one pad per 16 makes every pass's 8-byte accesses conflict-free.
+__device__ __forceinline__ uint32_t pidx(uint32_t i) { return i + (i >> 4); }
+__device__ __forceinline__ void ce(double& a, double& b)
+{
+    double lo, hi;   // (inline asm: fmin / fmax would add canonicalising v_max_f64 x, x for signalling NaNs that cannot occur)
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    a = lo;
+    b = hi;
+}
+// half-cleaners on register bits R-1 ... 0 of the 16 registers
+template <int R>
+__device__ __forceinline__ void half_cleaners(double (&x)[16])
+{
+#pragma unroll
+    for (int bit = R - 1; bit >= 0; --bit) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (!(c & (1 << bit))) ce(x[c], x[c | (1 << bit)]);
+    }
+}
+__device__ __forceinline__ void sort16(double (&x)[16])
+{
+#pragma unroll
+    for (int k = 2; k <= 16; k <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if ((c ^ (k - 1)) > c) ce(x[c], x[c ^ (k - 1)]);   // mirror inside the k-block
+#pragma unroll
+        for (int j = k >> 2; j > 0; j >>= 1) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (!(c & j)) ce(x[c], x[c | j]);
+        }
+    }
+}
+template <bool MULTI_WAVE>
+__device__ __forceinline__ void pass_sync()
+{
+    if (MULTI_WAVE) __syncthreads(); else wave_order();
+}
+#define SR_LOAD16(ADDR)  _Pragma("unroll") for (int c = 0; c < 16; ++c) x[c] = s[pidx(ADDR)]
+#define SR_STORE16(ADDR) _Pragma("unroll") for (int c = 0; c < 16; ++c) s[pidx(ADDR)] = x[c]
+
+// sorts the N = 2^M keys (16 <= N, N / 16 <= blockDim.x working threads) at s[pidx(0 ... N-1)]
+template <bool MULTI_WAVE>
+__device__ void sort_lds_f64(double* s, uint32_t M)
+{
+    const uint32_t t = threadIdx.x;
+    const bool work = t < (1u << (M - 4));
+    double x[16];
+    if (work) {
+        double* row = s + 17u * t;   // pidx(16 t + c) = 17 t + c
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = row[c];
+        sort16(x);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) row[c] = x[c];
+    }
+#pragma unroll 1
+    for (uint32_t m = 5; m <= M; ++m) {
+        pass_sync<MULTI_WAVE>();
+        uint32_t g = m - 4;   // free low bits of the merge's first pass; then: low bits still to be cleaned
+        if (work) {
+            const uint32_t low = t & ((1u << g) - 1u), blk = t >> g;
+            const uint32_t l0 = (blk << m) + low, u0 = (blk << m) + (1u << (m - 1)) + ((1u << g) - 1u - low);
+            // registers 0..7: L_b = l0 + (b << g); registers 8..15: U'_b = u0 + (b << g); mirror pairs L_b <-> U'_(7-b)
+            if (g >= 4) {   // (b << g) has no bits below 16: the pad term is linear in b
+                const uint32_t pl = pidx(l0), pu = pidx(u0), st = (1u << g) + (1u << (g - 4));
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[c] = s[(c < 8 ? pl : pu) + (uint32_t)(c & 7) * st];
+#pragma unroll
+                for (int b8 = 0; b8 < 8; ++b8) ce(x[b8], x[15 - b8]);
+                half_cleaners<3>(x);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) s[(c < 8 ? pl : pu) + (uint32_t)(c & 7) * st] = x[c];
+            } else {
+                SR_LOAD16((c < 8 ? l0 : u0) + ((uint32_t)(c & 7) << g));
+#pragma unroll
+                for (int b8 = 0; b8 < 8; ++b8) ce(x[b8], x[15 - b8]);
+                half_cleaners<3>(x);
+                SR_STORE16((c < 8 ? l0 : u0) + ((uint32_t)(c & 7) << g));
+            }
+        }
+        while (g > 0) {
+            pass_sync<MULTI_WAVE>();
+            if (g >= 4) {
+                const uint32_t p = g - 4;
+                if (work) {
+                    const uint32_t base = ((t >> p) << (p + 4)) | (t & ((1u << p) - 1u));
+                    if (p >= 4) {
+                        const uint32_t pb = pidx(base), st = (1u << p) + (1u << (p - 4));
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) x[c] = s[pb + (uint32_t)c * st];
+                        half_cleaners<4>(x);
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) s[pb + (uint32_t)c * st] = x[c];
+                    } else {
+                        SR_LOAD16(base + ((uint32_t)c << p));
+                        half_cleaners<4>(x);
+                        SR_STORE16(base + ((uint32_t)c << p));
+                    }
+                }
+                g -= 4;
+            } else {
+                if (work) {
+                    double* row = s + 17u * t;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) x[c] = row[c];
+                    if (g == 3) half_cleaners<3>(x);
+                    else if (g == 2) half_cleaners<2>(x);
+                    else half_cleaners<1>(x);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) row[c] = x[c];
+                }
+                g = 0;
+            }
+        }
+    }
+    pass_sync<MULTI_WAVE>();
+}
+
+// First sort launch: one 128-thread block per global tile; a list of up to 1024 keys is its first wave's alone (the other
+// leaves at once), up to 2048 both waves'.  Longer lists are appended to the work list.
+__global__ void __launch_bounds__(128)
+bin_sort_tile_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* __restrict__ table /*exclusive prefix*/,
+                     const uint32_t* __restrict__ total /*[0]: R*/, const uint64_t* __restrict__ keys,
+                     const float4* __restrict__ rec, BinView b, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list)
+{
+    __shared__ double s_keys[BIN_SORT_TILE + BIN_SORT_TILE / 16];
+    const uint32_t gt = blockIdx.x, t = threadIdx.x;
+    uint32_t start, n;
+    SR_STAMP(0);
+#ifdef SR_BIN_TIMING
+    if (threadIdx.x == 0 && g_bin_dbg) {
+        g_bin_dbg[8 * blockIdx.x + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        g_bin_dbg[8 * blockIdx.x + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    }
+#endif
+    tile_span(gt, gtiles, nchunk, table, total, start, n);
+    if (t == 0) {   // empty tiles keep [0, 0), like the radix front end's zeroed table
+        b.ranges[2 * gt] = n ? start : 0u;
+        b.ranges[2 * gt + 1] = n ? start + n : 0u;
+        if (n > (uint32_t)BIN_SORT_TILE) big_list[atomicAdd(big_count, 1u)] = gt;
+    }
+    if (n == 0 || n > (uint32_t)BIN_SORT_TILE) return;
+    const bool two = n > 1024u;
+    if (!two && t >= 64u) return;
+    uint32_t M = 4;
+    while ((1u << M) < n) ++M;
+    const uint32_t N = 1u << M, T = two ? 128u : 64u;
+    const uint64_t* src = keys + start;
+    uint64_t* s_bits = reinterpret_cast<uint64_t*>(s_keys);
+    for (uint32_t i0 = t; i0 < N; i0 += 8 * T) {   // (N is a multiple of 16; eight loads in flight per lane)
+        uint64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + u * T;
+            v[u] = src[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + u * T;
+            if (i < N) s_bits[pidx(i)] = i < n ? v[u] : 0x7FF0000000000000ull;   // pad: +infinity
+        }
+    }
+    SR_STAMP(1);
+    if (two) { __syncthreads(); sort_lds_f64<true>(s_keys, M); } else { wave_order(); sort_lds_f64<false>(s_keys, M); }
+    SR_STAMP(3);
+    auto row_at = [&](uint32_t q) { return (uint32_t)s_bits[pidx(q)] & 0xFFFFFFu; };
+    if (two) write_tile<128>(row_at, n, start, gt, gx, tiles, rec, b);
+    else write_tile<64>(row_at, n, start, gt, gx, tiles, rec, b);
+#ifdef SR_BIN_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SR_STAMP(5);
+}
+
+// Second sort launch: a few 1024-thread blocks stride over the work list; up to BIN_SORT_BIG keys in registers (8 or 16 per
+// thread), the global network beyond.
+__global__ void __launch_bounds__(1024)
+bin_sort_big_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* __restrict__ table,
+                    const uint32_t* __restrict__ total, uint64_t* __restrict__ keys, const float4* __restrict__ rec, BinView b,
+                    const uint32_t* __restrict__ big_count, const uint32_t* __restrict__ big_list)
+{
+    constexpr int ROWS_WORDS = BIN_SORT_BIG + BIN_SORT_BIG / 32, EX_WORDS = 2 * 1024 * BIN_EX_REGS;
+    __shared__ uint64_t s_buf[(ROWS_WORDS > EX_WORDS ? ROWS_WORDS : EX_WORDS) / 2];
+    uint32_t* s_rows = reinterpret_cast<uint32_t*>(s_buf);
+    const uint32_t nwork = *big_count;
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint32_t gt = big_list[wi];
+        uint32_t start, n;
+        tile_span(gt, gtiles, nchunk, table, total, start, n);
+        if (n <= (uint32_t)BIN_SORT_BIG) {
+            const uint64_t* src = keys + start;
+            if (n <= 4096u) sort_list<4, 1024>(src, n, s_buf, s_rows);
+            else if (n <= 8192u) sort_list<8, 1024>(src, n, s_buf, s_rows);
+            else sort_list<16, 1024>(src, n, s_buf, s_rows);
+            write_tile<1024>([&](uint32_t q) { return s_rows[pad32(q)]; }, n, start, gt, gx, tiles, rec, b);
+        } else {
+            uint64_t* list = keys + start;
+            bitonic_sort_global<1024>(list, n);
+            write_tile<1024>([&](uint32_t q) { return (uint32_t)list[q] & 0xFFFFFFu; }, n, start, gt, gx, tiles, rec, b);
+        }
+        __syncthreads();   // the next work item reuses the LDS
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+static int g_bin_mode = -1;   // -1 auto, 0 never, 1 whenever the shape allows
+void set_bin_mode(int mode) { g_bin_mode = mode < 0 ? -1 : (mode > 1 ? 1 : mode); }
+
+size_t bin_table_entries(int32_t P, int32_t V, int tiles)
+{
+    return (size_t)(V > 0 ? V : 1) * (size_t)tiles * (size_t)bin_chunks(P, tiles);
+}
+
+size_t bin_scratch_bytes(int32_t P, int32_t V, int tiles)
+{
+    const size_t entries = bin_table_entries(P, V, tiles);
+    return align_up(entries * sizeof(uint32_t), 256) + scan_tmp_bytes((int64_t)entries);
+}
+
+bool use_bins(int32_t P, int32_t V, int tiles, size_t scratch_bytes)
+{
+    if (g_bin_mode == 0 || P <= 0 || tiles <= 0 || tiles > BIN_MAX_TILES) return false;
+    if (bin_table_entries(P, V, tiles) >= ((size_t)1 << 31)) return false;
+    if (bin_scratch_bytes(P, V, tiles) > scratch_bytes) return false;
+    if (g_bin_mode == 1) return true;
+    return (int64_t)V * tiles <= BIN_AUTO_MAX_TILES;
+}
+
+// geometry stage: per-(tile, chunk) counts and their exclusive scan (the state words of the scan at scan_tmp must be zero:
+// preprocess_kernel clears them)
+int launch_bin_count(const splatraster_settings& s, int32_t P, int32_t V, const GeomView& g, uint32_t* table, void* scan_tmp,
+                     hipStream_t stream)
+{
+    const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
+    const int tiles = gx * gy, nchunk = bin_chunks(P, tiles);
+    if (bin_chunk_rows(tiles) == BIN_THREADS * 2)
+        hipLaunchKernelGGL((bin_walk_kernel<2, false>), dim3((unsigned)nchunk, (unsigned)V), dim3(BIN_THREADS),
+                           (size_t)tiles * sizeof(uint32_t), stream, P, tiles, gx, gy, nchunk, g.rec, table,
+                           (uint64_t*)nullptr, g.total + 2);
+    else
+        hipLaunchKernelGGL((bin_walk_kernel<8, false>), dim3((unsigned)nchunk, (unsigned)V), dim3(BIN_THREADS),
+                           (size_t)tiles * sizeof(uint32_t), stream, P, tiles, gx, gy, nchunk, g.rec, table,
+                           (uint64_t*)nullptr, g.total + 2);
+    SR_LAUNCH_CHECK();
+    return exclusive_scan_u32((int64_t)bin_table_entries(P, V, tiles), table, g.total, scan_tmp, stream, true);
+}
+
+// render stage: scatter the keys, sort every tile's list, write the payload
+int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g,
+                            const uint32_t* table, const BinView& b, uint64_t* keys, uint32_t* big_list, hipStream_t stream)
+{
+    const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
+    const int tiles = gx * gy, nchunk = bin_chunks(P, tiles);
+    const int gtiles = V * tiles;
+    (void)R;
+    if (bin_chunk_rows(tiles) == BIN_THREADS * 2)
+        hipLaunchKernelGGL((bin_walk_kernel<2, true>), dim3((unsigned)nchunk, (unsigned)V), dim3(BIN_THREADS),
+                           (size_t)tiles * sizeof(uint32_t), stream, P, tiles, gx, gy, nchunk, g.rec,
+                           const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr);
+    else
+        hipLaunchKernelGGL((bin_walk_kernel<8, true>), dim3((unsigned)nchunk, (unsigned)V), dim3(BIN_THREADS),
+                           (size_t)tiles * sizeof(uint32_t), stream, P, tiles, gx, gy, nchunk, g.rec,
+                           const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr);
+    SR_LAUNCH_CHECK();
+    uint32_t* big_count = g.total + 2;
+    hipLaunchKernelGGL(bin_sort_tile_kernel, dim3((unsigned)gtiles), dim3(128), 0, stream, gtiles, tiles, gx, nchunk, table,
+                       g.total, keys, g.rec, b, big_count, big_list);
+    SR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bin_sort_big_kernel, dim3(BIN_BIG_BLOCKS), dim3(1024), 0, stream, gtiles, tiles, gx, nchunk, table,
+                       g.total, keys, g.rec, b, big_count, big_list);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
+}
+
+}  // namespace sr

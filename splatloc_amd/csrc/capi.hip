@@ -153,7 +153,7 @@ GeomView geom_view(void* base, int32_t P, int32_t V)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, ipack, featp, gacc, ckpt, tile_order, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, ipack, featp, gacc, ckpt, tile_order, big_list, bytes;
 };
 static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t H, int32_t C)
 {
@@ -181,6 +181,7 @@ static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t 
     const bool ck = C <= 4 && 4 * (size_t)tiles <= (size_t)SPLIT_MAX_WAVES;
     L.ckpt = take(ck ? nv * (size_t)SPLIT_PARTS * (size_t)(C + 2) * (size_t)W * (size_t)H * sizeof(float) : 16);
     L.tile_order = take(4 * (tiles > 0 ? tiles : 1));
+    L.big_list = take(4 * (tiles > 0 ? tiles : 1));
     L.bytes = o;
     return L;
 }
@@ -202,6 +203,7 @@ BinView bin_view(void* base, int32_t P, int32_t V, int64_t R, int32_t W, int32_t
     v.gacc = reinterpret_cast<float*>(b + L.gacc);
     v.ckpt = reinterpret_cast<float*>(b + L.ckpt);
     v.tile_order = reinterpret_cast<uint32_t*>(b + L.tile_order);
+    v.big_list = reinterpret_cast<uint32_t*>(b + L.big_list);
     return v;
 }
 
@@ -344,6 +346,23 @@ static WinCams make_cams(int32_t V, const splatraster_window_view* views)
     return c;
 }
 
+// The binned front end (binsort.hip) keeps its (tile, chunk) table and the state of its scan where the radix front end
+// keeps the depth-sort buffers (sort_keys ... scan_tmp): the geometry buffer's size does not depend on the path.
+struct BinScratch { bool on; uint32_t* table; void* scan_tmp; int64_t entries; };
+static BinScratch bin_scratch(const splatraster_settings& s, int32_t P, int32_t V, void* geometry)
+{
+    const int tiles = ((s.image_width + TILE - 1) / TILE) * ((s.image_height + TILE - 1) / TILE);
+    const GeomLayout L = geom_layout(P, V);
+    BinScratch b{};
+    b.on = geometry && use_bins(P, V, tiles, L.total - L.sort_keys);
+    if (!b.on) return b;
+    char* base = reinterpret_cast<char*>(geometry);
+    b.entries = (int64_t)bin_table_entries(P, V, tiles);
+    b.table = reinterpret_cast<uint32_t*>(base + L.sort_keys);
+    b.scan_tmp = base + L.sort_keys + align_up((size_t)b.entries * sizeof(uint32_t), 256);
+    return b;
+}
+
 // Stage 1 of the forward over a window of V views (V = 1: the plain call): one preprocess, ONE depth sort of the
 // V * P rows, one scan; the per-view instance counts are read back under the sort.
 static int window_geometry(const splatraster_settings* s, int32_t V, const splatraster_window_view* views, int32_t P,
@@ -378,12 +397,18 @@ static int window_geometry(const splatraster_settings* s, int32_t V, const splat
     GeomView g = geom_view(geometry, P, V);
     char* base = reinterpret_cast<char*>(geometry);
     const WinCams cams = make_cams(V, views);
+    const BinScratch bins = bin_scratch(*s, P, V, geometry);
     {
         StageTimer t(SPLATRASTER_STAGE_PREPROCESS, stream);
         // the look-back state of the depth sort and of the scan is cleared by preprocess_kernel
-        st = launch_preprocess(*s, P, V, cams, means3D, shs, opacities, scales, rotations, cov3D_precomp, g,
-                               g.sort_tmp, (uint32_t)(sort_zero_bytes(n, 32) / 4),
-                               reinterpret_cast<uint32_t*>(base + L.scan_tmp), (uint32_t)(scan_state_bytes(n) / 4), stream);
+        if (bins.on)
+            st = launch_preprocess(*s, P, V, cams, means3D, shs, opacities, scales, rotations, cov3D_precomp, g, nullptr, 0u,
+                                   reinterpret_cast<uint32_t*>(bins.scan_tmp), (uint32_t)(scan_state_bytes(bins.entries) / 4),
+                                   stream, false);
+        else
+            st = launch_preprocess(*s, P, V, cams, means3D, shs, opacities, scales, rotations, cov3D_precomp, g,
+                                   g.sort_tmp, (uint32_t)(sort_zero_bytes(n, 32) / 4),
+                                   reinterpret_cast<uint32_t*>(base + L.scan_tmp), (uint32_t)(scan_state_bytes(n) / 4), stream);
     }
     if (st) return st;
     HostSlot* slot = nullptr;
@@ -392,6 +417,12 @@ static int window_geometry(const splatraster_settings* s, int32_t V, const splat
     if (st) return st;
     SR_HIP_CHECK(hipMemcpyAsync(slot->p, g.block_tiles, sizeof(uint32_t) * nblk * (size_t)V, hipMemcpyDeviceToHost, stream));
     SR_HIP_CHECK(hipEventRecord(slot->ev, stream));
+    if (bins.on) {
+        // binned front end (binsort.hip): per-(tile, chunk) counts + their scan instead of the depth sort + offsets scan
+        StageTimer t(SPLATRASTER_STAGE_DEPTH_SORT, stream);
+        st = launch_bin_count(*s, P, V, g, bins.table, bins.scan_tmp, stream);
+        if (st) return st;
+    } else {
     {
         StageTimer t(SPLATRASTER_STAGE_DEPTH_SORT, stream);
         bool in_alt = false;
@@ -407,6 +438,7 @@ static int window_geometry(const splatraster_settings* s, int32_t V, const splat
                                 g.span_owner, (uint32_t)EMIT_SPAN, SPAN_OWNER_CAP);
     }
     if (st) return st;
+    }
     SR_HIP_CHECK(hipEventSynchronize(slot->ev));  // the copy only: sort and scan may still be running
     uint64_t total = 0;
     for (int v = 0; v < V; ++v) {
@@ -452,7 +484,15 @@ static int window_render(const splatraster_settings* s, int32_t V, const splatra
     uint32_t* v0 = (passes & 1) ? b.vals_tmp : b.point_list;
     uint32_t* k1 = (passes & 1) ? b.tile_list : b.keys_tmp;
     uint32_t* v1 = (passes & 1) ? b.point_list : b.vals_tmp;
-    if (R > 0) {
+    const BinScratch bins = bin_scratch(*s, P, V, geometry);
+    if (R > 0 && bins.on) {
+        // binned front end: scatter the 64-bit keys into their (tile, chunk) pieces, sort every tile's list in LDS and write
+        // the payload + lists + ranges (binsort.hip); the keys live where the radix path keeps its unsorted pairs
+        StageTimer t(SPLATRASTER_STAGE_TILE_SORT, stream);
+        st = launch_bin_scatter_sort(*s, P, V, R, g, bins.table, b, reinterpret_cast<uint64_t*>(b.keys_tmp), b.big_list, stream);
+        if (st) return st;
+    }
+    if (R > 0 && !bins.on) {
         {
             StageTimer t(SPLATRASTER_STAGE_EMIT, stream);
             st = launch_emit(*s, P, V, R, g, k0, v0, b.ranges, 2u * (uint32_t)gtiles, stream);  // also clears the range table
@@ -473,7 +513,7 @@ static int window_render(const splatraster_settings* s, int32_t V, const splatra
     const float* featp = feat;  // 16-byte aligned rows for the compositing kernels
     if (R > 0) {
         StageTimer t(SPLATRASTER_STAGE_PAYLOAD, stream);
-        st = launch_payload(*s, V, R, g, b, stream);
+        if (!bins.on) st = launch_payload(*s, V, R, g, b, stream);
         if (st) return st;
         if (s->channels % 4) {
             st = launch_pad_features(P, s->channels, feat, b.featp, stream);
@@ -691,6 +731,12 @@ int splatraster_debug_set_small_panel_max_waves(int waves)
 int splatraster_debug_set_payload_stream_min(int64_t instances)
 {
     sr::set_payload_stream_min(instances);
+    return SPLATRASTER_OK;
+}
+
+int splatraster_debug_set_front_end(int mode)
+{
+    set_bin_mode(mode);
     return SPLATRASTER_OK;
 }
 

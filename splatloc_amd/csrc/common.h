@@ -98,7 +98,7 @@ struct GeomView {
     uint8_t* clamped;        // [3P]
     uint32_t* sort_keys;     // [n] scratch (depth bits)
     uint32_t* sort_tmp;      // scratch for the n-sized sort + scan partials
-    uint32_t* total;         // [2] device-side R (uint64 as two words), written by the scan
+    uint32_t* total;         // [4] device-side R (uint64 as two words), written by the scan; [2]: entries of the binned front end's work list
     uint32_t* block_tiles;   // [V * preprocess_blocks(P)] per-(view, block) sums of tiles_touched, written by preprocess
     uint32_t* span_owner;    // [SPAN_OWNER_CAP] depth rank owning instance k * EMIT_SPAN, written by the one-pass scan
 };
@@ -116,6 +116,7 @@ struct BinView {
     float* gacc;          // [V * P * gacc_row_floats(C)] backward gradient accumulator rows (one per row)
     float* ckpt;          // [V][SPLIT_PARTS][C + 2][H * W] segment records of the forward (T in front of the segment, its own colours, depth), split launches only
     uint32_t* tile_order; // [V * tiles] global tile ids, longest list first: the launch order of the compositing kernels
+    uint32_t* big_list;   // [V * tiles] binned front end: the (view, tile) lists too long for the first sort launch
 };
 struct ImgView {
     float* final_T;       // [V][H * W]
@@ -130,7 +131,7 @@ ImgView img_view(void* base, int32_t W, int32_t H, int32_t V);
 int launch_preprocess(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const float* means3D,
                       const float* shs /*V == 1 only*/, const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, GeomView g, uint32_t* zero0, uint32_t nzero0, uint32_t* zero1, uint32_t nzero1,
-                      hipStream_t stream);
+                      hipStream_t stream, bool depth_keys = true /*false: no depth-sort input (binned front end)*/);
 // sums the gradient contributions of the V views of a window into ONE set of parameter gradients (written once,
 // in view order: deterministic given the accumulator rows); dL/dmeans2D is per view
 int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const WinGrad& grads,
@@ -158,6 +159,33 @@ int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint
                        uint32_t span = 0, uint32_t span_cap = 0);
 constexpr int EMIT_SPAN = 1024;  // instances emitted per workgroup (binning.hip)
 constexpr uint32_t SPAN_OWNER_CAP = 1u << 16;  // emit workgroups that get their first rank from the scan (R <= 64 M)
+
+// exclusive scan of in[0, n) in place (in == out); total (u64 as 2 words) optional; state words at tmp zeroed by the caller
+// when state_zeroed
+int exclusive_scan_u32(int64_t n, uint32_t* inout, uint32_t* total, void* tmp, hipStream_t stream, bool state_zeroed = false);
+
+// ---- tile-binned front end (binsort.hip): counting sort by (view, tile) + one LDS sort per tile ----------------
+constexpr int BIN_THREADS = 1024;           // threads of a count / scatter block
+// rows of one view per count / scatter block: 2048 (2 per thread) — every CU gets a block at SplatLoc's sizes — unless the frame
+// has so many tiles that the (tile, chunk) table would outgrow the rows it describes: then 8192 (8 per thread)
+static inline int bin_chunk_rows(int tiles) { return BIN_THREADS * (tiles <= 2048 ? 2 : 8); }
+static inline int bin_chunks(int32_t P, int tiles) { return (P + bin_chunk_rows(tiles) - 1) / bin_chunk_rows(tiles); }
+constexpr int BIN_MAX_TILES = 16384;        // tiles per view: the LDS histogram of a count / scatter block (64 KB)
+#ifndef SR_BIN_AUTO_MAX_TILES
+#define SR_BIN_AUTO_MAX_TILES 6144          // (view, tile) lists up to which the binned front end is the default
+#endif
+constexpr int BIN_AUTO_MAX_TILES = SR_BIN_AUTO_MAX_TILES;
+constexpr int BIN_SORT_TILE = 2048;         // longest list of the per-tile launch (2 waves x 16 keys per lane, in 17 KB of LDS)
+constexpr int BIN_EX_REGS = 4;              // keys per thread that cross waves through LDS at a time
+constexpr int BIN_SORT_BIG = 16384, BIN_BIG_BLOCKS = 32; // the work-list launch for longer lists (keys in registers of 1024 threads, blocks)
+void set_bin_mode(int mode);   // -1 auto, 0 radix front end always, 1 binned whenever the shape allows
+size_t bin_table_entries(int32_t P, int32_t V, int tiles);
+size_t bin_scratch_bytes(int32_t P, int32_t V, int tiles);
+bool use_bins(int32_t P, int32_t V, int tiles, size_t scratch_bytes);
+int launch_bin_count(const splatraster_settings& s, int32_t P, int32_t V, const GeomView& g, uint32_t* table, void* scan_tmp,
+                     hipStream_t stream);
+int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g,
+                            const uint32_t* table, const BinView& b, uint64_t* keys, uint32_t* big_list, hipStream_t stream);
 
 int launch_emit(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g, uint32_t* keys,
                 uint32_t* vals, uint32_t* ranges, uint32_t nranges, hipStream_t stream);

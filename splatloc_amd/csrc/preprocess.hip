@@ -207,8 +207,10 @@ preprocess_kernel(int P, int V, int W, int H, float scale_modifier, int sh_degre
             rec[2 * g + 1] = r1;
             // input of the depth sort: view depth > 0.2 for every visible Gaussian, so its IEEE bits
             // order like the value; culled rows sort to the end
-            sort_keys[g] = out_radius > 0 ? __float_as_uint(tz) : 0xFFFFFFFFu;
-            sort_vals[g] = (uint32_t)g | (min(out_tiles, 255u) << 24);   // (rows < 2^24; the count rides along for the scan)
+            if (sort_keys) {   // (null: the binned front end, binsort.hip, orders the instances per tile instead)
+                sort_keys[g] = out_radius > 0 ? __float_as_uint(tz) : 0xFFFFFFFFu;
+                sort_vals[g] = (uint32_t)g | (min(out_tiles, 255u) << 24);   // (rows < 2^24; the count rides along for the scan)
+            }
         }
         uint32_t t = out_tiles;
 #pragma unroll
@@ -230,14 +232,15 @@ preprocess_kernel(int P, int V, int W, int H, float scale_modifier, int sh_degre
 int launch_preprocess(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const float* means3D,
                       const float* shs, const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, GeomView g, uint32_t* zero0, uint32_t nzero0,
-                      uint32_t* zero1, uint32_t nzero1, hipStream_t stream)
+                      uint32_t* zero1, uint32_t nzero1, hipStream_t stream, bool depth_keys)
 {
     if (P == 0) return SPLATRASTER_OK;
     const int blocks = preprocess_blocks(P);
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(PREPROCESS_BLOCK), 0, stream, P, V, s.image_width,
                        s.image_height, s.scale_modifier, s.sh_degree, s.sh_coeffs, cams,
                        means3D, shs, opacities, scales, rotations, cov3D_precomp, g.rec,
-                       g.tiles_touched, g.rgb, g.clamped, g.block_tiles, g.sort_keys, g.depth_order, zero0, nzero0, zero1, nzero1);
+                       g.tiles_touched, g.rgb, g.clamped, g.block_tiles, depth_keys ? g.sort_keys : nullptr,
+                       depth_keys ? g.depth_order : nullptr, zero0, nzero0, zero1, nzero1);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

@@ -372,6 +372,20 @@ int inclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* perm, uint
     return scan_u32<false>(n, in, perm, out, total, tmp, stream);
 }
 
+int exclusive_scan_u32(int64_t n, uint32_t* inout, uint32_t* total, void* tmp, hipStream_t stream, bool state_zeroed)
+{
+    const size_t state = scan_state_bytes(n);
+    if (n > 0 && state) {
+        if (!state_zeroed) SR_HIP_CHECK(hipMemsetAsync(tmp, 0, state, stream));
+        const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(scan_onepass_kernel<true>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, n, inout, nullptr, inout,
+                           reinterpret_cast<uint64_t*>(total), reinterpret_cast<ScanState*>(tmp), nullptr, 0u, 0u);
+        SR_LAUNCH_CHECK();
+        return SPLATRASTER_OK;
+    }
+    return scan_u32<true>(n, inout, nullptr, inout, total, tmp, stream);
+}
+
 // ---------------------------------------------------------------------------------------
 // radix sort
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,128 @@
+"""The binned front end (csrc/binsort.hip: counting sort by (view, tile) + one LDS sort per tile) against the radix front
+end (two global stable sorts) and the CPU oracle — needs an MI355X.
+
+Both front ends must leave the SAME forward state: point list, tile ids, ranges, the per-instance payload the compositing
+kernels stream, and therefore bit-identical images / n_contrib / final_T.  The per-view and window entry points share the
+code; shapes are chosen so that every tier of the per-tile sort runs: the one-wave network (lists <= 256), the four-wave
+network in LDS, the work list of the second launch (lists beyond four times the mean) and the global-memory fall-back
+(one list beyond 16 384 entries).
+"""
+import numpy as np
+import pytest
+import torch
+
+from splatloc_amd import _native
+from splatloc_amd.synthetic import make_scene
+from tests.helpers import HipRun, oracle_backward, oracle_forward
+from tests.test_gpu_parity import _check_backward, _check_forward
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_front_end():
+    yield
+    _native.set_front_end(-1)
+
+
+def _state_equal(a: HipRun, b: HipRun):
+    for k in ("tiles_touched", "point_list", "tile_list", "ranges", "n_contrib"):
+        assert torch.equal(a.state[k], b.state[k]), k
+    assert torch.equal(a.state["final_T"].view(torch.int32), b.state["final_T"].view(torch.int32)), "final_T bits"
+    for k in ("color", "depth", "alpha"):
+        assert torch.equal(getattr(a, k).view(torch.int32), getattr(b, k).view(torch.int32)), k + " bits"
+    assert torch.equal(a.radii, b.radii)
+
+
+def _concentrate(sc, n, pixel, depth_lo=1.0, depth_hi=5.0, seed=7):
+    """moves the first n Gaussians onto one pixel (distinct depths): one tile's list gets n entries more"""
+    g = torch.Generator().manual_seed(seed)
+    cam = sc.camera
+    z = depth_lo + (depth_hi - depth_lo) * torch.rand(n, generator=g)
+    fx, fy = cam.image_width / (2.0 * cam.tanfovx), cam.image_height / (2.0 * cam.tanfovy)
+    px, py = pixel
+    sc.means3D[:n, 0] = (px - (cam.image_width - 1) / 2.0) / fx * z
+    sc.means3D[:n, 1] = (py - (cam.image_height - 1) / 2.0) / fy * z
+    sc.means3D[:n, 2] = z
+    sc.scales[:n] = 0.002
+    return sc
+
+
+CASES = {
+    "S0": lambda: make_scene(10_000, 640, 480, 3, 0, scale_median=0.02),
+    "ragged_C35": lambda: make_scene(3_000, 333, 201, 35, 22, scale_median=0.03),
+    "tiny": lambda: make_scene(300, 17, 9, 4, 117, scale_median=0.08),
+    "deep_lists": lambda: make_scene(20_000, 256, 256, 3, 26, scale_median=0.05),
+    "screen_filling": lambda: make_scene(200, 96, 64, 3, 41, scale_median=1.5),
+    "one_long_list": lambda: _concentrate(make_scene(30_000, 256, 256, 4, 51, scale_median=0.02), 9_000, (100.3, 77.6)),
+    "beyond_lds": lambda: _concentrate(make_scene(24_000, 128, 128, 3, 52, scale_median=0.02), 18_000, (40.2, 50.9)),
+    "more_than_one_chunk": lambda: make_scene(40_000, 320, 240, 4, 53, scale_median=0.01),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_front_ends_leave_the_same_state(name):
+    sc = CASES[name]()
+    _native.set_front_end(0)
+    radix = HipRun(sc, backward=False)
+    _native.set_front_end(1)
+    binned = HipRun(sc, backward=True)
+    _state_equal(radix, binned)
+    # and the binned run on its own against the oracle, forward and backward
+    f = oracle_forward(sc)
+    _check_forward(binned, f, sc)
+    _check_backward(binned, oracle_backward(f, sc))
+    if name == "one_long_list":
+        r = f["ranges"].astype(np.int64)
+        lens = r[:, 1] - r[:, 0]
+        assert lens.max() > 8192, (lens.max(), lens.mean())   # the work-list launch, 16 keys per thread
+    if name == "beyond_lds":
+        r = f["ranges"].astype(np.int64)
+        assert (r[:, 1] - r[:, 0]).max() > 16384
+
+
+def test_exact_depth_ties_and_duplicates_keep_index_order():
+    sc = make_scene(600, 128, 96, 3, seed=42, scale_median=0.06)
+    sc.means3D[:, 2] = torch.round(sc.means3D[:, 2] * 2.0) / 2.0
+    sc.means3D[300:] = sc.means3D[:300]
+    _native.set_front_end(1)
+    run = HipRun(sc, backward=False)
+    _check_forward(run, oracle_forward(sc), sc)
+
+
+def test_empty_frame_and_all_culled():
+    sc = make_scene(500, 96, 64, 4, seed=61, scale_median=0.05)
+    sc.means3D[:, 2] = -1.0          # everything behind the camera
+    _native.set_front_end(1)
+    run = HipRun(sc, backward=True)
+    assert run.num_rendered == 0
+    assert float(run.color.abs().max()) == 0.0
+    assert int(run.state["ranges"].abs().max()) == 0
+
+
+def test_window_of_views_binned_equals_radix():
+    """5 views of one scene as ONE launch sequence: per-view state identical under both front ends."""
+    from splatloc_amd import introspect, rasterize_window
+    from tests.test_gpu_window import _views      # the window tests' camera set
+    sc = make_scene(30_000, 320, 240, 4, 71, scale_median=0.02)
+    dev = torch.device("cuda:0")
+    settings = [rs for _, rs, _ in _views(sc, 5, dev)]
+    outs = {}
+    for mode in (0, 1):
+        _native.set_front_end(mode)
+        m3 = sc.means3D.to(dev).requires_grad_(True)
+        m2 = [torch.zeros_like(m3, requires_grad=True) for _ in settings]
+        res = rasterize_window(settings, m3, m2, sc.features.to(dev), sc.opacities.to(dev), sc.scales.to(dev),
+                               sc.rotations.to(dev))
+        fn = res[0][0].grad_fn
+        saved = fn.saved_tensors
+        st = introspect.window_state((saved[7], saved[8], saved[9]), 30_000, 5, 320, 240, fn.R)
+        outs[mode] = (res, st)
+    torch.cuda.synchronize()
+    for v in range(5):
+        a, b = outs[0][1][v], outs[1][1][v]
+        for k in ("point_list", "tile_list", "ranges", "n_contrib"):
+            assert torch.equal(a[k], b[k]), (v, k)
+        assert torch.equal(a["final_T"].view(torch.int32), b["final_T"].view(torch.int32))
+        for i in range(3):
+            assert torch.equal(outs[0][0][v][i].view(torch.int32), outs[1][0][v][i].view(torch.int32))
