@@ -142,6 +142,42 @@ def cpu_baseline(workload, frames=3):
             "host_cpu_count": os.cpu_count()}
 
 
+def cpu_baseline_torch_dense(workload="S0", rows=8, threads=None):
+    """BASELINE config 1's "PyTorch-CPU autograd reference" (BASELINE.md §2 item 2), timed: tests/torch_dense_ref.render_dense
+    — float32 tensor algebra + torch.autograd on the host cores, every pixel of a band against every visible Gaussian —
+    fwd + bwd of `rows` image rows in the middle of the frame (the full S0 frame is 3e9 pairs: ~12 GB per intermediate),
+    extrapolated to the frame's height.  A bounded sample of the same workload; reported beside the oracle's figure."""
+    from splatloc_amd.synthetic import WORKLOADS, make_workload
+    from tests.torch_dense_ref import render_dense
+    wl = WORKLOADS[workload]
+    sc = make_workload(workload)
+    cam = sc.camera
+    H, W = wl["H"], wl["W"]
+    if threads:
+        torch.set_num_threads(threads)
+    y0 = (H - rows) // 2
+    leaf = lambda t: t.detach().clone().float().requires_grad_(True)  # noqa: E731
+    times = []
+    for k in range(2):      # one warm-up band, one timed
+        m3, col, op, sca, rot = (leaf(t) for t in (sc.means3D, sc.features, sc.opacities, sc.scales, sc.rotations))
+        t0 = time.perf_counter()
+        color, depth, alpha, _ = render_dense(H, W, cam.tanfovx, cam.tanfovy, sc.bg, m3, op, cam.world_view_transform,
+                                              cam.full_proj_transform, colors_precomp=col, scales=sca, rotations=rot,
+                                              rows=(y0, y0 + rows))
+        loss = ((color * sc.dL_dcolor[:, y0:y0 + rows]).sum() + (depth * sc.dL_ddepth[:, y0:y0 + rows]).sum()
+                + (alpha * sc.dL_dalpha[:, y0:y0 + rows]).sum())
+        t1 = time.perf_counter()
+        loss.backward()
+        t2 = time.perf_counter()
+        times.append((t2 - t0, t1 - t0, t2 - t1))
+    band = times[-1]
+    frame_s = band[0] * H / rows
+    return {"value": 1.0 / frame_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"tests/torch_dense_ref.render_dense in float32 + torch.autograd on the host: fwd+bwd of image rows "
+                      f"[{y0}, {y0 + rows}) of {workload} ({band[0]:.2f} s: fwd {band[1]:.2f} + bwd {band[2]:.2f}; second of two "
+                      f"runs), extrapolated x {H}/{rows}"}
+
+
 def bench_activations(args, dev):
     """--stage activations: the fused parameter activations + SH / feature packing (SURVEY.md
     §8f-1, splatloc_amd.fused.activate_pack) forward + backward on the S2 parameter shapes
@@ -636,29 +672,42 @@ def bench_refine_step(args, dev):
     }), flush=True)
 
 
-def bench_scene(args, dev):
+def bench_scene(args, dev, rank=0, world=1):
     """--stage scene: the reference's WHOLE reconstruction schedule as one run (train_gaussians.py:310-355 `do_recon`;
     splatloc_amd.scene.do_recon): `--keyframes` synthetic RGB-D key-frames at the reference's frame size (640x480, Replica
     intrinsics) x (extend_from_pcd_seq + 10 map iterations, densify_and_prune every 150 / offset 50), then `--refine`
     colour-refinement iterations (the reference: 26 000), save_ply, and the forward-only eval_rendering loop with device
     PSNR / SSIM.  P grows from zero.  Reports wall time per phase next to the figure extrapolated from the per-iteration
-    stage benches.  Secondary figure, not the BASELINE metric."""
+    stage benches.  Secondary figure, not the BASELINE metric.
+
+    `--gpus N` (BASELINE config 5), two forms:
+      --replicas   N independent scenes (seed = rank), one per GPU, NO collective on the data path — what
+                   /root/reference/replica.sh:1-6 does one scene after the other; value = N scenes / the slowest rank's time;
+      (default)    ONE scene reconstructed frame-parallel: the views of every map window dealt to the ranks, two collectives
+                   per step (`--reduce ring | rs_ag`), the one-view refinement run redundantly and re-broadcast once."""
     import tempfile
     import types
     from splatloc_amd.evaluation import eval_rendering
     from splatloc_amd.ply import save_ply
     from splatloc_amd.scene import DEFAULT_CONFIG, SceneModel, do_recon, synthetic_keyframes
     K, W, H = args.keyframes, 640, 480
+    replicas = bool(args.replicas) and world > 1
+    scene_seed = rank if replicas else 0
     t0 = time.perf_counter()
-    frames, _ = synthetic_keyframes(K, W, H, P_truth=200_000, seed=0, device=dev)
+    frames, _ = synthetic_keyframes(K, W, H, P_truth=args.truth, seed=scene_seed, device=dev)
     torch.cuda.synchronize(dev)
     t_data = time.perf_counter() - t0
     pipe = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
     bg = torch.zeros(3, device=dev)
     model = SceneModel(DEFAULT_CONFIG, dev)
     torch.cuda.reset_peak_memory_stats(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
-    stats = do_recon(model, frames, pipe, bg, DEFAULT_CONFIG, refine_iterations=args.refine, seed=0, batched=not args.no_window)
+    grp = None if (replicas or world == 1) else dist.group.WORLD
+    stats = do_recon(model, frames, pipe, bg, DEFAULT_CONFIG, refine_iterations=args.refine, seed=scene_seed,
+                     batched=not args.no_window, group=grp, distributed=not replicas)
     t_recon = time.perf_counter() - t1
     with tempfile.TemporaryDirectory() as td:
         t2 = time.perf_counter()
@@ -671,14 +720,32 @@ def bench_scene(args, dev):
     t_eval = time.perf_counter() - t3
     map_ms = 1e3 * stats["map_seconds"] / max(stats["map_iterations"], 1)
     ref_ms = 1e3 * stats["refine_seconds"] / max(stats["refine_iterations"], 1)
+    per_rank = [{"rank": rank, "recon_s": round(t_recon, 3), "map_s": round(stats["map_seconds"], 3),
+                 "refine_s": round(stats["refine_seconds"], 3), "rows_final": stats["rows_final"],
+                 "mean_psnr": round(ev["mean_psnr"], 3), "peak_memory_GB": round(stats["peak_memory_bytes"] / 2 ** 30, 3)}]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])       # reporting only (control plane): after the timed schedule
+        per_rank = gathered
+    if rank != 0:
+        return
+    t_max = max(r["recon_s"] for r in per_rank)
+    n_scenes = world if replicas else 1
+    mode = "replicas" if replicas else ("frame-parallel" if world > 1 else "single")
     print(json.dumps({
         "metric": "SplatLoc.do_recon scenes/hour on synthetic key-frames (whole schedule; secondary figure, NOT the BASELINE metric)",
-        "value": round(3600.0 / t_recon, 3), "unit": "scenes/h", "n_gpus": 1, "steps": 1, "warmup": 0,
-        "ms_per_step": round(1e3 * t_recon, 1), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{K} key-frames {W}x{H} (Replica intrinsics) of a 200k-Gaussian synthetic room; per key-frame "
+        "value": round(3600.0 * n_scenes / t_max, 3), "unit": "scenes/h", "n_gpus": world, "steps": 1, "warmup": 0,
+        "ms_per_step": round(1e3 * t_max, 1), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak" if replicas else "strong",
+        "config": {"workload": f"{K} key-frames {W}x{H} (Replica intrinsics) of a {args.truth}-Gaussian synthetic room; per key-frame "
                                "extend_from_pcd_seq + 10 map iterations (window 5, densify every 150 offset 50, reset every 2001); "
                                f"{args.refine} color_refinement iterations; save_ply; eval_rendering",
-                   "launch_mode": "per-view calls" if args.no_window else "window-batched"},
+                   "launch_mode": "per-view calls" if args.no_window else "window-batched",
+                   "multi_gpu_mode": mode, "scenes": n_scenes,
+                   "collectives_on_the_data_path": 0 if (replicas or world == 1) else "2 payload + 1 header per map step, 1 broadcast after the refinement",
+                   "reduce": None if (replicas or world == 1) else args.reduce,
+                   "dist_backend": None if world == 1 else os.environ.get("SPLATLOC_DIST_BACKEND", "nccl")},
+        "per_rank": per_rank,
         "seconds": {"synthetic_keyframes": round(t_data, 2), "map_phase": round(stats["map_seconds"], 2),
                     "refine_phase": round(stats["refine_seconds"], 2), "save_ply": round(t_ply, 3), "eval_rendering": round(t_eval, 3)},
         "map_ms_per_iteration": round(map_ms, 3), "refine_ms_per_iteration": round(ref_ms, 4),
@@ -689,6 +756,89 @@ def bench_scene(args, dev):
         "ply_bytes": ply_bytes,
         "eval": {"mean_psnr": round(ev["mean_psnr"], 3), "mean_ssim": round(ev["mean_ssim"], 4), "frames": ev["frames"],
                  "frames_per_s": round(ev["frames"] / t_eval, 1)},
+    }), flush=True)
+
+
+def bench_pose_refine(args, dev):
+    """--stage pose_refine: BASELINE config 4 as it is worded — "feature raster + pose refinement" — at full size: 500k
+    Gaussians (S2's scene, SplatLoc's [rgb | kp] layout, C = 4), one 640x480 query frame at the 12-Scenes intrinsics
+    (configs/scenes12/base_config.yaml:17-27: fx = fy = 572, cx = 320, cy = 240), the pose perturbed by ~1.5 degrees / 5 cm.
+    One iteration = render, L1 colour + 0.2 L1 depth, backward with dL/dviewmatrix / dL/dprojmatrix, Adam on (axis-angle,
+    translation), next camera tensors (splatloc_amd.pose.refine_pose; utils/optimization_utils.py:31-42 is the
+    parameterisation).  Reported: iterations/s of the graph-free loop (csrc/pose.hip) and of round 4's autograd loop, and the
+    live GPU idle of the graph-free loop (wall time of an un-instrumented region vs the kernel time of the same loop under
+    torch.profiler, like tools/refine_idle.py).  The reference has no such loop: a build extension, secondary figure."""
+    from splatloc_amd import GaussianRasterizationSettings, GaussianRasterizer, pose
+    from splatloc_amd.camera import PinholeCamera
+    from splatloc_amd.synthetic import make_workload
+    sc = make_workload("S2-ref-layout").to(dev)
+    P = int(sc.means3D.shape[0])
+    W, H = 640, 480
+    cam = PinholeCamera(W, H, 572.0, 572.0, 320.0, 240.0)
+    cam.to(dev)
+    W2C_true = pose.at_to_transform_matrix(torch.tensor([[0.015, -0.02, 0.008]], device=dev),
+                                           torch.tensor([[0.03, -0.02, 0.04]], device=dev))[0]
+    with torch.no_grad():
+        view, proj, campos = pose.camera_tensors(W2C_true, cam.projection_matrix)
+        rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, sc.bg, 1.0, view, proj, 0, campos, False, False)
+        tgt_c, tgt_d, _, _ = GaussianRasterizer(raster_settings=rs)(
+            means3D=sc.means3D, means2D=torch.zeros_like(sc.means3D), shs=None, colors_precomp=sc.features,
+            opacities=sc.opacities, scales=sc.scales, rotations=sc.rotations, cov3D_precomp=None)
+    g = dict(means3D=sc.means3D, colors=sc.features, opacities=sc.opacities, scales=sc.scales, rotations=sc.rotations)
+    N = max(args.steps, 20) * 5
+    W2C0 = torch.eye(4, device=dev)
+
+    def run(graph_free, n):
+        return pose.refine_pose((tgt_c, tgt_d), g, cam, W2C0, iterations=n, background=sc.bg, graph_free=graph_free)
+
+    out = {}
+    for name, gf in (("graph_free", True), ("autograd_loop", False)):
+        run(gf, 20)
+        torch.cuda.synchronize(dev)
+        walls = []
+        for _ in range(max(args.repeats, 1)):
+            t0 = time.perf_counter()
+            W2C, hist = run(gf, N)
+            torch.cuda.synchronize(dev)
+            walls.append((time.perf_counter() - t0) / N)
+        walls.sort()
+        out[name] = {"ms_per_iteration": round(1e3 * walls[len(walls) // 2], 4), "iterations_per_s": round(1.0 / walls[len(walls) // 2], 1),
+                     "ms_all_regions": [round(1e3 * w, 4) for w in walls],
+                     "loss_first_last": [round(float(hist[0]), 6), round(float(hist[-1]), 6)]}
+    # live idle of the graph-free loop
+    from torch.profiler import ProfilerActivity, profile
+    M = 60
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        run(True, M)
+        torch.cuda.synchronize(dev)
+    rows = []
+    for e in prof.key_averages():
+        dt = getattr(e, "device_time_total", None)
+        if dt is None:
+            dt = getattr(e, "cuda_time_total", 0)
+        if dt and e.count:
+            rows.append((e.key[:70], e.count / M, dt / M))
+    rows.sort(key=lambda r: -r[2])
+    busy_us = sum(r[2] for r in rows)
+    wall_us = 1e3 * out["graph_free"]["ms_per_iteration"]
+
+    def pose_err(M4):
+        dR = M4[:3, :3] @ W2C_true[:3, :3].T
+        return float(torch.acos(((torch.trace(dR) - 1) / 2).clamp(-1, 1))) + float((M4[:3, 3] - W2C_true[:3, 3]).norm())
+
+    Wf, _ = run(True, 300)
+    print(json.dumps({
+        "metric": "pose-refinement iterations/s (render + L1 RGB-D + backward with pose gradients + Adam on 6 parameters; build extension, NOT the BASELINE metric)",
+        "value": out["graph_free"]["iterations_per_s"], "unit": "iterations/s", "n_gpus": 1, "steps": N, "warmup": 20,
+        "ms_per_step": out["graph_free"]["ms_per_iteration"], "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"P={P} Gaussians (S2's scene), one {W}x{H} query frame, fx = fy = 572 (12-Scenes), C = 4 ([rgb | kp]); "
+                               "pose = T(axis-angle, translation) @ W2C_init, perturbed by ~1.5 deg / 5 cm"},
+        "graph_free": out["graph_free"], "autograd_loop": out["autograd_loop"],
+        "speedup_over_autograd_loop": round(out["autograd_loop"]["ms_per_iteration"] / out["graph_free"]["ms_per_iteration"], 3),
+        "idle": {"wall_us_per_iteration": round(wall_us, 1), "gpu_busy_us_per_iteration_torch_profiler": round(busy_us, 1),
+                 "idle_us_per_iteration": round(wall_us - busy_us, 1), "kernels_per_iteration": round(sum(r[1] for r in rows), 1)},
+        "kernel_table_us_per_iteration": [{"kernel": k, "launches": round(c, 2), "us": round(u, 1)} for k, c, u in rows[:24]],
+        "pose_error_rad_plus_m": {"start": round(pose_err(W2C0), 5), "after_300_iterations": round(pose_err(Wf), 5)},
     }), flush=True)
 
 
@@ -745,17 +895,40 @@ def bench_eval_rendering(args, dev):
     }), flush=True)
 
 
+def count_gpus_without_hip() -> int:
+    """GPUs of this node as the KFD driver lists them (/sys/class/kfd/kfd/topology/nodes/*/properties: a node with
+    simd_count > 0 is a GPU), narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES — read without
+    loading the HIP runtime, so the process that only LAUNCHES the ranks provably never initialises a GPU.
+    Falls back to torch.cuda.device_count() (which on this image does not initialise HIP either) when sysfs is unreadable."""
+    import glob
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n, seen = 0, False
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        seen = True
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n if seen else torch.cuda.device_count()
+
+
 def launch_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) as a FRESH child process —
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <same args>` — and return
     its exit code; rank 0's JSON line goes straight to the inherited stdout.  Called before anything touches the GPU (this
-    process never initialises HIP: `torch.cuda.device_count()` only counts devices), and it starts a child, it never
-    re-execs.  SPLATLOC_DIST_BACKEND=gloo lets a 1-GPU box drive the N-rank path (tests); with RCCL ("nccl", the default)
+    process never initialises HIP: the GPUs are counted from the KFD topology in sysfs, `count_gpus_without_hip`), and it
+    starts a child, it never re-execs.  SPLATLOC_DIST_BACKEND=gloo lets a 1-GPU box drive the N-rank path (tests); with RCCL ("nccl", the default)
     N ranks need N GPUs and anything less is refused instead of silently measuring fewer."""
     import socket
     import subprocess
     backend = os.environ.get("SPLATLOC_DIST_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
+    ndev = count_gpus_without_hip()
     if backend == "nccl" and ndev < n:
         print(f"bench.py --gpus {n}: this node shows {ndev} GPU(s); RCCL needs one GPU per rank "
               "(SPLATLOC_DIST_BACKEND=gloo runs the N-rank plumbing on fewer GPUs, for tests only)", file=sys.stderr)
@@ -793,10 +966,17 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="debug: time the forward only (not the metric)")
     ap.add_argument("--keyframes", type=int, default=60, help="--stage scene: key-frames of the synthetic scene")
     ap.add_argument("--refine", type=int, default=26000, help="--stage scene: color_refinement iterations (the reference: 26000)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="--stage scene --gpus N: N INDEPENDENT scenes, one per GPU, no collective on the data path (what "
+                         "/root/reference/replica.sh runs one after the other); without it the one scene is reconstructed "
+                         "frame-parallel by the N ranks")
+    ap.add_argument("--reduce", default="ring", choices=["ring", "rs_ag"],
+                    help="N > 1: the SUM exchange of a step as one all-reduce (ring) or as reduce-scatter + all-gather (rs_ag)")
+    ap.add_argument("--truth", type=int, default=200_000, help="--stage scene: Gaussians of the synthetic ground-truth room")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of K steps is repeated this many times; value = the MEDIAN region (min / max reported)")
     ap.add_argument("--stage", default="raster",
-                    choices=["raster", "activations", "loss", "map_step", "refine_step", "scene", "eval_rendering"],
+                    choices=["raster", "activations", "loss", "map_step", "refine_step", "scene", "eval_rendering", "pose_refine"],
                     help="raster = the BASELINE metric (default); activations = the fused front-end stage alone")
     args = ap.parse_args()
 
@@ -825,10 +1005,18 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.stage in ("activations", "loss", "map_step", "refine_step", "scene", "eval_rendering"):
+    from splatloc_amd import training as _training
+    _training.REDUCE_MODE = args.reduce
+    if args.stage == "scene" and world > 1:
+        bench_scene(args, dev, rank, world)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if args.stage in ("activations", "loss", "map_step", "refine_step", "scene", "eval_rendering", "pose_refine"):
         if rank == 0:
             {"activations": bench_activations, "loss": bench_loss, "map_step": bench_map_step,
-             "refine_step": bench_refine_step, "scene": bench_scene, "eval_rendering": bench_eval_rendering}[args.stage](args, dev)
+             "refine_step": bench_refine_step, "scene": bench_scene, "eval_rendering": bench_eval_rendering,
+             "pose_refine": bench_pose_refine}[args.stage](args, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -948,11 +1136,13 @@ def main():
                     p.grad = z[k]
                 inc = z["tail"]
             if inc is not None:
-                _, inc_out, red = reduce_step([p.grad for p in params], sum_extras=[inc[0], inc[1]], max_extras=[max_radii])
+                _, inc_out, red = reduce_step([p.grad for p in params], sum_extras=[inc[0], inc[1]], max_extras=[max_radii],
+                                              mode=args.reduce)
                 accum.add_(inc_out[0])
                 denom.add_(inc_out[1])
             else:   # per-view calls (--no-window / --streams): autograd accumulated into the first view's allocation
-                g_out, inc_out, red = reduce_step([p.grad for p in params], sum_extras=[accum, denom], max_extras=[max_radii])
+                g_out, inc_out, red = reduce_step([p.grad for p in params], sum_extras=[accum, denom], max_extras=[max_radii],
+                                                  mode=args.reduce)
                 for p, g in zip(params, g_out):
                     p.grad = g
                 accum.copy_(inc_out[0])
@@ -1148,6 +1338,8 @@ def main():
             out["metric"] = "DEBUG fwd-only frames/s (not the BASELINE metric)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
+            if args.workload == "S0":      # BASELINE config 1: the PyTorch-CPU autograd reference, timed beside the oracle
+                out["cpu_baseline"]["pytorch_cpu_autograd"] = cpu_baseline_torch_dense("S0")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -472,6 +472,26 @@ int splatknn_dist2(int32_t N, const float* points /* [N,3] */, float* out /* [N]
 /* test hook: point count from which splatknn_dist2 takes the grid search (< 0 restores the default 10 000) */
 int splatknn_debug_set_grid_min(int32_t n);
 
+/* ---- pose refinement on the device (build extension, DESIGN.md §4.8: the reference's rasterizer returns no camera gradient
+ * and nothing calls its utils/optimization_utils.py:5-66 pose helpers) ------------------------------------------------------
+ * L = mean |color - target_color| + depth_weight * mean |depth - target_depth| and its gradient planes in one pass;
+ * `*loss_out += L` (a float atomic: zero it before the first call; monitoring value).  target_depth may be NULL (no depth
+ * term; g_depth, when given, is zeroed). */
+int splatraster_l1_rgbd_loss(int64_t n_color, const float* color, const float* target_color, int64_t n_depth, const float* depth,
+                             const float* target_depth, float depth_weight, float* g_color, float* g_depth, float* loss_out,
+                             void* stream);
+/* One Adam step on a camera pose and the camera tensors of the new pose, without leaving the device.
+ * The pose is W2C = T(w, t) @ W2C_init with an axis-angle w and a translation t — at_to_transform_matrix of
+ * utils/optimization_utils.py:31-42 (Rodrigues made regular at w = 0) —, the camera tensors are what
+ * utils/camera_utils.py:129-139 derives from it: viewmatrix = W2C^T, projmatrix = viewmatrix @ projection_matrix,
+ * campos = -R^T t.  state [20 floats, device]: w[3], t[3], Adam exp_avg[6], exp_avg_sq[6], step, pad — all zero at the start.
+ * advance != 0: chains dL_dviewmatrix [16], dL_dprojmatrix [16], dL_dcampos [3 or NULL] (splatraster_backward's outputs) to
+ * (w, t), takes the torch.optim.Adam step (lr_rot for w, lr_trans for t) and writes the NEW pose's tensors;
+ * advance == 0: only writes the tensors of the current state (the first iteration).  All matrices row-major [4, 4]. */
+int splatraster_pose_step(const float* dL_dviewmatrix, const float* dL_dprojmatrix, const float* dL_dcampos, const float* W2C_init,
+                          const float* projection_matrix, float lr_rot, float lr_trans, float beta1, float beta2, float eps,
+                          int advance, float* state, float* viewmatrix, float* projmatrix, float* campos, void* stream);
+
 /* ---- per-stage timing (HIP events on the launch stream) ----------------------------- */
 
 /* Stage ids: every kernel group of the path is bracketed by a hipEvent pair when timing

@@ -133,6 +133,8 @@ SYMBOLS = {
     "splatraster_refinement_loss": (C.c_int, [_i32, _i32, _i32, C.c_float] + [_vp] * 6),
     "splatraster_eval_metrics_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "splatraster_eval_metrics": (C.c_int, [_i32, _i32, _i32] + [_vp] * 5),
+    "splatraster_l1_rgbd_loss": (C.c_int, [_i64, _vp, _vp, _i64, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
+    "splatraster_pose_step": (C.c_int, [_vp] * 5 + [C.c_float] * 5 + [C.c_int] + [_vp] * 5),
     "splatraster_error_string": (C.c_char_p, [C.c_int]),
     "splatraster_last_hip_error": (C.c_char_p, []),
     "splatraster_abi_version": (C.c_int, []),

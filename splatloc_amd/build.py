@@ -37,7 +37,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-a
 EXTRA_FLAGS: list = []
 NO_CONTRACT = {"preprocess.hip", "binning.hip", "binsort.hip", "knn.hip"}
 SOURCES = ["preprocess.hip", "preprocess_bwd.hip", "scan_sort.hip", "binning.hip", "binsort.hip", "composite_fwd.hip",
-           "composite_bwd.hip", "knn.hip", "activations.hip", "losses.hip", "densify.hip", "capi.hip"]
+           "composite_bwd.hip", "knn.hip", "activations.hip", "losses.hip", "densify.hip", "pose.hip", "capi.hip"]
 
 
 def have_hipcc() -> bool:

@@ -969,6 +969,27 @@ int splatraster_eval_metrics(int32_t channels, int32_t height, int32_t width, co
     return launch_eval_metrics(channels, height, width, render, gt, out, workspace, reinterpret_cast<hipStream_t>(stream));
 }
 
+int splatraster_l1_rgbd_loss(int64_t n_color, const float* color, const float* target_color, int64_t n_depth, const float* depth,
+                             const float* target_depth, float depth_weight, float* g_color, float* g_depth, float* loss_out,
+                             void* stream)
+{
+    if (n_color <= 0 || n_depth < 0) return SPLATRASTER_ERR_BAD_ARG;
+    if (!color || !target_color || !g_color || !loss_out) return SPLATRASTER_ERR_BAD_ARG;
+    if (n_depth > 0 && target_depth && !depth) return SPLATRASTER_ERR_BAD_ARG;
+    return launch_l1_rgbd_loss(n_color, color, target_color, n_depth, depth, target_depth, depth_weight, g_color, g_depth, loss_out,
+                               reinterpret_cast<hipStream_t>(stream));
+}
+
+int splatraster_pose_step(const float* dL_dviewmatrix, const float* dL_dprojmatrix, const float* dL_dcampos, const float* W2C_init,
+                          const float* projection_matrix, float lr_rot, float lr_trans, float beta1, float beta2, float eps,
+                          int advance, float* state, float* viewmatrix, float* projmatrix, float* campos, void* stream)
+{
+    if (!W2C_init || !projection_matrix || !state || !viewmatrix || !projmatrix) return SPLATRASTER_ERR_BAD_ARG;
+    if (advance && (!dL_dviewmatrix || !dL_dprojmatrix)) return SPLATRASTER_ERR_BAD_ARG;
+    return launch_pose_step(dL_dviewmatrix, dL_dprojmatrix, dL_dcampos, W2C_init, projection_matrix, lr_rot, lr_trans, beta1, beta2,
+                            eps, advance, state, viewmatrix, projmatrix, campos, reinterpret_cast<hipStream_t>(stream));
+}
+
 int splatknn_debug_set_grid_min(int32_t n)
 {
     knn_set_grid_min(n);

@@ -287,6 +287,12 @@ size_t eval_metrics_workspace_bytes(int32_t C, int32_t H, int32_t W);
 int launch_eval_metrics(int32_t C, int32_t H, int32_t W, const float* image, const float* gt, float* out, void* workspace,
                         hipStream_t stream);
 
+int launch_l1_rgbd_loss(int64_t n_color, const float* color, const float* tgt_c, int64_t n_depth, const float* depth,
+                        const float* tgt_d, float depth_weight, float* g_color, float* g_depth, float* loss_out, hipStream_t stream);
+int launch_pose_step(const float* dL_dview, const float* dL_dproj, const float* dL_dcampos, const float* W2C0, const float* Pm,
+                     float lr_rot, float lr_trans, float beta1, float beta2, float eps, int advance, float* state, float* view_out,
+                     float* proj_out, float* campos_out, hipStream_t stream);
+
 int knn_dist2(int32_t N, const float* points, float* out, void* workspace, hipStream_t stream);
 size_t knn_workspace_bytes(int32_t N);
 void knn_set_grid_min(int n);   // point count from which the exact grid search replaces the tiled brute force (< 0: default)

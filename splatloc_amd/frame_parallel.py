@@ -136,27 +136,47 @@ def sync_densification_stats(grad_accum_inc: torch.Tensor, denom_inc: torch.Tens
     denom_inc.copy_(packed[n:].view_as(denom_inc))
 
 
-_LAYOUT_CHECKED: set = set()
-
-
-def _check_same_layout(numel: int, device, group) -> None:
+def _check_same_layout(numel, device, group) -> None:
     """A SUM over buffers of different lengths is undefined behaviour in RCCL (and silently wrong sums when the
-    lengths agree but the piece order does not).  The first time a buffer length is reduced, every rank checks that
-    all ranks are about to reduce the same length (one tiny MAX collective, then never again for that length)."""
-    key = (id(group), int(numel))
-    if key in _LAYOUT_CHECKED:
-        return
-    t = torch.tensor([numel, -numel], dtype=torch.int64, device=device)
+    lengths agree but the piece order does not).  EVERY call verifies, with one fixed-size 32-byte MAX collective
+    issued before the payload, that all ranks are about to reduce the same length.  (Rounds 3-4 cached the lengths a
+    rank had already checked: a rank that had cached a length skipped the collective while a diverging peer issued
+    it, pairing the peer's int64 MAX with this rank's float SUM — a hang instead of the intended error.  The check is
+    only a check if every rank always takes part in it.)"""
+    lens = [int(numel), 0] if not isinstance(numel, (tuple, list)) else [int(v) for v in numel][:2] + [0] * (2 - len(numel))
+    t = torch.tensor([lens[0], -lens[0], lens[1], -lens[1]], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    lo, hi = -int(t[1]), int(t[0])
-    if lo != hi:
-        raise RuntimeError(f"frame_parallel.reduce_step: ranks disagree on the reduce buffer ({lo} .. {hi} elements); "
-                           "every rank must hold the same replica and use the same gradient layout")
-    _LAYOUT_CHECKED.add(key)
+    v = t.tolist()
+    if v[0] != -v[1] or v[2] != -v[3]:
+        raise RuntimeError(f"frame_parallel.reduce_step: ranks disagree on the reduce buffers (SUM {-v[1]} .. {v[0]}, "
+                           f"MAX {-v[3]} .. {v[2]} elements); every rank must hold the same replica and use the same gradient layout")
+
+
+def _backend_of(group) -> str:
+    try:
+        return str(dist.get_backend(group))
+    except Exception:  # noqa: BLE001
+        return "?"
+
+
+def _sum_all_ranks(buf: torch.Tensor, group, mode: str):
+    """SUM `buf` (flat, contiguous) over the ranks, in place.  mode "ring": one all-reduce.  mode "rs_ag": reduce-scatter +
+    all-gather on the same buffer (every rank owns 1/N of it between the two) — on a full xGMI mesh the direct algorithms
+    use all seven links of a GPU at once where a ring is bound by one link pair; RCCL picks its algorithm
+    itself, so which form wins is a measurement, and one hardware run can print both (`bench.py --reduce rs_ag`).  Needs the
+    length to be a multiple of the world size: the caller pads.  gloo has no reduce-scatter: there the pair is emulated by
+    the all-reduce (the plumbing is what the CPU tests cover)."""
+    if mode == "rs_ag" and _backend_of(group) != "gloo":
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        n = buf.numel() // world
+        mine = buf[rank * n:(rank + 1) * n]
+        dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, group=group)
+        return dist.all_gather_into_tensor(buf, mine, group=group, async_op=True)
+    return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
 def reduce_step(grads: Sequence[torch.Tensor], sum_extras: Sequence[torch.Tensor] = (),
-                max_extras: Sequence[torch.Tensor] = (), group=None):
+                max_extras: Sequence[torch.Tensor] = (), group=None, mode: str = "ring"):
     """Everything one frame-parallel optimisation step exchanges, in at most TWO collectives:
 
       (1) ONE SUM all-reduce over [grads | sum_extras] — the parameter gradients and the increments of
@@ -171,38 +191,54 @@ def reduce_step(grads: Sequence[torch.Tensor], sum_extras: Sequence[torch.Tensor
     back as views of the reduced buffer (no copy back).  Every rank must pass the same shapes in the same order; the
     buffer length is verified across ranks the first time it is seen.
 
+    `mode`: "ring" = one all-reduce for (1); "rs_ag" = reduce-scatter + all-gather on the same buffer (`_sum_all_ranks`;
+    an in-place span whose length is not a multiple of the world size is packed so that it can be padded).  Before the
+    payload every rank takes part in one 32-byte length check (`_check_same_layout`; info["header_collectives"]).
+
     Returns (grads_out, sum_extras_out, info): tensors holding the reduced values (the inputs themselves on the in-place
-    path) and info = {"collectives", "sum_path": "in-place span" | "packed", "sum_bytes", "max_bytes"}.
+    path) and info = {"collectives", "sum_path": "in-place span" | "packed", "sum_bytes", "max_bytes", "mode"}.
     Single process / no process group: returns the inputs unchanged, info["collectives"] = 0."""
     grads, sum_extras, max_extras = list(grads), list(sum_extras), list(max_extras)
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return grads, sum_extras, {"collectives": 0, "sum_path": None, "sum_bytes": 0, "max_bytes": 0}
-    info = {"collectives": 0, "sum_path": None, "sum_bytes": 0, "max_bytes": 0}
+    if mode not in ("ring", "rs_ag"):
+        raise ValueError(f"reduce_step: mode {mode!r}")
+    info = {"collectives": 0, "header_collectives": 0, "sum_path": None, "sum_bytes": 0, "max_bytes": 0, "mode": mode}
+    world = dist.get_world_size(group)
     pending = []
     members = [t for t in grads + sum_extras if t.numel()]
     packed = None
     if members:
         with torch.no_grad():
             spans, rest = _shared_spans(members) if len(members) > 1 else ([], members)
-            if len(spans) == 1 and not rest:
+            total = sum(t.numel() for t in members)
+            divisible = mode != "rs_ag" or total % world == 0
+            if len(spans) == 1 and not rest and (mode != "rs_ag" or spans[0].numel() % world == 0):
                 buf = spans[0]
                 info["sum_path"] = "in-place span"
-            elif len(members) == 1 and members[0].is_contiguous():
+            elif len(members) == 1 and members[0].is_contiguous() and divisible:
                 buf = members[0].view(-1)
                 info["sum_path"] = "in-place span"
             else:
-                buf = packed = torch.cat([t.reshape(-1) for t in members])
+                parts = [t.reshape(-1) for t in members]
+                if not divisible:
+                    parts.append(torch.zeros(world - total % world, dtype=members[0].dtype, device=members[0].device))
+                buf = packed = torch.cat(parts)
                 info["sum_path"] = "packed"
-        _check_same_layout(buf.numel(), buf.device, group)
+        max_len = sum(t.numel() for t in max_extras)
+        _check_same_layout((buf.numel(), max_len), buf.device, group)   # both payload lengths in one header
+        info["header_collectives"] = 1
         info["sum_bytes"] = buf.numel() * buf.element_size()
-        pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
-        info["collectives"] += 1
+        pending.append(_sum_all_ranks(buf, group, mode))
+        info["collectives"] += 2 if (mode == "rs_ag" and _backend_of(group) != "gloo") else 1
     mx = [t for t in max_extras if t.numel()]
     mbuf = None
     if mx:
         with torch.no_grad():
             mbuf = mx[0].view(-1) if (len(mx) == 1 and mx[0].is_contiguous()) else torch.cat([t.reshape(-1) for t in mx])
-        _check_same_layout(mbuf.numel(), mbuf.device, group)
+        if not members:
+            _check_same_layout((0, mbuf.numel()), mbuf.device, group)
+            info["header_collectives"] = 1
         info["max_bytes"] = mbuf.numel() * mbuf.element_size()
         pending.append(dist.all_reduce(mbuf, op=dist.ReduceOp.MAX, group=group, async_op=True))
         info["collectives"] += 1

@@ -127,13 +127,74 @@ def camera_tensors(W2C: torch.Tensor, projection_matrix: torch.Tensor):
 
 
 def refine_pose(render_target, gaussians: dict, camera, W2C_init: torch.Tensor, iterations: int = 100, lr_rot: float = 2e-3,
-                lr_trans: float = 3e-3, depth_weight: float = 0.2, background: torch.Tensor | None = None, on_step=None):
+                lr_trans: float = 3e-3, depth_weight: float = 0.2, background: torch.Tensor | None = None, on_step=None,
+                graph_free: bool = True):
     """Gradient descent on a camera pose through the rasterizer: the pose is W2C = T(w, t) @ W2C_init with an axis-angle w
     and a translation t (both start at zero), the loss is L1(colour) + depth_weight * L1(depth) against `render_target` =
     (colour [C,H,W], depth [1,H,W] or None), Adam on (w, t).  `gaussians`: dict(means3D, colors, opacities, scales, rotations)
     of device tensors (activated values, as the rasterizer takes them); `camera`: intrinsics holder with image_width / height,
     tanfovx / tanfovy and `projection_matrix` (splatloc_amd.camera.PinholeCamera or the reference's Camera).
-    Returns (W2C [4,4] detached, history of loss values as one device tensor [iterations])."""
+    Returns (W2C [4,4] detached, history of loss values as one device tensor [iterations]).
+
+    `graph_free` (default): an iteration is ONE launch sequence with no torch operator in it — the rasterizer's forward and
+    backward called directly (`PlainCtx`, like training.color_refinement_step), `splatraster_l1_rgbd_loss` for the loss and
+    its gradient planes, `splatraster_pose_step` for the chain rule to (w, t), the Adam step and the next camera tensors
+    (csrc/pose.hip): no autograd graph, no torch.optim, the 6 numbers never visit the host.  `graph_free=False` is round
+    4's loop (autograd through the 4x4 algebra + torch.optim.Adam): the same iterates to float32 rounding
+    (tests/test_gpu_pose.py), ~3x the host time per iteration."""
+    if not graph_free:
+        return _refine_pose_autograd(render_target, gaussians, camera, W2C_init, iterations, lr_rot, lr_trans, depth_weight,
+                                     background, on_step)
+    import ctypes as C
+    from . import _native
+    from .rasterizer import GaussianRasterizationSettings, PlainCtx, _RasterizeGaussians, _stream
+    lib = _native.load()
+    dev = gaussians["means3D"].device
+    tgt_c, tgt_d = render_target
+    tgt_c = tgt_c.to(dev).float().contiguous()
+    tgt_d = None if (tgt_d is None or not depth_weight) else tgt_d.to(dev).float().contiguous()
+    W2C0 = W2C_init.to(dev).float().contiguous()
+    Pm = camera.projection_matrix.to(dev).float().contiguous()
+    H, W = int(camera.image_height), int(camera.image_width)
+    bg = background if background is not None else torch.zeros(int(tgt_c.shape[0]) if tgt_c.shape[0] <= 3 else 0, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    state = torch.zeros(20, **f32)          # w, t, Adam moments, step (splatraster_pose_step)
+    view, proj, campos = torch.empty(4, 4, **f32), torch.empty(4, 4, **f32), torch.empty(3, **f32)
+    hist = torch.zeros(iterations, **f32)
+    g_color, g_depth = torch.empty_like(tgt_c), torch.empty((1, H, W), **f32)
+    carrier = torch.zeros_like(gaussians["means3D"])
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+    b1, b2, eps = 0.9, 0.999, 1e-8          # torch.optim.Adam's defaults, as round 4's loop used them
+
+    def step(advance, grads=(None, None, None)):
+        _native.check(lib.splatraster_pose_step(ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(W2C0), ptr(Pm), lr_rot, lr_trans,
+                                                b1, b2, eps, advance, ptr(state), ptr(view), ptr(proj), ptr(campos), _stream(dev)),
+                      "pose_step")
+
+    step(0)
+    rs = GaussianRasterizationSettings(H, W, camera.tanfovx, camera.tanfovy, bg, 1.0, view, proj, 0, campos, False, False)
+    n_c, n_d = tgt_c.numel(), H * W
+    with torch.no_grad():
+        for it in range(iterations):
+            ctx = PlainCtx()
+            color, depth, _alpha, _radii = _RasterizeGaussians.forward(
+                ctx, gaussians["means3D"], carrier, None, gaussians["colors"], gaussians["opacities"], gaussians["scales"],
+                gaussians["rotations"], None, rs, view, proj, campos)
+            _native.check(lib.splatraster_l1_rgbd_loss(n_c, ptr(color), ptr(tgt_c), n_d, ptr(depth), ptr(tgt_d), float(depth_weight),
+                                                       ptr(g_color), ptr(g_depth), C.c_void_p(hist.data_ptr() + 4 * it),
+                                                       _stream(dev)), "l1_rgbd_loss")
+            grads = _RasterizeGaussians.backward(ctx, g_color, g_depth if tgt_d is not None else None, None)
+            step(1, grads[9:12])
+            if on_step:
+                on_step(it, hist[it])
+        w, t = state[:3].clone()[None], state[3:6].clone()[None]
+        return (at_to_transform_matrix(w, t)[0] @ W2C0).detach(), hist
+
+
+def _refine_pose_autograd(render_target, gaussians: dict, camera, W2C_init: torch.Tensor, iterations: int = 100,
+                          lr_rot: float = 2e-3, lr_trans: float = 3e-3, depth_weight: float = 0.2,
+                          background: torch.Tensor | None = None, on_step=None):
+    """round 4's refine_pose: autograd through the pose algebra and the drop-in autograd.Function, torch.optim.Adam."""
     from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     dev = gaussians["means3D"].device
     tgt_c, tgt_d = render_target

@@ -173,13 +173,15 @@ def load_depth(config, viewpoint):
 
 
 def do_recon(gaussians, keyframes, pipe=None, background=None, config=None, refine_iterations: int = 26000, seed: int = 0,
-             batched: bool = True, group=None, on_event=None) -> dict:
+             batched: bool = True, group=None, on_event=None, distributed: bool = True) -> dict:
     """SplatLoc.do_recon (train_gaussians.py:310-355) on `keyframes` (the reference: every `kf_interval`-th dataset frame).
     `batched = False` renders every window — and every refinement iteration — as the reference does: one `render()` per view
     through the drop-in autograd.Function (`render_path="per-view"` of training.map_step / color_refinement_step) instead of
     one graph-free launch sequence per window; `stats["render_paths"]` records which paths the map steps took.  The random draws the reference takes from global RNGs (`torch.randperm` of the window,
     `random.randint` of the refinement view, `np.random.choice` of the key-frame down-sampling) come from generators seeded
-    by `seed`, identical on every rank of a frame-parallel job.  Returns counters and timings; the model is updated in place."""
+    by `seed`, identical on every rank of a frame-parallel job.  `distributed = False`: no collective even when a process
+    group exists — every rank reconstructs a scene of its own (one scene per GPU: /root/reference/replica.sh).  Returns counters
+    and timings; the model is updated in place."""
     cfg = config or gaussians.config
     tr, opt = cfg["Training"], cfg["opt_params"]
     dev = gaussians._xyz.device
@@ -207,7 +209,7 @@ def do_recon(gaussians, keyframes, pipe=None, background=None, config=None, refi
             idx = torch.randperm(len(stack), generator=rng_w)[:tr["window_size"]]          # train_gaussians.py:195
             rows = int(gaussians._xyz.shape[0])
             map_step([stack[i] for i in idx], gaussians, pipe, background, cfg, iteration_count, densify=dens,
-                     gaussian_reset=tr["gaussian_reset"], seed=seed, group=group, render_path=path)
+                     gaussian_reset=tr["gaussian_reset"], seed=seed, group=group, render_path=path, distributed=distributed)
             stats["render_paths"].add(LAST_STEP_INFO.get("render_path"))
             if int(gaussians._xyz.shape[0]) != rows:
                 stats["densify_rows"].append([iteration_count, rows, int(gaussians._xyz.shape[0])])
@@ -226,7 +228,7 @@ def do_recon(gaussians, keyframes, pipe=None, background=None, config=None, refi
                               primitive_reg=bool(tr.get("primitive_reg", True)), render_path=path)
         if on_event and iteration % 500 == 0:
             on_event("refine", iteration, gaussians)
-    if refine_iterations:
+    if refine_iterations and distributed:
         # one view per step does not shard: every rank refined its own replica redundantly, and float-atomic
         # rounding lets redundant replicas drift in the last bits — rank 0's state becomes everybody's again (one broadcast)
         from .frame_parallel import broadcast_model

@@ -6,6 +6,8 @@ may be torch.optim.Adam or splatloc_amd.optim.Adam (one launch over the 8 groups
 """
 from __future__ import annotations
 
+import os
+
 import math
 
 import torch
@@ -199,12 +201,15 @@ def _map_grads_direct(mine, gaussians, pipe, background, config, with_reg: bool)
     return pkgs, loss, grads2d
 
 
+# how a multi-GPU map_step sums its payload: "ring" (one all-reduce) or "rs_ag" (reduce-scatter + all-gather);
+# frame_parallel.reduce_step(mode=...).  bench.py --reduce sets it; every rank must use the same value
+REDUCE_MODE = os.environ.get("SPLATLOC_REDUCE_MODE", "ring")
 # what the last multi-GPU map_step exchanged (frame_parallel.reduce_step's info: collectives, path, bytes) — monitoring
 LAST_STEP_INFO: dict = {}
 
 
 def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: int, *, densify=None,
-             gaussian_reset: int = 0, seed: int = 0, group=None, render_path: str = "auto"):
+             gaussian_reset: int = 0, seed: int = 0, group=None, render_path: str = "auto", distributed: bool = True):
     """One iteration of the loop body of SplatLoc.map (train_gaussians.py:188-267) on the window `viewpoints` (the
     caller has drawn it: `all_viewpoint_stack[torch.randperm(len(...))[:window_size]]`, :195), with the device-side
     pieces of this package, single- or multi-GPU:
@@ -233,7 +238,9 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
     from .densify import densify_and_prune, reset_opacity_nonvisible
     from .frame_parallel import reduce_step, shard_views
     from .losses import isotropic_loss, mapping_loss_window
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    # `distributed=False`: this rank reconstructs its OWN scene although a process group exists (one scene per GPU,
+    # /root/reference/replica.sh; bench.py --stage scene --replicas): no collective at all
+    multi = distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank = dist.get_rank(group) if multi else 0
     world = dist.get_world_size(group) if multi else 1
     primitive_reg = bool(config["Training"].get("primitive_reg", True))
@@ -290,7 +297,7 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
                 add_densification_stats_window(grads2d, radii, inc[0], inc[1], gaussians.max_radii2D)
             g_out, inc_out, info = reduce_step([p.grad for p in live], sum_extras=[inc[0], inc[1]],
                                                max_extras=[gaussians.max_radii2D] + ([seen] if seen is not None else []),
-                                               group=group)
+                                               group=group, mode=REDUCE_MODE)
             for p, g in zip(live, g_out):
                 p.grad = g          # views of the reduced buffer: no copy back
             gaussians.xyz_gradient_accum += inc_out[0]

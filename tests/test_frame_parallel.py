@@ -129,7 +129,7 @@ def _reduce_step_worker(rank, world, port, out):
             max_r = torch.full((P,), float(rank * 7))
             seen = torch.zeros(P)
             seen[rank::2] = 1.0
-            reduce_step(grads, [sp["tail"][0], sp["tail"][1]], [max_r], None)       # first call: + the one-off layout checks
+            reduce_step(grads, [sp["tail"][0], sp["tail"][1]], [max_r], None)
             n_first = len(calls)
             calls.clear()
             for k in ("m3", "op", "col", "sca", "rot"):
@@ -138,7 +138,9 @@ def _reduce_step_worker(rank, world, port, out):
             sp["tail"][1].fill_(1.0 if rank == 0 else 0.0)
             g, e, info = reduce_step(grads, [sp["tail"][0], sp["tail"][1]], [max_r, seen], None)
             assert info["collectives"] == 2 and info["sum_path"] == "in-place span", info
-            assert len(calls) == 3 and n_first >= 3, (calls, n_first)   # SUM + MAX (+ one layout check: [max_r | seen] is a new length)
+            # SUM + MAX + the 32-byte length header, on EVERY call (a rank that skipped the header because it had seen the
+            # length before would pair its SUM with a diverging peer's header: round-4 advisor finding)
+            assert len(calls) == 3 and n_first == 3 and info["header_collectives"] == 1, (calls, n_first)
             assert all(a is b for a, b in zip(g, grads))
             assert all(torch.all(t == 2.0) for t in g) and torch.all(e[0] == 0.5) and torch.all(e[1] == 1.0)
             assert torch.all(max_r == 7.0) and torch.all(seen == 1.0)
@@ -154,10 +156,17 @@ def _reduce_step_worker(rank, world, port, out):
             assert all(torch.all(t == 3.0) for t in g2 if t.numel()) and g2[2].shape == (P, 0, 3)
             assert g2[1].shape == (P, 1, 3) and torch.all(e2[0] == 1.0)
             assert g2[0].untyped_storage().data_ptr() == g2[3].untyped_storage().data_ptr()
-            # ranks that disagree on the layout are refused, not summed
-            bad = [torch.zeros(10 + rank)]
+            # the same exchange as reduce-scatter + all-gather (gloo has no reduce-scatter: emulated by the all-reduce; the
+            # padding / packing of a length that is not a multiple of the world size is what this covers)
+            odd = [torch.full((7, 3), float(rank + 1)), torch.full((4,), float(rank + 1))]      # 25 elements, world 2
+            g3, _, info3 = reduce_step(odd, [], [max_r], None, mode="rs_ag")
+            assert info3["mode"] == "rs_ag" and info3["sum_path"] == "packed" and info3["sum_bytes"] == 4 * 26
+            assert all(torch.all(t == 3.0) for t in g3) and g3[0].shape == (7, 3)
+            # ranks that disagree on the layout are refused, not summed — also when one of them has reduced "its" length
+            # before (rank 0 repeats the length of the very first call, rank 1 brings a new one)
+            bad = list(grads) + [sp["tail"][0], sp["tail"][1]] if rank == 0 else [torch.zeros(11)]
             try:
-                reduce_step(bad, [], [], None)
+                reduce_step(bad, [], [max_r], None)
                 raised = False
             except RuntimeError as ex:
                 raised = "disagree" in str(ex)

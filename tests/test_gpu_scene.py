@@ -134,3 +134,40 @@ def test_replicas_run_the_whole_schedule_bit_identically():
     out = json.loads(lines[0])
     assert out["world"] == 2 and out["identical"], out
     assert out["rows_final"] > out["rows_after_keyframe"][0] and out["densifications"] >= 1
+
+
+def _bench_scene_two_ranks(extra):
+    env = dict(os.environ, SPLATLOC_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--stage", "scene", "--gpus", "2", "--keyframes", "6", "--refine", "40",
+           "--truth", "20000"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-2500:])
+    return json.loads(lines[0])
+
+
+def test_bench_scene_replicas_one_scene_per_rank():
+    """BASELINE config 5 as /root/reference/replica.sh:1-6 has it — independent scenes — on 2 ranks (gloo, both on cuda:0):
+    `bench.py --stage scene --gpus 2 --replicas` runs one do_recon per rank with NO collective on the data path (a process
+    group exists, for the launch and the report only); the scenes differ (seed = rank); value = 2 scenes / the slower rank."""
+    out = _bench_scene_two_ranks(["--replicas"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["multi_gpu_mode"] == "replicas"
+    assert out["config"]["scenes"] == 2 and out["config"]["collectives_on_the_data_path"] == 0
+    pr = out["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["rows_final"] > 0 and r["mean_psnr"] > 15.0 for r in pr)
+    assert pr[0]["rows_final"] != pr[1]["rows_final"]          # two different rooms
+    t_max = max(r["recon_s"] for r in pr)
+    assert abs(out["value"] - 2 * 3600.0 / t_max) <= 1e-3 * out["value"] + 1e-3
+
+
+@pytest.mark.parametrize("reduce", ["ring", "rs_ag"])
+def test_bench_scene_frame_parallel(reduce):
+    """The same schedule as ONE scene reconstructed by 2 ranks (views of every map window dealt to the ranks; gloo: rs_ag is
+    emulated by the all-reduce, the padding / packing path is real)."""
+    out = _bench_scene_two_ranks(["--reduce", reduce])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["multi_gpu_mode"] == "frame-parallel"
+    assert out["config"]["scenes"] == 1 and out["config"]["reduce"] == reduce
+    pr = out["per_rank"]
+    assert pr[0]["rows_final"] == pr[1]["rows_final"] and abs(pr[0]["mean_psnr"] - pr[1]["mean_psnr"]) < 1e-6   # replicas
+    assert out["eval"]["mean_psnr"] > 15.0

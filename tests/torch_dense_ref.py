@@ -55,8 +55,11 @@ def quat_to_rot(q):
 
 def render_dense(H, W, tanfovx, tanfovy, bg, means3D, opacities, viewmatrix, projmatrix, campos=None,
                  colors_precomp=None, shs=None, sh_degree=0, scales=None, rotations=None,
-                 cov3D_precomp=None, scale_modifier=1.0, means2D_probe=None):
+                 cov3D_precomp=None, scale_modifier=1.0, means2D_probe=None, rows=None):
     """Returns (color [C,H,W], depth [1,H,W], alpha [1,H,W], radii [P]).
+
+    rows = (y0, y1): only the image rows [y0, y1) of the H x W frame are composited (outputs [C, y1-y0, W], ...): the
+    bounded sample bench.py's CPU leg times at S0, where the full frame is 3e9 (pixel, Gaussian) pairs.
 
     means2D_probe: optional [P,2] zero tensor added to the NDC centre, so that its .grad is
     the dL/dmeans2D the extension reports.
@@ -126,7 +129,8 @@ def render_dense(H, W, tanfovx, tanfovy, bg, means3D, opacities, viewmatrix, pro
     keyd = torch.where(ok, tz.detach().to(torch.float32).double(), torch.full_like(tz, float("inf")).double())
     order = torch.argsort(keyd, stable=True)
     order = order[ok[order]]
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=dt, device=dev), torch.arange(W, dtype=dt, device=dev), indexing="ij")
+    y0, y1 = (0, H) if rows is None else (int(rows[0]), int(rows[1]))
+    ys, xs = torch.meshgrid(torch.arange(y0, y1, dtype=dt, device=dev), torch.arange(W, dtype=dt, device=dev), indexing="ij")
     pxf, pyf = xs.reshape(-1), ys.reshape(-1)                 # [N]
     tpx, tpy = torch.div(pxf, TILE, rounding_mode="floor"), torch.div(pyf, TILE, rounding_mode="floor")
     o = order
@@ -149,11 +153,12 @@ def render_dense(H, W, tanfovx, tanfovy, bg, means3D, opacities, viewmatrix, pro
     Tincl = torch.cumprod(one_m, dim=1)
     Texcl = torch.cat([torch.ones(Tincl.shape[0], 1, dtype=dt, device=dev), Tincl[:, :-1]], dim=1)
     w = alpha * Texcl                                            # [N,G]
-    Tfin = Tincl[:, -1] if Tincl.shape[1] else torch.ones(H * W, dtype=dt, device=dev)
+    Tfin = Tincl[:, -1] if Tincl.shape[1] else torch.ones((y1 - y0) * W, dtype=dt, device=dev)
     bgf = torch.zeros(Cn, dtype=dt, device=dev)
     nb = min(Cn, bg.numel())
     bgf[:nb] = bg.to(device=dev, dtype=dt)[:nb]
     color = (w @ feat[o]) + Tfin[:, None] * bgf[None]
     depth = w @ tz[o]
     alpha_img = 1.0 - Tfin
-    return (color.t().reshape(Cn, H, W), depth.reshape(1, H, W), alpha_img.reshape(1, H, W), radii)
+    Hb = y1 - y0
+    return (color.t().reshape(Cn, Hb, W), depth.reshape(1, Hb, W), alpha_img.reshape(1, Hb, W), radii)
