@@ -1248,8 +1248,11 @@ def main():
         valu = prof.get("valu.json")
         roofline_valu = None
         clk = None
-        cpath = os.path.join(ROOT, "profiles", "clocks.json")
-        if os.path.exists(cpath):
+        import glob as _glob
+        # the newest clock summary of a builder run (profiles/rNN_clocks.json, tools/clock_trace.py): ONE copy, no "clocks.json" twin
+        cfiles = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_clocks.json")))
+        cpath = cfiles[-1] if cfiles else ""
+        if cpath:
             try:
                 cj = json.load(open(cpath))
                 a = cj.get("amdsmi_library_20hz") or {}
@@ -1266,7 +1269,7 @@ def main():
             roofline_valu = {"source": "profiles/valu.json (builder rocprofv3 SQ-counter run, same workload and launch mode)",
                              "bound": "valu-issue", "kernels": {},
                              # measured clock of a >= 10-s loop of this workload (tools/clock_trace.py: amdsmi at ~20 Hz from a separate
-                             # process; a replay of profiles/clocks.json, not live): the SQ fractions below are fractions of ACHIEVED
+                             # process; a replay of the newest profiles/rNN_clocks.json, not live): the SQ fractions below are fractions of ACHIEVED
                              # cycles (kernel cycles from GRBM_GUI_ACTIVE); `..._at_peak_clock` re-states them against 2.4 GHz
                              "clock": clk, "peak_sclk_mhz": 2400}
             for k, c in valu.items():

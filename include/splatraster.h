@@ -557,6 +557,11 @@ int splatraster_debug_set_payload_stream_min(int64_t instances);
  * binned front end whenever the shape allows (at most 16 384 tiles per view).  Both produce bit-identical point lists,
  * ranges and payloads.  Must not change between the geometry and the render stage of a forward. */
 int splatraster_debug_set_front_end(int mode);
+/* A/B / test hook of the binned front end: the per-tile sort launch exists for lists of up to 2048 keys (128 threads, every
+ * tile of a 640x480 frame resident at once) and of up to 4096 (256 threads); by default the library follows a hint the kernel
+ * raises when it meets a list beyond 2048 keys (longer lists than the chosen launch holds go to its work-list launch either
+ * way).  2048 / 4096 force an instantiation, any other value restores the default.  Results never depend on it. */
+int splatraster_debug_set_tile_sort_cap(int keys);
 int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
 /* test hook: fills the LDS of every compute unit with `pattern` (e.g. a NaN's bits): enough workgroups of 64 KB each to cover
  * the whole array.  The compositing kernels read rows of their LDS staging buffers that a round did not write (the absent second

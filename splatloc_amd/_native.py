@@ -100,6 +100,7 @@ SYMBOLS = {
     "splatraster_debug_set_small_panel_max_waves": (C.c_int, [C.c_int]),
     "splatraster_debug_set_split_max_waves": (C.c_int, [C.c_int]),
     "splatraster_debug_set_front_end": (C.c_int, [C.c_int]),
+    "splatraster_debug_set_tile_sort_cap": (C.c_int, [C.c_int]),
     "splatraster_debug_set_payload_stream_min": (C.c_int, [C.c_int64]),
     "splatraster_mark_visible": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_get_geometry_layout": (C.c_int, [_i32, C.POINTER(GeometryLayout)]),
@@ -184,6 +185,8 @@ def load(build_if_missing: bool = True):
         lib.splatraster_debug_set_split_max_waves(int(os.environ["SPLATRASTER_SPLIT_MAX_WAVES"]))
     if os.environ.get("SPLATRASTER_FRONT_END"):   # -1 auto, 0 radix sorts, 1 binned whenever the shape allows
         lib.splatraster_debug_set_front_end(int(os.environ["SPLATRASTER_FRONT_END"]))
+    if os.environ.get("SPLATRASTER_TILE_SORT_CAP"):
+        lib.splatraster_debug_set_tile_sort_cap(int(os.environ["SPLATRASTER_TILE_SORT_CAP"]))
     if os.environ.get("SPLATRASTER_SMALL_PANEL_MAX_WAVES"):
         lib.splatraster_debug_set_small_panel_max_waves(int(os.environ["SPLATRASTER_SMALL_PANEL_MAX_WAVES"]))
     return lib

@@ -12,23 +12,26 @@
 //   3. bin_walk_kernel<.., true>   the same walk; an LDS atomic on the (tile, chunk) cursor hands out the slot; writes the 64-bit
 //                          key (depth bits << 32 | row).  The order inside a (tile, chunk) piece is whatever the LDS atomics
 //                          made it — the next kernel fixes it
-//   4. bin_sort_tile_kernel  one block per (view, tile), ceil(n / 1024) of its four waves at work: the list (up to 4096
-//                          keys) is sorted IN REGISTERS by a bitonic network, at most 16 keys per lane — distances below the
-//                          keys-per-lane are compare-exchanges between a lane's own registers, the six distances between lanes
-//                          are DPP / permlane exchanges, only the one to three distances across waves of a list beyond 1024
-//                          keys go through LDS — and written out as the payload the compositing kernels stream (irec, ipack)
-//                          together with point_list, tile_list and the tile's range.
-//                          (History, 1200 lists of ~1000 keys, 640x480: the whole network in LDS 57 us, LDS-bandwidth-bound;
-//                          256 threads x 4 keys in registers 48 - 60 us, VALU-issue-bound at 3 700 instructions per wave x
-//                          4 waves — a wave64 VALU instruction occupies its SIMD for 4 cycles; ONE wave x 32 keys per lane
-//                          73 us: 10 500 instructions per wave, a power-of-two network pads 1030 keys to 2048; this form:
-//                          profiles/r05_ab_probes.txt.)
+//   4. bin_sort_tile_kernel  one block per (view, tile): the list is loaded into LDS and sorted by a register-blocked
+//                          bitonic network whose compare-exchange is v_min_f64 / v_max_f64 on the keys read as doubles (see
+//                          "the first sort launch" below), one thread per 16 keys, then written out as the payload the
+//                          compositing kernels stream (irec, ipack) together with point_list, tile_list and the tile's range.
+//                          Two instantiations: lists up to 2048 keys (128 threads, 17 KB of LDS: every tile of a 640x480
+//                          frame resident at once) and up to 4096 (256 threads, 35 KB); the host picks by a hint the kernel
+//                          itself raises in host-mapped memory when it meets a list beyond 2048 (a reconstructed room has a
+//                          few dozen such tiles, the uniform S* clouds none): a hint, never a correctness matter.
+//                          (History of this kernel, 1200 lists of ~1000 keys: the whole network in LDS with integer
+//                          compare-exchanges 57 us; 256 threads x 4 keys in registers, DPP exchanges 48 - 60 us (VALU-issue-bound:
+//                          3 700 instructions per wave, a wave64 VALU instruction occupies its SIMD for 4 cycles); one wave x
+//                          32 keys per lane 73 us; this form 39 us, of which ~20 us are the 92 MB of payload traffic.)
 // (depth bits, row) is unique inside a tile, so the sorted list is THE (tile, depth, index) order of the lineage's stable
 // 64-bit sort — bit-identical point lists and ranges to the radix front end (tests/test_gpu_binsort.py runs both).
-// Lists of more than 4096 entries go to a work list served by a second launch (1024 threads x 8 or 16 keys in registers;
-// beyond 16 384 keys a normalised network runs on the global buffer: slow, correct).
+// Lists beyond the first launch's capacity go to a work list served by a second launch (1024 threads x 4 ... 16 keys in
+// registers, DPP / LDS exchanges; beyond 16 384 keys a normalised network runs on the global buffer: slow, correct).
 //
 // Compiled with -ffp-contract=off like preprocess.hip / binning.hip: the rect arithmetic must round like preprocess's.
+#include <mutex>
+
 #include "composite_common.h"
 #ifdef SR_BIN_TIMING   // tools/micro/tilesort_bench.hip: s_memtime stamps of every phase of a block
 namespace sr { __device__ unsigned long long* g_bin_dbg = nullptr; }
@@ -70,7 +73,12 @@ __device__ __forceinline__ void wave_order()
 // grid (chunks, V), 1024 threads, ROWS rows of the view per thread; dynamic LDS: tiles words.  16 waves per block and at most
 // a few dependent steps per thread: the walk is a chain of LDS atomic round trips (the returned slot addresses the store), so
 // it is latency that more resident waves hide, not bandwidth (4 waves x 8 rows per block: 13 / 21 us for count / scatter at
-// 500k rows, 640x480; 16 waves x 2 rows: see profiles/r05_ab_probes.txt).
+// 500k rows, 640x480; 16 waves x 2 rows: 9 / 16 us).
+// A rect of up to BIN_INLINE_TILES tiles is walked by the thread that owns the row; a larger one is queued in LDS and walked
+// by a whole WAVE (lanes stride over its tiles) after the barrier: on a reconstructed room — walls seen at grazing angles,
+// Gaussians over hundreds of tiles — the thread-serial walk of such a rect was the block's critical path (33 / 48 us for
+// count / scatter on 196k rows where the uniform 500k-row cloud took 9 / 16 us).
+constexpr int BIN_INLINE_TILES = 8, BIN_QUEUE = 1024;
 template <int ROWS, bool SCATTER>
 __global__ void __launch_bounds__(BIN_THREADS)
 bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __restrict__ rec,
@@ -78,9 +86,13 @@ bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __re
                 uint64_t* __restrict__ keys /*SCATTER: [R]*/, uint32_t* __restrict__ big_count /*COUNT: zeroed here*/)
 {
     extern __shared__ uint32_t s_bin[];
+    __shared__ uint64_t s_qkey[BIN_QUEUE];
+    __shared__ uint32_t s_qrect[BIN_QUEUE];   // x0 | y0 << 8 | width << 16 | height << 24 (at most 255 tiles a side: BIN_MAX_TILES)
+    __shared__ uint32_t s_qn;
     const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
     uint32_t* col = table + (size_t)v * tiles * nchunk + chunk;
     if (!SCATTER && big_count && t == 0 && chunk == 0 && v == 0) *big_count = 0u;
+    if (t == 0) s_qn = 0u;
     const int i0 = chunk * (BIN_THREADS * ROWS);
     float4 p[ROWS];   // every row's record is requested before the first one is used
 #pragma unroll
@@ -96,11 +108,35 @@ bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __re
         const uint32_t g = (uint32_t)v * (uint32_t)P + (uint32_t)(i0 + k * BIN_THREADS + t);
         const Rect r = rect_of(p[k], gx, gy);
         const uint64_t key = ((uint64_t)__float_as_uint(p[k].z) << 32) | g;
+        const int w = r.x1 - r.x0, h = r.y1 - r.y0;
+        if (w * h > BIN_INLINE_TILES) {
+            const uint32_t q = atomicAdd(&s_qn, 1u);
+            if (q < (uint32_t)BIN_QUEUE) {
+                s_qkey[q] = key;
+                s_qrect[q] = (uint32_t)r.x0 | ((uint32_t)r.y0 << 8) | ((uint32_t)w << 16) | ((uint32_t)h << 24);
+                continue;
+            }   // (queue full: walked here)
+        }
         for (int y = r.y0; y < r.y1; ++y)
             for (int x = r.x0; x < r.x1; ++x) {
                 const uint32_t slot = atomicAdd(&s_bin[y * gx + x], 1u);
                 if (SCATTER) keys[slot] = key;
             }
+    }
+    __syncthreads();
+    {   // the queued rects: one wave each, lanes stride over the tiles
+        const uint32_t nq = min(s_qn, (uint32_t)BIN_QUEUE);
+        const int lane = t & (WAVE - 1);
+        for (uint32_t q = (uint32_t)t / WAVE; q < nq; q += BIN_THREADS / WAVE) {
+            const uint64_t key = s_qkey[q];
+            const uint32_t rc = s_qrect[q];
+            const int x0 = (int)(rc & 255u), y0 = (int)((rc >> 8) & 255u), w = (int)((rc >> 16) & 255u), h = (int)(rc >> 24);
+            for (int e = lane; e < w * h; e += WAVE) {
+                const int yy = e / w, xx = e - yy * w;
+                const uint32_t slot = atomicAdd(&s_bin[(y0 + yy) * gx + x0 + xx], 1u);
+                if (SCATTER) keys[slot] = key;
+            }
+        }
     }
     if (!SCATTER) {
         __syncthreads();
@@ -504,14 +540,18 @@ __device__ void sort_lds_f64(double* s, uint32_t M)
     pass_sync<MULTI_WAVE>();
 }
 
-// First sort launch: one 128-thread block per global tile; a list of up to 1024 keys is its first wave's alone (the other
-// leaves at once), up to 2048 both waves'.  Longer lists are appended to the work list.
-__global__ void __launch_bounds__(128)
+// host-mapped word (one per device): raised by the tile kernel when it meets a list beyond BIN_SORT_TILE_NARROW keys
+__device__ uint32_t* g_bin_wide_sink = nullptr;
+
+// First sort launch: one block of CAP / 16 threads per global tile, of which ceil(n / 1024) waves work on the list (the
+// others leave at once): a list of up to 1024 keys is one wave's alone.  Lists longer than CAP are appended to the work list.
+template <int CAP>
+__global__ void __launch_bounds__(CAP / 16)
 bin_sort_tile_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* __restrict__ table /*exclusive prefix*/,
                      const uint32_t* __restrict__ total /*[0]: R*/, const uint64_t* __restrict__ keys,
                      const float4* __restrict__ rec, BinView b, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list)
 {
-    __shared__ double s_keys[BIN_SORT_TILE + BIN_SORT_TILE / 16];
+    __shared__ double s_keys[CAP + CAP / 16];
     const uint32_t gt = blockIdx.x, t = threadIdx.x;
     uint32_t start, n;
     SR_STAMP(0);
@@ -525,14 +565,18 @@ bin_sort_tile_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* 
     if (t == 0) {   // empty tiles keep [0, 0), like the radix front end's zeroed table
         b.ranges[2 * gt] = n ? start : 0u;
         b.ranges[2 * gt + 1] = n ? start + n : 0u;
-        if (n > (uint32_t)BIN_SORT_TILE) big_list[atomicAdd(big_count, 1u)] = gt;
+        if (n > (uint32_t)CAP) big_list[atomicAdd(big_count, 1u)] = gt;
+        if (n > (uint32_t)BIN_SORT_TILE_NARROW) {   // tell the host that the wide instantiation pays on this scene
+            uint32_t* sink = g_bin_wide_sink;
+            if (sink) __hip_atomic_store(sink, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-    if (n == 0 || n > (uint32_t)BIN_SORT_TILE) return;
-    const bool two = n > 1024u;
-    if (!two && t >= 64u) return;
+    if (n == 0 || n > (uint32_t)CAP) return;
     uint32_t M = 4;
     while ((1u << M) < n) ++M;
-    const uint32_t N = 1u << M, T = two ? 128u : 64u;
+    const uint32_t N = 1u << M, T = N <= 1024u ? 64u : N / 16u;   // working threads: one per 16 keys, at least a wave
+    const bool two = T > 64u;
+    if (t >= T) return;
     const uint64_t* src = keys + start;
     uint64_t* s_bits = reinterpret_cast<uint64_t*>(s_keys);
     for (uint32_t i0 = t; i0 < N; i0 += 8 * T) {   // (N is a multiple of 16; eight loads in flight per lane)
@@ -552,8 +596,9 @@ bin_sort_tile_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* 
     if (two) { __syncthreads(); sort_lds_f64<true>(s_keys, M); } else { wave_order(); sort_lds_f64<false>(s_keys, M); }
     SR_STAMP(3);
     auto row_at = [&](uint32_t q) { return (uint32_t)s_bits[pidx(q)] & 0xFFFFFFu; };
-    if (two) write_tile<128>(row_at, n, start, gt, gx, tiles, rec, b);
-    else write_tile<64>(row_at, n, start, gt, gx, tiles, rec, b);
+    if (T == 64u) write_tile<64>(row_at, n, start, gt, gx, tiles, rec, b);
+    else if (T == 128u || CAP <= 2048) write_tile<128>(row_at, n, start, gt, gx, tiles, rec, b);
+    else write_tile<256>(row_at, n, start, gt, gx, tiles, rec, b);
 #ifdef SR_BIN_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -605,9 +650,10 @@ size_t bin_scratch_bytes(int32_t P, int32_t V, int tiles)
     return align_up(entries * sizeof(uint32_t), 256) + scan_tmp_bytes((int64_t)entries);
 }
 
-bool use_bins(int32_t P, int32_t V, int tiles, size_t scratch_bytes)
+bool use_bins(int32_t P, int32_t V, int gx, int gy, size_t scratch_bytes)
 {
-    if (g_bin_mode == 0 || P <= 0 || tiles <= 0 || tiles > BIN_MAX_TILES) return false;
+    const int tiles = gx * gy;
+    if (g_bin_mode == 0 || P <= 0 || tiles <= 0 || tiles > BIN_MAX_TILES || gx > 255 || gy > 255) return false;
     if (bin_table_entries(P, V, tiles) >= ((size_t)1 << 31)) return false;
     if (bin_scratch_bytes(P, V, tiles) > scratch_bytes) return false;
     if (g_bin_mode == 1) return true;
@@ -633,6 +679,27 @@ int launch_bin_count(const splatraster_settings& s, int32_t P, int32_t V, const 
     return exclusive_scan_u32((int64_t)bin_table_entries(P, V, tiles), table, g.total, scan_tmp, stream, true);
 }
 
+// which instantiation of the tile kernel: 0 = follow the hint (default), else BIN_SORT_TILE_NARROW / BIN_SORT_TILE_WIDE forced
+static int g_tile_cap = 0;
+void set_bin_tile_cap(int cap) { g_tile_cap = (cap == BIN_SORT_TILE_NARROW || cap == BIN_SORT_TILE_WIDE) ? cap : 0; }
+static uint32_t* g_wide_host[64] = {};     // pinned, host-mapped hint word per device
+static int g_wide_left[64] = {};           // frames the wide instantiation stays selected after the last raised hint
+static std::mutex g_wide_mu;
+
+static int wide_hint_init(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_wide_mu);
+    if (g_wide_host[dev]) return SPLATRASTER_OK;
+    uint32_t* h = nullptr;
+    SR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped | hipHostMallocPortable));
+    *h = 0u;
+    uint32_t* d = nullptr;
+    SR_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0));
+    SR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bin_wide_sink), &d, sizeof(d)));
+    g_wide_host[dev] = h;
+    return SPLATRASTER_OK;
+}
+
 // render stage: scatter the keys, sort every tile's list, write the payload
 int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g,
                             const uint32_t* table, const BinView& b, uint64_t* keys, uint32_t* big_list, hipStream_t stream)
@@ -651,8 +718,23 @@ int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V,
                            const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr);
     SR_LAUNCH_CHECK();
     uint32_t* big_count = g.total + 2;
-    hipLaunchKernelGGL(bin_sort_tile_kernel, dim3((unsigned)gtiles), dim3(128), 0, stream, gtiles, tiles, gx, nchunk, table,
-                       g.total, keys, g.rec, b, big_count, big_list);
+    int dev = 0;
+    SR_HIP_CHECK(hipGetDevice(&dev));
+    bool wide = g_tile_cap == BIN_SORT_TILE_WIDE;
+    if (dev >= 0 && dev < 64) {
+        int st = wide_hint_init(dev);
+        if (st) return st;
+        volatile uint32_t* h = g_wide_host[dev];
+        if (*h) { *h = 0u; g_wide_left[dev] = BIN_WIDE_FRAMES; }      // (benign race between host threads: a hint)
+        if (g_tile_cap == 0) wide = g_wide_left[dev] > 0;
+        if (g_wide_left[dev] > 0) --g_wide_left[dev];
+    }
+    if (wide)
+        hipLaunchKernelGGL(bin_sort_tile_kernel<BIN_SORT_TILE_WIDE>, dim3((unsigned)gtiles), dim3(BIN_SORT_TILE_WIDE / 16), 0, stream,
+                           gtiles, tiles, gx, nchunk, table, g.total, keys, g.rec, b, big_count, big_list);
+    else
+        hipLaunchKernelGGL(bin_sort_tile_kernel<BIN_SORT_TILE_NARROW>, dim3((unsigned)gtiles), dim3(BIN_SORT_TILE_NARROW / 16), 0,
+                           stream, gtiles, tiles, gx, nchunk, table, g.total, keys, g.rec, b, big_count, big_list);
     SR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bin_sort_big_kernel, dim3(BIN_BIG_BLOCKS), dim3(1024), 0, stream, gtiles, tiles, gx, nchunk, table,
                        g.total, keys, g.rec, b, big_count, big_list);

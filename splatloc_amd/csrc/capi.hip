@@ -351,10 +351,10 @@ static WinCams make_cams(int32_t V, const splatraster_window_view* views)
 struct BinScratch { bool on; uint32_t* table; void* scan_tmp; int64_t entries; };
 static BinScratch bin_scratch(const splatraster_settings& s, int32_t P, int32_t V, void* geometry)
 {
-    const int tiles = ((s.image_width + TILE - 1) / TILE) * ((s.image_height + TILE - 1) / TILE);
+    const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE, tiles = gx * gy;
     const GeomLayout L = geom_layout(P, V);
     BinScratch b{};
-    b.on = geometry && use_bins(P, V, tiles, L.total - L.sort_keys);
+    b.on = geometry && use_bins(P, V, gx, gy, L.total - L.sort_keys);
     if (!b.on) return b;
     char* base = reinterpret_cast<char*>(geometry);
     b.entries = (int64_t)bin_table_entries(P, V, tiles);
@@ -737,6 +737,12 @@ int splatraster_debug_set_payload_stream_min(int64_t instances)
 int splatraster_debug_set_front_end(int mode)
 {
     set_bin_mode(mode);
+    return SPLATRASTER_OK;
+}
+
+int splatraster_debug_set_tile_sort_cap(int keys)
+{
+    set_bin_tile_cap(keys);
     return SPLATRASTER_OK;
 }
 

@@ -175,13 +175,15 @@ constexpr int BIN_MAX_TILES = 16384;        // tiles per view: the LDS histogram
 #define SR_BIN_AUTO_MAX_TILES 6144          // (view, tile) lists up to which the binned front end is the default
 #endif
 constexpr int BIN_AUTO_MAX_TILES = SR_BIN_AUTO_MAX_TILES;
-constexpr int BIN_SORT_TILE = 2048;         // longest list of the per-tile launch (2 waves x 16 keys per lane, in 17 KB of LDS)
+constexpr int BIN_SORT_TILE_NARROW = 2048, BIN_SORT_TILE_WIDE = 4096;   // longest list of the per-tile launch's two instantiations
+constexpr int BIN_WIDE_FRAMES = 64;         // frames the wide instantiation stays selected after a list beyond 2048 was seen
+void set_bin_tile_cap(int cap);             // test / A-B hook: 2048 or 4096 forces an instantiation, anything else: follow the hint
 constexpr int BIN_EX_REGS = 4;              // keys per thread that cross waves through LDS at a time
 constexpr int BIN_SORT_BIG = 16384, BIN_BIG_BLOCKS = 32; // the work-list launch for longer lists (keys in registers of 1024 threads, blocks)
 void set_bin_mode(int mode);   // -1 auto, 0 radix front end always, 1 binned whenever the shape allows
 size_t bin_table_entries(int32_t P, int32_t V, int tiles);
 size_t bin_scratch_bytes(int32_t P, int32_t V, int tiles);
-bool use_bins(int32_t P, int32_t V, int tiles, size_t scratch_bytes);
+bool use_bins(int32_t P, int32_t V, int gx, int gy /*tiles per row / column of a view*/, size_t scratch_bytes);
 int launch_bin_count(const splatraster_settings& s, int32_t P, int32_t V, const GeomView& g, uint32_t* table, void* scan_tmp,
                      hipStream_t stream);
 int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g,

@@ -40,16 +40,10 @@
 #define SR_BWD_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2, 5 cameras: 2: 0.947, 3: 0.914 ms)
 #endif
 
-#ifndef SR_BWD_LDSDMA
-#define SR_BWD_LDSDMA 0  // 1 = stage the feature rows with LDS-DMA loads (A/B in DESIGN.md)
-#endif
 #ifndef SR_BWD_MINW
 #define SR_BWD_MINW 4  // waves per SIMD the register allocator must allow (A/B on S2: 1.035 vs 1.07 ms at 3)
 #endif
 
-#ifndef SR_BWD_SKIP_BRANCH
-#define SR_BWD_SKIP_BRANCH 0  // 1 = skip a candidate pair that no pixel of the quadrant hits (A/B: slower, more VGPRs)
-#endif
 #ifndef SR_BWD_DOT_CHAINS
 #define SR_BWD_DOT_CHAINS 2  // (>= 1) independent accumulators of the 4x4x1 MFMA dot product (A/B: 1: 0.950, 2: 0.928, 3: 0.944 (other box), 6 spills)
 #endif
@@ -65,12 +59,6 @@
 #ifndef SR_BWD_TM
 #define SR_BWD_TM 1   // 1 = transposed moment reduction (small-layout panel variant): E = G dL/dalpha parked in an 8-column LDS panel, reduced by lane = (Gaussian, pixel column)
 #endif
-#ifndef SR_BWD_TM_WIDE
-#define SR_BWD_TM_WIDE 0  // 1 = also in the NC >= 32 kernels (A/B on S2: LOSES — the E panel's 2.4 KB and the registers cost a wave per SIMD)
-#endif
-#ifndef SR_BWD_NB3
-#define SR_BWD_NB3 0  // 1 = channels beyond the first 32 (and the depth weight) as a third 16-column block of the flush (A/B on S2: loses)
-#endif
 #ifndef SR_BWD_MINW_TM
 #define SR_BWD_MINW_TM 3  // waves per SIMD of the NC >= 32 kernel WITH the E panel (12.6 KB of LDS per wave: 12 workgroups per CU)
 #endif
@@ -80,18 +68,9 @@
 
 namespace sr {
 
-#ifdef SR_TRACE_WAVES  // debug build for tools/wave_trace.py: per-workgroup start/end (100 MHz clock)
-__device__ unsigned long long g_trace_bwd[2 * 40960];
-#endif
 
-#ifdef SR_BWD_PROFILE
-__device__ unsigned long long g_bwd_prof[12];
-#define BP_T(v) const unsigned long long v = __builtin_readcyclecounter()
-#define BP_ADD(i, x) bprof[i] += (x)
-#else
 #define BP_T(v)
 #define BP_ADD(i, x)
-#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -108,17 +87,16 @@ struct BwdCfg {
     static constexpr bool MFMA = NC >= 32 || SMALLP;
     // NC in (32, 47]: the channels beyond 32 and the depth weight are a THIRD 16-column block of the flush (16 more
     // MFMAs per 16 Gaussians) instead of 4 of the 10 butterfly values per Gaussian
-    static constexpr bool B3 = SR_BWD_NB3 && NC > 32 && NC < 48;
-    static constexpr int NM = NC >= 32 ? (B3 ? NC : 32) : (SMALLP ? NC : 0);   // channels reduced on the matrix pipe
-    static constexpr int NB = NC >= 32 ? (B3 ? 3 : 2) : 1;         // 16-column blocks of the contraction
-    static constexpr bool XD = (SMALLP || B3) && AUX;              // column NC of the blocks = the depth weight
+    static constexpr int NM = NC >= 32 ? 32 : (SMALLP ? NC : 0);   // channels reduced on the matrix pipe
+    static constexpr int NB = NC >= 32 ? 2 : 1;         // 16-column blocks of the contraction
+    static constexpr bool XD = SMALLP && AUX;              // column NC of the blocks = the depth weight
     static constexpr int NV = NC - NM;         // channels reduced with the packed butterfly
     // TM (small-layout panel variant; measured on the reference layout, 5 views: 0.791 -> 0.762 ms): the six geometric
     // moments leave the butterfly too.  E = G dL/dalpha is parked in an
     // 8-column LDS panel [64 pix][8 Gaussians]; every 8 Gaussians lane (g = l & 7, i = l >> 3) sums its Gaussian over
     // pixel column i (8 reads), forms the moments with ITS Gaussian's mean, and three swap stages fold the 8 columns:
     // ~8 VALU per Gaussian instead of 6 moment products + 13 butterfly instructions.
-    static constexpr bool TM = SR_BWD_TM && (SMALLP || (SR_BWD_TM_WIDE && MFMA));
+    static constexpr bool TM = SR_BWD_TM && SMALLP;
     static constexpr int EG = 8;               // Gaussians per E-panel reduction
     static constexpr int ES = 9;               // LDS row stride of the E panel [64 pix][EG]
     // AUX = false: no view of the launch has a depth / alpha gradient (color_refinement, train_gaussians.py:283-285):
@@ -209,19 +187,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     __shared__ float s_e[TM ? WAVE * ES : 1];     // E panel [64 pix][EG]: column c belongs to weight-panel slot e0 + c
     __shared__ float2 s_emean[TM ? GROUP : 1];    // projected mean of every parked Gaussian
 
-#ifdef SR_TRACE_WAVES
-    struct TraceEnd {
-        unsigned long long t0;
-        unsigned long long* buf;
-        __device__ ~TraceEnd()
-        {
-            if (threadIdx.x == 0 && blockIdx.x < 40960) {
-                buf[2 * blockIdx.x] = t0;
-                buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-            }
-        }
-    } trace_end{__builtin_amdgcn_s_memrealtime(), g_trace_bwd};
-#endif
     int gtile, quad;   // global tile = view * tiles + tile: the grid covers the V views of the window
     const int gx = (W + TILE - 1) / TILE;
     quadrant_of_block(blockIdx.x, V * tiles, gx, gtile, quad, tile_order);
@@ -354,10 +319,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     const uint32_t end = min(end0, list0 + wave_last);
     if (NC <= 4) { if (split && beg >= end) return; }   // nothing of this half contributes
 
-#ifdef SR_BWD_PROFILE
-    unsigned long long bprof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    BP_T(tk0);
-#endif
     // wave_reduce_pack leaves total k in lane bitreverse6(k); values [0, KV) belong to the first
     // Gaussian of a pair, [KV, 2 KV) to the second; inside a Gaussian: NV colours then 7 geometric
     const int slotv = (int)(__brev((unsigned)lane) >> 26);
@@ -373,7 +334,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     // (v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
     //  D[row = 4 (l >> 4) + reg][col = l & 15])
     auto flush_panel = [&](int count) {
-        BP_T(tf0);
         __builtin_amdgcn_wave_barrier();
         f32x4 D[NB];
 #pragma unroll
@@ -405,8 +365,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             }
         }
         __builtin_amdgcn_wave_barrier();
-        BP_T(tf1);
-        BP_ADD(6, tf1 - tf0);
     };
 
     // Moments of the parked E columns.  Lane (g = l & 7, i = l >> 3) owns Gaussian column g and pixel column i of the
@@ -415,7 +373,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     // column) fold the 8 columns: lane l ends with moment (l >> 5 & 1) + 2 (l >> 4 & 1) + 4 (l >> 3 & 1) of Gaussian g.
     auto reduce_e = [&](int count) {
         if constexpr (TM) {
-            BP_T(te0);
             __builtin_amdgcn_wave_barrier();
             const int eg = lane & 7, ei = lane >> 3;
             const float2 mu = s_emean[min(e0 + eg, GROUP - 1)];
@@ -441,8 +398,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 acc_add<DET>(gacc, gacc64, di, outv, det_pass);
             }
             __builtin_amdgcn_wave_barrier();
-            BP_T(te1);
-            BP_ADD(4, te1 - te0);
         }
     };
 
@@ -468,12 +423,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #pragma unroll 1
     for (int chunk = nchunks - 1; chunk >= 0; --chunk) {
         const uint32_t base = beg + (uint32_t)chunk * WAVE;
-        BP_T(tc0);
         const bool cur_reach = (pw >> (24 + quad)) & 1u;
         uint64_t cand = __builtin_amdgcn_ballot_w64(cur_reach);
-        BP_T(tc1);
-        BP_ADD(0, tc1 - tc0);
-        BP_ADD(8, 1);
         const uint32_t cur_gid = pw & 0xFFFFFFu;
         // the chunk in front: requested now, consumed after this one (the loop's last iteration requests nothing: the guard
         // is per lane, so there is no wave-uniform branch around the loads)
@@ -482,7 +433,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 #pragma unroll 1
         while (cand != 0) {
             // ---- stage the records and feature rows of the LAST <= FS candidates (row 0 = the deepest) ----
-            BP_T(ts0);
             const int ncand = min(FS, (int)__popcll(cand));
             const int rank = __popcll(cand & gt_mask);
             const bool mine = cur_reach && ((cand >> lane) & 1ull) && rank < FS;
@@ -496,42 +446,19 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             }
             __builtin_amdgcn_wave_barrier();
             // 16-byte pieces of the 16-byte-aligned padded rows
-#if SR_BWD_LDSDMA
-            // LDS-DMA (global_load_lds_dwordx4): lane l of issue k lands at s_feat + 16 (64 k + l) without passing
-            // through VGPRs, so EVERY piece of the round is in flight at once (one memory latency per round
-            // instead of one per SR_BWD_STAGE_UNROLL pieces)
-#pragma unroll
-            for (int k = 0; k < (FS * PPR + WAVE - 1) / WAVE; ++k) {
-                const int e = k * WAVE + lane;
-                if (k * WAVE < ncand * PPR && e < ncand * PPR) {
-                    const int row = e / PPR, pc = e - row * PPR;
-                    __builtin_amdgcn_global_load_lds(&featp4[(size_t)(__umul24(s_cgid[row] - row0, (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))],
-                                                     reinterpret_cast<float4*>(s_feat) + k * WAVE, 16, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
 #pragma unroll SR_BWD_STAGE_UNROLL
             for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
                 reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(s_cgid[row] - row0, (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];
             }
-#endif
             if (mine) {
                 s_rec0[rank] = rec_a;
                 s_rec1[rank] = rec_b;
             }
             __builtin_amdgcn_wave_barrier();
-#ifdef SR_BWD_PROFILE
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-            BP_T(ts1);
-            BP_ADD(1, ts1 - ts0);
-            BP_ADD(9, 1);
             // One pair of candidates (list positions j0 > j1: the deeper one first; staged rows r0, r1); qm0 / qm1 are
             // their dot products when the matrix pipe already produced them.
             auto process_pair = [&](int j0, int j1, bool has1, int r0, int r1, float qm0, float qm1) {
-                BP_T(tp0);
                 const float4 p0 = s_rec0[r0], q0 = s_rec1[r0];
                 const float4 p1 = s_rec0[r1], q1 = s_rec1[r1];
                 const float dx0 = p0.x - fx, dy0 = p0.y - fy, dx1 = p1.x - fx, dy1 = p1.y - fy;
@@ -544,12 +471,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 const bool hit0 = (idx0 + (uint32_t)j0 < last) && pw0 <= 0.0f && ar0 >= ALPHA_MIN;
                 const bool hit1 = has1 && (idx0 + (uint32_t)j1 < last) && pw1 <= 0.0f && ar1 >= ALPHA_MIN;
                 const float G0 = hit0 ? Gr0 : 0.0f, G1 = hit1 ? Gr1 : 0.0f;
-#if SR_BWD_SKIP_BRANCH
-                if (__builtin_amdgcn_ballot_w64(hit0 || hit1) == 0) return;
-#endif
-                BP_T(tp1);
-                BP_ADD(2, tp1 - tp0);
-                BP_ADD(10, 1);
                 // ---- dot products q = f . g (+ depth) of both Gaussians ----
                 float qd0 = qm0, qd1 = qm1;
                 if (!DOTM) {
@@ -602,11 +523,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 }
                 const float E0 = G0 * dA0, E1 = G1 * dA1;   // (0 for a miss)
                 const uint32_t gi0 = s_cgid[r0], gi1 = s_cgid[r1];
-#ifdef SR_BWD_PROFILE
-                asm volatile("" ::"v"(E0), "v"(E1), "v"(w0), "v"(w1));
-#endif
-                BP_T(tp2);
-                BP_ADD(3, tp2 - tp1);
                 if constexpr (KV > 0) {
                     float red[2 * KV];
 #pragma unroll
@@ -638,17 +554,11 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                     }
                     {
                         const float outv = wave_reduce_pack<2 * KV>(red, lane);
-#ifdef SR_BWD_PROFILE
-                        asm volatile("" ::"v"(outv));
-#endif
-                        BP_T(tp3);
-                        BP_ADD(4, tp3 - tp2);
                         const uint32_t gi = slot_second ? gi1 : gi0;
                         const size_t di = (size_t)(__umul24(gi, (uint32_t)GROW) + (uint32_t)slot_off);   // gi < 2^24 (checked on the host)
                         if (slot_ok && (has1 || !slot_second)) acc_add<DET>(gacc, gacc64, di, outv, det_pass);
                     }
                 }
-                BP_T(tp4);
                 if constexpr (MFMA) {
                     // park the weights (0 for pixels that miss); a pair never straddles a flush
                     s_w[lane * WS + nslot] = w0;
@@ -666,8 +576,6 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                         }
                     }
                     nslot += has1 ? 2 : 1;
-                    BP_T(tp5);
-                    BP_ADD(5, tp5 - tp4);
                     if constexpr (TM) {
                         if (nslot - e0 >= EG - 1 || nslot >= GROUP - 1) {
                             reduce_e(nslot - e0);
@@ -733,16 +641,10 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                 const int j3 = has3 ? 63 - __builtin_clzll(cand) : j2;
                 if (has3) cand &= ~(1ull << j3);
                 float qm[4] = {0.f, 0.f, 0.f, 0.f};
-                BP_T(td0);
                 if (DOTM) {
                     const f32x4 Q = dot4(slot);
                     qm[0] = Q[0]; qm[1] = Q[1]; qm[2] = Q[2]; qm[3] = Q[3];
-#ifdef SR_BWD_PROFILE
-                    asm volatile("" ::"v"(qm[0]), "v"(qm[3]));
-#endif
                 }
-                BP_T(td1);
-                BP_ADD(7, td1 - td0);
                 process_pair(j0, j1, has1, slot, slot + 1, qm[0], qm[1]);
                 if (has2) process_pair(j2, j3, has3, slot + 2, slot + 3, qm[2], qm[3]);
             }
@@ -750,28 +652,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     }
     if constexpr (TM) { if (nslot - e0 > 0) reduce_e(nslot - e0); }
     if (MFMA && nslot > 0) flush_panel(nslot);
-#ifdef SR_BWD_PROFILE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    BP_T(tk1);
-    bprof[11] = tk1 - tk0;
-    if (lane == 0 && (blockIdx.x % 61u) == 0) {   // a SAMPLE of the waves: same-address atomics from every wave stall the L2 channel they share
-#pragma unroll
-        for (int k = 0; k < 12; ++k) atomicAdd(&g_bwd_prof[k], bprof[k]);
-    }
-#endif
 }
 
-#ifdef SR_BWD_PROFILE
-extern "C" int splatraster_debug_bwd_prof(unsigned long long* out, int reset)
-{
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_prof), sizeof(unsigned long long) * 12) != hipSuccess) return 2;
-    if (reset) {
-        unsigned long long z[12] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_prof), z, sizeof(z)) != hipSuccess) return 2;
-    }
-    return 0;
-}
-#endif
 
 
 static int g_small_panel_max_waves = SR_BWD_SMALL_PANEL_MAX_WAVES;
@@ -866,9 +748,3 @@ int launch_composite_bwd(const splatraster_settings& s, int32_t P, int32_t V, in
 
 }  // namespace sr
 
-#ifdef SR_TRACE_WAVES
-extern "C" int splatraster_debug_trace_bwd(unsigned long long* out, int n)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sr::g_trace_bwd), sizeof(unsigned long long) * 2 * (size_t)n) == hipSuccess ? 0 : 2;
-}
-#endif

@@ -32,9 +32,6 @@
 #define SR_FWD_STAGE_UNROLL 3  // gather iterations in flight together while staging feature rows (A/B on S2: 1: 0.429, 2: 0.456, 3: 0.416, 5: 0.478 ms)
 #endif
 
-#ifndef SR_FWD_LDSDMA
-#define SR_FWD_LDSDMA 0  // 1 = stage the feature rows with LDS-DMA loads
-#endif
 #ifndef SR_FWD_M4
 #define SR_FWD_M4 1  // leftover channels + depth of a wide layout on v_mfma_f32_4x4x1 (0: VALU pair sums)
 #endif
@@ -44,9 +41,6 @@
 
 namespace sr {
 
-#ifdef SR_TRACE_WAVES  // debug build for tools/wave_trace.py: per-workgroup start/end (100 MHz clock)
-__device__ unsigned long long g_trace_fwd[2 * 40960];
-#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -133,19 +127,6 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
     __shared__ __attribute__((aligned(16))) float s_feat[FS * NCP];
     __shared__ uint32_t s_cgid[FS];
 
-#ifdef SR_TRACE_WAVES
-    struct TraceEnd {
-        unsigned long long t0;
-        unsigned long long* buf;
-        __device__ ~TraceEnd()
-        {
-            if (threadIdx.x == 0 && blockIdx.x < 40960) {
-                buf[2 * blockIdx.x] = t0;
-                buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-            }
-        }
-    } trace_end{__builtin_amdgcn_s_memrealtime(), g_trace_fwd};
-#endif
     int gtile, quad;   // global tile = view * tiles + tile: the grid covers the V views of the window
     const int gx = (W + TILE - 1) / TILE;
     quadrant_of_block(blockIdx.x, V * tiles, gx, gtile, quad, tile_order);
@@ -252,26 +233,12 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
             if (cur_reach && ((cand >> lane) & 1ull) && rank < FS) s_cgid[rank] = cur_gid - row0;   // feature row (shared by the views)
             __builtin_amdgcn_wave_barrier();
             // 16-byte pieces of the 16-byte-aligned padded rows
-#if SR_FWD_LDSDMA
-#pragma unroll
-            for (int k = 0; k < (FS * PPR + WAVE - 1) / WAVE; ++k) {
-                const int e = k * WAVE + lane;
-                if (k * WAVE < ncand * PPR && e < ncand * PPR) {
-                    const int row = e / PPR, pc = e - row * PPR;
-                    __builtin_amdgcn_global_load_lds(&featp4[(size_t)(__umul24(s_cgid[row], (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))],
-                                                     reinterpret_cast<float4*>(s_feat) + k * WAVE, 16, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-#else
 #pragma unroll SR_FWD_STAGE_UNROLL
             for (int e = lane; e < ncand * PPR; e += WAVE) {
                 const int row = e / PPR, pc = e - row * PPR;
                 reinterpret_cast<float4*>(s_feat)[e] = featp4[(size_t)(__umul24(s_cgid[row], (uint32_t)CP4) + (uint32_t)((c0 >> 2) + pc))];   // ids < 2^24: checked on the host
             }
             __builtin_amdgcn_wave_barrier();
-#endif
             if (ncand & 1) {      // the absent candidate's feature row: finite, whatever the LDS held
                 if (lane < PPR) reinterpret_cast<float4*>(s_feat)[ncand * PPR + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
                 __builtin_amdgcn_wave_barrier();
@@ -499,9 +466,3 @@ int launch_composite_fwd(const splatraster_settings& s, int32_t P, int32_t V, in
 
 }  // namespace sr
 
-#ifdef SR_TRACE_WAVES
-extern "C" int splatraster_debug_trace_fwd(unsigned long long* out, int n)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sr::g_trace_fwd), sizeof(unsigned long long) * 2 * (size_t)n) == hipSuccess ? 0 : 2;
-}
-#endif

@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 def _restore_front_end():
     yield
     _native.set_front_end(-1)
+    _native.check(_native.load().splatraster_debug_set_tile_sort_cap(0), "tile_sort_cap")
 
 
 def _state_equal(a: HipRun, b: HipRun):
@@ -79,6 +80,22 @@ def test_front_ends_leave_the_same_state(name):
     if name == "beyond_lds":
         r = f["ranges"].astype(np.int64)
         assert (r[:, 1] - r[:, 0]).max() > 16384
+
+
+@pytest.mark.parametrize("cap", [2048, 4096, 0])
+def test_lists_between_the_two_tile_launches(cap):
+    """A list of ~3 500 keys: sorted by the 256-thread instantiation of the tile launch (cap 4096), by the work-list launch
+    (cap 2048), or by whichever the hint selects (0: the first frame meets the list with the narrow launch and raises the hint,
+    the second frame takes the wide one) — the same state every time."""
+    sc = _concentrate(make_scene(20_000, 256, 256, 4, 54, scale_median=0.02), 3_200, (130.4, 60.7))
+    f = oracle_forward(sc)
+    r = f["ranges"].astype(np.int64)
+    assert 2048 < (r[:, 1] - r[:, 0]).max() <= 4096
+    _native.set_front_end(1)
+    _native.check(_native.load().splatraster_debug_set_tile_sort_cap(cap), "tile_sort_cap")
+    for _ in range(2):
+        run = HipRun(sc, backward=False)
+        _check_forward(run, f, sc)
 
 
 def test_exact_depth_ties_and_duplicates_keep_index_order():

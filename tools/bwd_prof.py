@@ -1,3 +1,6 @@
+"""Per-phase cycle counters of the wide backward (SR_BWD_PROFILE, kept in tools/patches/r05_variants.patch):
+    python tools/ablate.py --patch tools/patches/r05_variants.patch bprof "-DSR_BWD_PROFILE"   (here, before gpurun)
+    python tools/bwd_prof.py [variant name = bprof]                                              (on the GPU box)"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, ".")
 os.environ["SPLATRASTER_LIB"] = os.path.abspath("splatloc_amd/_lib/variants/libsplatraster_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "bprof"))

@@ -11,6 +11,9 @@
 #include <random>
 #include <vector>
 
+#ifndef SR_BENCH_CAP
+#define SR_BENCH_CAP 2048   // -DSR_BENCH_CAP=4096: the wide instantiation
+#endif
 #include "../../splatloc_amd/csrc/binsort.hip"
 
 namespace sr {   // the pieces of the library this translation unit does not carry
@@ -77,7 +80,7 @@ int main(int argc, char** argv)
         CK(hipMemset(d_total + 2, 0, 4));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(sr::bin_sort_tile_kernel, dim3(tiles), dim3(128), 0, 0, tiles, tiles, gx, 1, d_table, d_total, d_keys,
+        hipLaunchKernelGGL(sr::bin_sort_tile_kernel<SR_BENCH_CAP>, dim3(tiles), dim3(SR_BENCH_CAP / 16), 0, 0, tiles, tiles, gx, 1, d_table, d_total, d_keys,
                            d_rec, b, d_total + 2, d_big_list);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));

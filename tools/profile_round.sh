@@ -14,5 +14,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $RAW/fetch -o bench -- python3 $R/b
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $RAW/write -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-multi-stream "$@" > /dev/null 2> $OUT/write.err
 cd $R
 python3 tools/summarize_prof.py $RAW $OUT/summary > $OUT/summary.txt
-python3 tools/timeline.py $RAW/stats 2 > $OUT/timeline.txt 2>&1
+python3 tools/timeline.py $RAW/stats $OUT/bench_under_rocprof.json > $OUT/timeline.txt 2>&1
 rm -f $OUT/*.err

@@ -1,6 +1,7 @@
 """Wave start/end timeline of the compositing kernels (100 MHz s_memrealtime): resident waves
 over time, life-time distribution, tail.  Needs the debug variant:
-    python tools/ablate.py trace "-DSR_TRACE_WAVES=1"   (here, before gpurun)
+    python tools/ablate.py --patch tools/patches/r05_variants.patch trace "-DSR_TRACE_WAVES=1"   (here, before gpurun;
+                                                        the trace hooks live in the patch, not in the shipped kernels)
     python tools/wave_trace.py                          (on the GPU box)"""
 import ctypes as C, os, sys
 import numpy as np
