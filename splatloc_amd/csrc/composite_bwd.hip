@@ -135,6 +135,14 @@ __device__ __forceinline__ void acc_add(float* gacc, long long* gacc64, size_t i
             atomicMax(reinterpret_cast<unsigned*>(gacc) + idx, __float_as_uint(fabsf(v)));
         } else {
             const unsigned mb = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(gacc) + idx);
+            if (((mb >> 23) & 0xffu) == 0xffu) {
+                // a NaN or an infinity reached this element (it won pass 0's maximum): no fixed point can hold it.  The element
+                // must come back non-finite, like the float atomics of the normal path would leave it — this mode exists to
+                // expose such failures, not to flush them to 0 (round-4 advisor finding).  NaN: the recorded maximum says it
+                // all; infinities: their signs are counted (low word +inf, high word -inf) for fixed_to_float_kernel
+                if (__builtin_isinf(v)) atomicAdd(reinterpret_cast<unsigned long long*>(gacc64) + idx, v > 0.f ? 1ull : (1ull << 32));
+                return;
+            }
             const double scaled = ldexp((double)v, det_scale_exp(mb));
             atomicAdd(reinterpret_cast<unsigned long long*>(gacc64) + idx, (unsigned long long)__double2ll_rn(scaled));
         }
@@ -662,7 +670,7 @@ void set_small_panel_max_waves(int waves) { g_small_panel_max_waves = waves < 0 
 struct BwdLaunch {
     int P, V;
     const WinGrad* grads;
-    const float* ckpt;   // non-null: split launch — two waves per quadrant, the second from the forward's mid-list checkpoint
+    const float* ckpt;   // non-null: split launch — SPLIT_PARTS waves per quadrant, wave k > 0 from the forward's segment records (common.h)
     int det_pass;        // deterministic mode: 0 = per-element max pass, 1 = fixed-point sum pass (acc_add)
 };
 

@@ -412,7 +412,7 @@ int launch_debug_exp2(int64_t n, const float* x, float* y, hipStream_t stream)
 struct FwdLaunch {
     int P, V;
     const WinOut* outs;
-    float* ckpt;   // non-null: split launch (the backward runs two waves per quadrant)
+    float* ckpt;   // non-null: split launch (the backward runs SPLIT_PARTS waves per quadrant: the forward records every quarter's own sums)
 };
 
 template <int NC>

@@ -366,6 +366,12 @@ fixed_to_float_kernel(int64_t n, const long long* __restrict__ src, float* __res
     if (e >= n) return;
     const unsigned mb = reinterpret_cast<const unsigned*>(dst)[e];
     const int eb = (int)((mb >> 23) & 0xffu);
+    if (eb == 255) {   // a non-finite partial (composite_bwd.hip acc_add): NaN, or the infinity whose sign(s) were counted
+        const unsigned long long cnt = (unsigned long long)src[e];
+        const bool pos = (cnt & 0xffffffffull) != 0, neg = (cnt >> 32) != 0;
+        dst[e] = ((mb & 0x7fffffu) || pos == neg) ? __builtin_nanf("") : (neg ? -__builtin_inff() : __builtin_inff());
+        return;
+    }
     dst[e] = (float)ldexp((double)src[e], -(170 - (eb > 0 ? eb : 1)));
 }
 

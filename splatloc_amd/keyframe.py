@@ -87,6 +87,17 @@ def create_pcd_from_image_and_depth_score(gaussians, cam, rgb, depth, scores, sa
         if sample_idx is None and generator is not None:
             sample_idx = torch.randint(0, max(n_points, 1), (n_samples,), device=generator.device, generator=generator)   # with replacement
         elif sample_idx is None:
+            if kf_id < 0:
+                # no key-frame id threaded through (the reference's signature has none, gaussian_model.py:170): key the draw by a
+                # per-MODEL call counter, so that successive key-frames get independent draws like the reference's
+                # np.random.choice per call — and replicas, which insert key-frames in the same order, still agree
+                # (round-4 advisor finding: kf_id = -1 keyed every call alike: the same pixel ranks for every key-frame)
+                n_unkeyed = int(getattr(gaussians, "_unkeyed_pcd_draws", 0))
+                try:
+                    gaussians._unkeyed_pcd_draws = n_unkeyed + 1
+                except AttributeError:      # an object without a __dict__: no counter can be kept on it
+                    raise RuntimeError("create_pcd: pass kf_id (or sample_idx / generator) for the down-sampling draw") from None
+                kf_id = -1 - n_unkeyed
             sample_idx = _keyed_draw(n_points, n_samples, seed, kf_id)
         sample_idx = torch.as_tensor(sample_idx, device=dev, dtype=torch.long)
         if int(sample_idx.numel()) != n_samples:

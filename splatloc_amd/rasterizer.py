@@ -387,9 +387,12 @@ class _RasterizeWindow(torch.autograd.Function):
         ctx.have = (sca is not None, cov is not None)
         none = _empty(dev)
         flat_cams = [t if t is not None else none for cam in cams for t in cam]
-        ctx.bg = bg     # (a setting, not an autograd input; read by the deterministic / accurate debug mode only)
+        # the background is an INPUT of the backward: the back-to-front walk starts every pixel at A = bg . g - g_A (DESIGN.md
+        # §4.4), so it is saved like a tensor the backward reads (autograd's version check then catches an in-place change
+        # between forward and backward) — not kept as a bare attribute
+        ctx.have_bg = bg is not None
         ctx.save_for_backward(*[t if t is not None else none for t in (m3, col, opa, sca, rot, cov)], radii, geom, binning,
-                              img, color, depth, alpha, *flat_cams)
+                              img, color, depth, alpha, *flat_cams, bg if bg is not None else none)
         outs, rad = [], []
         for v in range(V):
             rv = radii[v]
@@ -407,7 +410,8 @@ class _RasterizeWindow(torch.autograd.Function):
         lib = _native.load()
         saved = ctx.saved_tensors
         m3, col, opa, sca, rot, cov, radii, geom, binning, img, color, depth, alpha = saved[:13]
-        flat_cams = saved[13:]
+        flat_cams = saved[13:-1]
+        bg = saved[-1] if ctx.have_bg else None
         dev = m3.device
         V, st = ctx.V, ctx.st
         opt = lambda t: t if t.numel() else None  # noqa: E731
@@ -460,7 +464,7 @@ class _RasterizeWindow(torch.autograd.Function):
         R = (C.c_int64 * V)(*ctx.R)
         with _on_device(dev):
             _native.check(lib.splatraster_backward_window(
-                C.byref(st), V, views, P, R, _ptr(ctx.bg), _ptr(m3), _ptr(col), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(geom),
+                C.byref(st), V, views, P, R, _ptr(bg), _ptr(m3), _ptr(col), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(geom),
                 _ptr(binning), _ptr(img), _ptr(d_m3), _ptr(d_col), _ptr(d_op), _ptr(d_sca), _ptr(d_rot), _ptr(d_cov),
                 _stream(dev)), "backward_window")
         del keep

@@ -125,3 +125,28 @@ def test_first_keyframe_into_an_empty_model():
     assert n == N and torch.equal(gm._xyz.detach().cpu(), rows[0]) and gm._features_rest.shape == (N, 0, 3)
     assert torch.equal(gm._features_dc.detach().cpu(), rows[1].transpose(1, 2).contiguous())
     assert gm.max_radii2D.shape == (N,) and float(gm.denom.sum()) == 0.0
+
+
+def test_unkeyed_downsampling_draws_differ_per_call_and_agree_across_models(golden_dir):
+    """create_pcd_from_image without kf_id / sample_idx / generator (the reference's own signature has no key-frame id,
+    gaussian_model.py:118,170): successive calls on one model must draw DIFFERENT pixel subsets — the reference draws a fresh
+    np.random.choice per call; round 4 keyed every such call by kf_id = -1 alike — and a second model (another replica) making
+    the same calls in the same order must reproduce them."""
+    from splatloc_amd import keyframe
+    d = np.load(os.path.join(golden_dir, "keyframe.npz"))
+    dev = torch.device(DEV)
+    cam = _cam(d, dev)
+    depth = torch.from_numpy(d["view_depth"]).to(dev)
+    clouds = []
+    for _model_id in range(2):
+        gm = types.SimpleNamespace(max_sh_degree=0, isotropic=False,
+                                   config={"Dataset": {"pcd_downsample": max(int(d["cfg"][0]), 4), "point_size": float(d["cfg"][1]),
+                                                       "adaptive_pointsize": bool(d["cfg"][2])}})
+        clouds.append([keyframe.create_pcd_from_image(gm, cam, depth)[0] for _ in range(3)])
+    a, b = clouds
+    assert not torch.equal(a[0], a[1]) and not torch.equal(a[1], a[2])
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    keyed = keyframe.create_pcd_from_image(types.SimpleNamespace(max_sh_degree=0, isotropic=False, config=gm.config), cam, depth,
+                                           kf_id=7)[0]
+    assert not torch.equal(keyed, a[0])

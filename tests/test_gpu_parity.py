@@ -519,3 +519,29 @@ def test_deterministic_sum_mode_is_bit_reproducible_and_strict(cfg):
     free = HipRun(sc)
     for n in names:
         assert_grad_close(n, free.np(getattr(free, n).grad), run.np(getattr(run, n).grad), rtol=2e-3, atol_scale=1e-4)
+
+
+@pytest.mark.parametrize("C", [4, 35])
+def test_deterministic_mode_propagates_non_finite_gradients(C):
+    """A NaN (and an infinity) in dL/dout must come back as a non-finite gradient in the deterministic-sum mode exactly where the
+    float-atomic mode returns one: the mode meant for regression hunting may not flush the failure it should expose to 0
+    (round-4 advisor finding: the NaN won the per-element maximum, every partial then scaled to 0)."""
+    from splatloc_amd import _native
+    sc = make_scene(3_000, 160, 96, C, 83, scale_median=0.04)
+    sc.dL_dcolor[0, 40, 70] = float("nan")
+    sc.dL_dcolor[min(1, C - 1), 50, 20] = float("inf")
+    free = HipRun(sc)
+    _native.set_deterministic(True)
+    try:
+        det = HipRun(sc)
+    finally:
+        _native.set_deterministic(False)
+    for n in ("colors", "opacities", "means2D"):
+        a, b = getattr(free, n).grad, getattr(det, n).grad
+        bad_a, bad_b = ~torch.isfinite(a), ~torch.isfinite(b)
+        assert bad_a.any(), n
+        # every row the float-atomic path poisons is poisoned in the deterministic mode too (its double-precision walk may
+        # turn a further inf - inf into NaN: a superset is allowed, a finite value in place of a non-finite one is not)
+        assert bool((bad_b | ~bad_a).all()), f"{n}: {int((bad_a & ~bad_b).sum())} non-finite elements came back finite"
+    ok = torch.isfinite(free.colors.grad).all(dim=1) & torch.isfinite(det.colors.grad).all(dim=1)
+    assert ok.any() and torch.allclose(free.colors.grad[ok], det.colors.grad[ok], rtol=2e-3, atol=1e-6)

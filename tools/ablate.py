@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Builds variant libraries with extra -D flags for within-run A/B perf experiments.
-usage: ablate.py [--patch tools/patches/X.patch] NAME "-DFLAG=1 ..."   ->  splatloc_amd/_lib/variants/libsplatraster_NAME.so
+usage: ablate.py [--patch tools/patches/X.patch [--patch Y.patch ...]] NAME "-DFLAG=1 ..."   ->  splatloc_amd/_lib/variants/libsplatraster_NAME.so
 Run a variant with SPLATRASTER_LIB=<that path> python bench.py ...
 
 --patch: the sources are copied to a scratch directory and the patch is applied there first (patch -p1).  The timing probes
@@ -15,9 +15,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from splatloc_amd import build as B  # noqa: E402
 
 argv = sys.argv[1:]
-patch = None
-if argv and argv[0] == "--patch":
-    patch, argv = os.path.abspath(argv[1]), argv[2:]
+patches = []
+while argv and argv[0] == "--patch":
+    patches.append(os.path.abspath(argv[1]))
+    argv = argv[2:]
+patch = patches[0] if patches else None
 name, flags = argv[0], (argv[1].split() if len(argv) > 1 else [])
 CSRC = B.CSRC
 if patch:
@@ -26,7 +28,8 @@ if patch:
     root = tempfile.mkdtemp(prefix="splat_probe_")
     shutil.copytree(os.path.dirname(B.CSRC), os.path.join(root, "splatloc_amd"), ignore=shutil.ignore_patterns("_lib", "__pycache__"))
     shutil.copytree(os.path.join(os.path.dirname(os.path.dirname(B.CSRC)), "include"), os.path.join(root, "include"))
-    subprocess.run(["patch", "-p1", "-i", patch], cwd=root, check=True)
+    for pt in patches:      # in the order given (every patch applies to the shipped tree; later ones tolerate the offsets of earlier ones)
+        subprocess.run(["patch", "-p1", "-i", pt], cwd=root, check=True)
     CSRC = os.path.join(root, "splatloc_amd", "csrc")
 out_dir = os.path.join(B.LIB_DIR, "variants")
 obj_dir = os.path.join(out_dir, "obj_" + name)
