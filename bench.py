@@ -67,7 +67,7 @@ def algorithmic_bytes(P, R, W, H, C, tiles):
 def actual_bytes(P, V, R, W, H, C, tiles):
     """Compulsory bytes of THIS implementation's stages (every array once per pass that needs it; L2 /
     Infinity-Cache hits, atomics and re-reads not counted) — the figure a stage's GB/s is quoted on.
-    DESIGN.md §4.2 derives each line."""
+    DESIGN.md §5 / HISTORY.md §4.2 derive each line."""
     CP = (C + 3) & ~3
     mo = C if ((C & 15) + 7 <= 16) else ((C + 15) & ~15)
     grow = (mo + 7 + 15) & ~15                     # gacc_row_floats(C)
@@ -477,7 +477,7 @@ def bench_map_step(args, dev):
             # (losses.mapping_loss_window): ONE backward on the rasterizer's outputs
             pkgs, _ = render_window(views, pc, pipe, bg)
             bw_tensors, bw_grads, loss = mapping_loss_window(cfg, pkgs, views)
-        elif fused:   # one activate_pack per window; the views on --streams HIP streams
+        elif fused:   # one activate_pack per window; the views on --streams HIP streams (HISTORY.md §11)
             pkgs, losses = render_window(views, pc, pipe, bg, streams=max(args.streams, 1),
                                          per_view=lambda k, cam, pkg: mapping_loss(cfg, pkg["render"], pkg["depth"], pkg["kp_prob"], cam))
             loss = sum(losses)

@@ -472,7 +472,7 @@ int splatknn_dist2(int32_t N, const float* points /* [N,3] */, float* out /* [N]
 /* test hook: point count from which splatknn_dist2 takes the grid search (< 0 restores the default 10 000) */
 int splatknn_debug_set_grid_min(int32_t n);
 
-/* ---- pose refinement on the device (build extension, DESIGN.md §4.8: the reference's rasterizer returns no camera gradient
+/* ---- pose refinement on the device (build extension, DESIGN.md §6.8: the reference's rasterizer returns no camera gradient
  * and nothing calls its utils/optimization_utils.py:5-66 pose helpers) ------------------------------------------------------
  * L = mean |color - target_color| + depth_weight * mean |depth - target_depth| and its gradient planes in one pass;
  * `*loss_out += L` (a float atomic: zero it before the first call; monitoring value).  target_depth may be NULL (no depth
@@ -542,14 +542,14 @@ int splatraster_debug_set_spin_limit(uint32_t limit);
  * carried an absolute float32 error in the suffix sum.) */
 int splatraster_debug_set_deterministic(int on);
 /* A/B hook: launches of the C = 4..15 backward with at most this many quadrant-waves take the small-layout panel
- * variant; < 0 restores the built-in default. */
+ * variant (HISTORY.md §11); < 0 restores the built-in default. */
 int splatraster_debug_set_small_panel_max_waves(int waves);
 /* A/B hook: narrow-layout launches (C <= 4) with at most this many quadrant-waves split every list of >= 256 entries in
- * four for the backward (the forward checkpoints every pixel's state at the quarter points of its tile's list).
+ * four for the backward (the forward checkpoints every pixel's state at the quarter points of its tile's list; DESIGN.md §6.3, HISTORY.md §11).
  * 0 = never, < 0 or > 6144 = the built-in default 6144 (one 640x480 frame).  Must not change between a forward and its backward. */
 int splatraster_debug_set_split_max_waves(int waves);
 /* A/B / test hook: instance count from which the per-instance payload is written with streaming (non-temporal) stores
- * (DESIGN.md §11); < 0 restores the built-in default (8 Mi instances), 0 = always.  Results never depend on it. */
+ * (HISTORY.md §11); < 0 restores the built-in default (8 Mi instances), 0 = always.  Results never depend on it. */
 int splatraster_debug_set_payload_stream_min(int64_t instances);
 /* A/B / test hook: which front end orders the tile instances.  -1 (default): the binned front end (counting sort by
  * (view, tile) + one LDS sort per tile) for windows of at most 6144 (view, tile) lists — SplatLoc's own

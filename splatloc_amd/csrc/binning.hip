@@ -2,7 +2,7 @@
 //
 // The lineage sorts R = sum(tiles_touched) 64-bit (tile | depth) keys with 6 radix passes.
 // Here the same ordering (tile, depth bits, Gaussian index) is produced with far less
-// traffic (DESIGN.md §binning):
+// traffic (DESIGN.md §3.1):
 //   1. stable sort of the P Gaussians by depth bits (32-bit keys, P elements; the keys are
 //      written by preprocess_kernel);
 //   2. instances are emitted IN DEPTH ORDER, one thread per instance (coalesced writes);

@@ -98,7 +98,7 @@ __device__ __forceinline__ float gauss_log2(const float4& q, float dx, float dy)
 // c0 = 1 exactly (2^n is exact at the integers); max relative error 1.7e-7 (1.4 ulp) — the accuracy
 // class of a libm expf.
 // v_exp_f32 (the hardware approximation, 1 quarter-rate instruction instead of 9 full-rate ones) is
-// not reproducible off the GPU; -DSR_EXP2_HW selects it for A/B timing only (cost: DESIGN.md §5).
+// not reproducible off the GPU; -DSR_EXP2_HW selects it for A/B timing only (cost: DESIGN.md §6.1).
 constexpr float EXP2_C0 = 1.0f, EXP2_C1 = 0.6931470036506653f, EXP2_C2 = 0.24022242426872253f,
                 EXP2_C3 = 0.05550733581185341f, EXP2_C4 = 0.009671512991189957f, EXP2_C5 = 0.001326472731307149f;
 // The arithmetic without the argument clamp, for the compositing kernels (backward -2 % on S2 / S1 in round 3; the forward

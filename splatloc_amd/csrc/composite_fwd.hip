@@ -4,7 +4,7 @@
 // diff_gauss.GaussianRasterizer.forward (gaussian_renderer/__init__.py:117-126; algorithm
 // per SURVEY.md §8a "COMPOSITE fwd").
 //
-// Machine mapping (DESIGN.md §4): ONE wave64 = one workgroup = one 8x8 pixel quadrant of a
+// Machine mapping (DESIGN.md §2): ONE wave64 = one workgroup = one 8x8 pixel quadrant of a
 // 16x16 tile.  The four quadrants of a tile have very different amounts of work; as waves of
 // one 256-thread workgroup they met at three barriers per batch and spent > 50 % of their
 // cycles waiting.  Here every quadrant walks the tile's list on its own, wave-synchronously,

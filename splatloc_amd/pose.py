@@ -3,7 +3,7 @@
 The reference ships `utils/optimization_utils.py` (axis-angle / quaternion / 6-D rotation + translation -> 4x4 transform) for
 optimising a camera pose through the renderer, but nothing in the reference calls it and its rasterizer returns no gradient
 for the camera: the path ends at `viewmatrix`.  Here it continues — `diff_gauss.GaussianRasterizer` returns
-dL/dviewmatrix, dL/dprojmatrix and dL/dcampos when those tensors require a gradient (DESIGN.md §4.8, tests/test_gpu_pose.py) —
+dL/dviewmatrix, dL/dprojmatrix and dL/dcampos when those tensors require a gradient (DESIGN.md §6.8, tests/test_gpu_pose.py) —
 so the helpers have a use.  Same names, argument meaning and return shapes as utils/optimization_utils.py:5-66, restated
 without pytorch3d (not installed here); the rotation conversions follow the published formulas pytorch3d implements
 (quaternions real part first; 6-D rotations: Zhou et al., "On the Continuity of Rotation Representations", rows b1, b2, b1 x b2).

@@ -388,7 +388,7 @@ class _RasterizeWindow(torch.autograd.Function):
         none = _empty(dev)
         flat_cams = [t if t is not None else none for cam in cams for t in cam]
         # the background is an INPUT of the backward: the back-to-front walk starts every pixel at A = bg . g - g_A (DESIGN.md
-        # §4.4), so it is saved like a tensor the backward reads (autograd's version check then catches an in-place change
+        # §6.3), so it is saved like a tensor the backward reads (autograd's version check then catches an in-place change
         # between forward and backward) — not kept as a bare attribute
         ctx.have_bg = bg is not None
         ctx.save_for_backward(*[t if t is not None else none for t in (m3, col, opa, sca, rot, cov)], radii, geom, binning,

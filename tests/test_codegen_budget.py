@@ -1,7 +1,7 @@
 """Register / scratch / occupancy budget of the two compositing kernels, read from the compiler's own report
 (`-Rpass-analysis=kernel-resource-usage`; hipcc cross-compiles gfx950 without a GPU).  Round 4 traced two regressions of
 the headline kernel to code generation nobody had looked at — a "prefetch" whose registers were spilled right behind the
-loads, an epilogue with a wait between every two stores — so the numbers the design depends on are
+loads, an epilogue with a wait between every two stores — so the numbers the design depends on (HISTORY.md §9) are
 pinned here: a source or toolchain change that costs a wave per SIMD or re-introduces scratch traffic fails on the CPU."""
 import os
 import re
@@ -56,7 +56,7 @@ def test_backward_kernels_stay_within_their_register_budget():
     u = _usage("composite_bwd.hip")
     wide = _kernel(u, "_ZN2sr20composite_bwd_kernelILi35ELb0ELb0ELb1E")        # <35, normal mode, butterfly variant, with depth / alpha>
     assert wide["VGPRs"] <= 128 and wide["Occupancy"] == 4, wide
-    assert wide["VGPRs Spill"] <= 3 and wide["ScratchSize"] <= 12, wide        # (the spilled values live outside the loops: DESIGN.md §9)
+    assert wide["VGPRs Spill"] <= 3 and wide["ScratchSize"] <= 12, wide        # (the spilled values live outside the loops: HISTORY.md §9)
     for nc in (1, 2, 3):                                                        # the butterfly variants of the narrow layouts: full occupancy, no scratch
         k = _kernel(u, f"_ZN2sr20composite_bwd_kernelILi{nc}ELb0ELb0ELb1E")
         assert k["Occupancy"] == 8 and k["ScratchSize"] == 0, (nc, k)

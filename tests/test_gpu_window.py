@@ -305,7 +305,7 @@ def test_window_full_size_against_oracle(name, V):
       * tensor bar: rtol 1e-4 + 5e-5 of the tensor's scale (2e-5 in the deterministic mode; round 3: 2e-3 + 1e-4);
       * per-ROW bar: rtol 1e-4 + 1e-3 of the row's own maximum for every tensor, so that a Gaussian whose gradient is a
         thousand times smaller than the largest cannot hide —
-    for BOTH the normal path (float atomics; since round 4 the backward walks back to front, DESIGN.md §5) and the
+    for BOTH the normal path (float atomics; since round 4 the backward walks back to front, DESIGN.md §6.3) and the
     deterministic / accurate mode."""
     from splatloc_amd import _native
     from splatloc_amd.synthetic import make_workload
