@@ -149,64 +149,93 @@ constexpr int RE = RT + 2 * RH;   // 26: tile + halo
 
 struct RefineWindow { float w[RW]; };
 
-__global__ void __launch_bounds__(RT * RT)
+// Round 5: both kernels work on 32x16 tiles with REGISTER-BLOCKED passes — a horizontal work item loads 14 consecutive taps
+// once and produces 4 adjacent outputs, a vertical one loads 12 rows and produces 2 — because the 16x16 / one-output-per-thread
+// form was bound by its LDS reads (22 + 55 per output): refine_fwd 22.1 -> 18.4 us, refine_bwd 16.1 -> 14.4 us (profiles/r05_ab_probes.txt #8).  Every output is
+// still accumulated tap by tap in ascending order with the same fused multiply-adds: the maps and the gradient are bit-identical.
+constexpr int FW = 32, FH = 16;               // tile of the refinement kernels
+constexpr int FEW = FW + 2 * RH, FEH = FH + 2 * RH;   // 42 x 26 with halo
+constexpr int FHG = FW / 4;                   // horizontal work items per row (4 outputs each)
+
+__global__ void __launch_bounds__(256)
 refine_fwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt, RefineWindow win,
                   float* __restrict__ dm_dmu1, float* __restrict__ dm_ds1, float* __restrict__ dm_ds12,
                   double* __restrict__ partial /*[blocks][2]: sum m, sum |x-y|*/)
 {
-    __shared__ float s_x[RE][RE + 1], s_y[RE][RE + 1];
-    __shared__ float s_h[5][RE][RT + 1];
-    __shared__ double s_red[RT * RT / WAVE][2];
+    __shared__ float s_x[FEH][FEW + 1], s_y[FEH][FEW + 1];
+    __shared__ float s_h[5][FEH][FW + 1];
+    __shared__ double s_red[256 / WAVE][2];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * RT, y0 = blockIdx.y * RT;
+    const int x0 = blockIdx.x * FW, y0 = blockIdx.y * FH;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int e = tid; e < RE * RE; e += RT * RT) {
-        const int r = e / RE, c = e - r * RE;
+    for (int e = tid; e < FEH * FEW; e += 256) {
+        const int r = e / FEW, c = e - r * FEW;
         const int gy = y0 + r - RH, gx = x0 + c - RH;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         s_x[r][c] = in ? img[plane + (size_t)gy * W + gx] : 0.0f;
         s_y[r][c] = in ? gt[plane + (size_t)gy * W + gx] : 0.0f;
     }
     __syncthreads();
-    for (int e = tid; e < RE * RT; e += RT * RT) {   // horizontal pass: RE rows x RT columns
-        const int r = e / RT, c = e - r * RT;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    if (tid < FEH * FHG) {   // horizontal pass: FEH rows x FHG groups of 4 columns
+        const int r = tid / FHG, c0 = (tid - r * FHG) * 4;
+        float xv[RW + 3], yv[RW + 3], xx[RW + 3], yy[RW + 3], xy[RW + 3];
 #pragma unroll
-        for (int k = 0; k < RW; ++k) {
-            const float xv = s_x[r][c + k], yv = s_y[r][c + k], wk = win.w[k];
-            a0 += wk * xv;
-            a1 += wk * yv;
-            a2 += wk * (xv * xv);
-            a3 += wk * (yv * yv);
-            a4 += wk * (xv * yv);
+        for (int k = 0; k < RW + 3; ++k) {
+            xv[k] = s_x[r][c0 + k];
+            yv[k] = s_y[r][c0 + k];
+            xx[k] = xv[k] * xv[k];
+            yy[k] = yv[k] * yv[k];
+            xy[k] = xv[k] * yv[k];
         }
-        s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2; s_h[3][r][c] = a3; s_h[4][r][c] = a4;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < RW; ++k) {
+                const float wk = win.w[k];
+                a0 += wk * xv[o + k];
+                a1 += wk * yv[o + k];
+                a2 += wk * xx[o + k];
+                a3 += wk * yy[o + k];
+                a4 += wk * xy[o + k];
+            }
+            s_h[0][r][c0 + o] = a0; s_h[1][r][c0 + o] = a1; s_h[2][r][c0 + o] = a2; s_h[3][r][c0 + o] = a3; s_h[4][r][c0 + o] = a4;
+        }
     }
     __syncthreads();
-    const int ty = tid / RT, tx = tid - ty * RT;
-    const int gy = y0 + ty, gx = x0 + tx;
+    const int tx = tid & (FW - 1), ty0 = (tid / FW) * 2;   // two vertically adjacent outputs per thread
+    const int gx = x0 + tx;
     double msum = 0.0, lsum = 0.0;
-    if (gy < H && gx < W) {
-        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float col[5][RW + 1];
 #pragma unroll
-        for (int k = 0; k < RW; ++k) {
-            const float wk = win.w[k];
+    for (int k = 0; k < RW + 1; ++k)
 #pragma unroll
-            for (int q = 0; q < 5; ++q) v[q] += wk * s_h[q][ty + k][tx];
+        for (int q = 0; q < 5; ++q) col[q][k] = s_h[q][ty0 + k][tx];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int ty = ty0 + o, gy = y0 + ty;
+        if (gy < H && gx < W) {
+            float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < RW; ++k) {
+                const float wk = win.w[k];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) v[q] += wk * col[q][o + k];
+            }
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float mu1 = v[0], mu2 = v[1];
+            const float sig1 = v[2] - mu1 * mu1, sig2 = v[3] - mu2 * mu2, sig12 = v[4] - mu1 * mu2;
+            const float A = 2.0f * mu1 * mu2 + C1, B = 2.0f * sig12 + C2;
+            const float Cc = mu1 * mu1 + mu2 * mu2 + C1, D = sig1 + sig2 + C2;
+            const float icd = 1.0f / (Cc * D);
+            const float m = A * B * icd;
+            const size_t oo = plane + (size_t)gy * W + gx;
+            dm_dmu1[oo] = (2.0f * mu2 * (B - A) * Cc * D - A * B * 2.0f * mu1 * (D - Cc)) * icd * icd;
+            dm_ds1[oo] = -m / D;
+            dm_ds12[oo] = 2.0f * A * icd;
+            msum += (double)m;
+            lsum += (double)fabsf(s_x[ty + RH][tx + RH] - s_y[ty + RH][tx + RH]);
         }
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float mu1 = v[0], mu2 = v[1];
-        const float sig1 = v[2] - mu1 * mu1, sig2 = v[3] - mu2 * mu2, sig12 = v[4] - mu1 * mu2;
-        const float A = 2.0f * mu1 * mu2 + C1, B = 2.0f * sig12 + C2;
-        const float Cc = mu1 * mu1 + mu2 * mu2 + C1, D = sig1 + sig2 + C2;
-        const float icd = 1.0f / (Cc * D);
-        const float m = A * B * icd;
-        const size_t o = plane + (size_t)gy * W + gx;
-        dm_dmu1[o] = (2.0f * mu2 * (B - A) * Cc * D - A * B * 2.0f * mu1 * (D - Cc)) * icd * icd;
-        dm_ds1[o] = -m / D;
-        dm_ds12[o] = 2.0f * A * icd;
-        msum = (double)m;
-        lsum = (double)fabsf(s_x[ty + RH][tx + RH] - s_y[ty + RH][tx + RH]);
     }
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
@@ -216,26 +245,26 @@ refine_fwd_kernel(int H, int W, const float* __restrict__ img, const float* __re
     if ((tid & (WAVE - 1)) == 0) { s_red[tid / WAVE][0] = msum; s_red[tid / WAVE][1] = lsum; }
     __syncthreads();
     if (tid == 0) {
-        double a = 0, b = 0;
-        for (int w = 0; w < RT * RT / WAVE; ++w) { a += s_red[w][0]; b += s_red[w][1]; }
+        double a = 0, bsum = 0;
+        for (int w = 0; w < 256 / WAVE; ++w) { a += s_red[w][0]; bsum += s_red[w][1]; }
         const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         partial[2 * bid] = a;
-        partial[2 * bid + 1] = b;
+        partial[2 * bid + 1] = bsum;
     }
 }
 
-__global__ void __launch_bounds__(RT * RT)
+__global__ void __launch_bounds__(256)
 refine_bwd_kernel(int H, int W, float n_total, float lambda, const float* __restrict__ img,
                   const float* __restrict__ gt, RefineWindow win, const float* __restrict__ dm_dmu1,
                   const float* __restrict__ dm_ds1, const float* __restrict__ dm_ds12, float* __restrict__ g_img)
 {
-    __shared__ float s_m[3][RE][RE + 1];
-    __shared__ float s_h[3][RE][RT + 1];
+    __shared__ float s_m[3][FEH][FEW + 1];
+    __shared__ float s_h[3][FEH][FW + 1];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * RT, y0 = blockIdx.y * RT;
+    const int x0 = blockIdx.x * FW, y0 = blockIdx.y * FH;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int e = tid; e < RE * RE; e += RT * RT) {
-        const int r = e / RE, c = e - r * RE;
+    for (int e = tid; e < FEH * FEW; e += 256) {
+        const int r = e / FEW, c = e - r * FEW;
         const int gy = y0 + r - RH, gx = x0 + c - RH;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         const size_t o = plane + (size_t)gy * W + gx;
@@ -244,34 +273,51 @@ refine_bwd_kernel(int H, int W, float n_total, float lambda, const float* __rest
         s_m[2][r][c] = in ? dm_ds12[o] : 0.0f;
     }
     __syncthreads();
-    for (int e = tid; e < RE * RT; e += RT * RT) {
-        const int r = e / RT, c = e - r * RT;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (tid < FEH * FHG) {
+        const int r = tid / FHG, c0 = (tid - r * FHG) * 4;
+        float mv[3][RW + 3];
+#pragma unroll
+        for (int k = 0; k < RW + 3; ++k)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) mv[q][k] = s_m[q][r][c0 + k];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < RW; ++k) {
+                const float wk = win.w[k];
+                a0 += wk * mv[0][o + k];
+                a1 += wk * mv[1][o + k];
+                a2 += wk * mv[2][o + k];
+            }
+            s_h[0][r][c0 + o] = a0; s_h[1][r][c0 + o] = a1; s_h[2][r][c0 + o] = a2;
+        }
+    }
+    __syncthreads();
+    const int tx = tid & (FW - 1), ty0 = (tid / FW) * 2;
+    const int gx = x0 + tx;
+    float col[3][RW + 1];
+#pragma unroll
+    for (int k = 0; k < RW + 1; ++k)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) col[q][k] = s_h[q][ty0 + k][tx];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int gy = y0 + ty0 + o;
+        if (gy >= H || gx >= W) continue;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
 #pragma unroll
         for (int k = 0; k < RW; ++k) {
             const float wk = win.w[k];
-            a0 += wk * s_m[0][r][c + k];
-            a1 += wk * s_m[1][r][c + k];
-            a2 += wk * s_m[2][r][c + k];
+            b0 += wk * col[0][o + k];
+            b1 += wk * col[1][o + k];
+            b2 += wk * col[2][o + k];
         }
-        s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2;
+        const size_t oo = plane + (size_t)gy * W + gx;
+        const float x = img[oo], y = gt[oo];
+        const float inv_n = 1.0f / n_total;
+        g_img[oo] = (1.0f - lambda) * sgn(x - y) * inv_n - lambda * inv_n * (b0 + 2.0f * x * b1 + y * b2);
     }
-    __syncthreads();
-    const int ty = tid / RT, tx = tid - ty * RT;
-    const int gy = y0 + ty, gx = x0 + tx;
-    if (gy >= H || gx >= W) return;
-    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < RW; ++k) {
-        const float wk = win.w[k];
-        b0 += wk * s_h[0][ty + k][tx];
-        b1 += wk * s_h[1][ty + k][tx];
-        b2 += wk * s_h[2][ty + k][tx];
-    }
-    const size_t o = plane + (size_t)gy * W + gx;
-    const float x = img[o], y = gt[o];
-    const float inv_n = 1.0f / n_total;
-    g_img[o] = (1.0f - lambda) * sgn(x - y) * inv_n - lambda * inv_n * (b0 + 2.0f * x * b1 + y * b2);
 }
 
 __global__ void __launch_bounds__(LOSS_BLOCK)
@@ -310,7 +356,7 @@ static RefineWindow refine_window()
 
 size_t refinement_loss_workspace_bytes(int32_t C, int32_t H, int32_t W)
 {
-    const size_t blocks = (size_t)((W + RT - 1) / RT) * ((H + RT - 1) / RT) * (size_t)C;
+    const size_t blocks = (size_t)((W + FW - 1) / FW) * ((H + FH - 1) / FH) * (size_t)C;
     return align_up(3 * sizeof(float) * (size_t)C * H * W, 256) + blocks * 2 * sizeof(double);
 }
 
@@ -452,13 +498,13 @@ int launch_refinement_loss(int32_t C, int32_t H, int32_t W, float lambda, const 
     const size_t n = (size_t)C * H * W;
     float* maps = reinterpret_cast<float*>(workspace);
     double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + align_up(3 * sizeof(float) * n, 256));
-    const dim3 grid((W + RT - 1) / RT, (H + RT - 1) / RT, C);
+    const dim3 grid((W + FW - 1) / FW, (H + FH - 1) / FH, C);
     const int blocks = (int)(grid.x * grid.y * grid.z);
     const RefineWindow win = refine_window();
-    hipLaunchKernelGGL(refine_fwd_kernel, grid, dim3(RT * RT), 0, stream, H, W, image, gt, win, maps, maps + n,
+    hipLaunchKernelGGL(refine_fwd_kernel, grid, dim3(256), 0, stream, H, W, image, gt, win, maps, maps + n,
                        maps + 2 * n, partial);
     SR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(refine_bwd_kernel, grid, dim3(RT * RT), 0, stream, H, W, (float)n, lambda, image, gt, win, maps,
+    hipLaunchKernelGGL(refine_bwd_kernel, grid, dim3(256), 0, stream, H, W, (float)n, lambda, image, gt, win, maps,
                        maps + n, maps + 2 * n, g_image);
     SR_LAUNCH_CHECK();
     hipLaunchKernelGGL(refine_finish_kernel, dim3(1), dim3(LOSS_BLOCK), 0, stream, blocks, (double)n, lambda, partial,
