@@ -150,9 +150,10 @@ constexpr int RE = RT + 2 * RH;   // 26: tile + halo
 struct RefineWindow { float w[RW]; };
 
 // Round 5: both kernels work on 32x16 tiles with REGISTER-BLOCKED passes — a horizontal work item loads 14 consecutive taps
-// once and produces 4 adjacent outputs, a vertical one loads 12 rows and produces 2 — because the 16x16 / one-output-per-thread
-// form was bound by its LDS reads (22 + 55 per output): refine_fwd 22.1 -> 18.4 us, refine_bwd 16.1 -> 14.4 us (profiles/r05_ab_probes.txt #8).  Every output is
-// still accumulated tap by tap in ascending order with the same fused multiply-adds: the maps and the gradient are bit-identical.
+// once and produces 4 adjacent outputs, a vertical one loads 12 rows and produces 2 (the 16x16 / one-output-per-thread form
+// read LDS 22 + 55 times per output): refine_fwd 22.1 -> 18.4 us, refine_bwd 16.1 -> 14.4 us (profiles/r05_ab_probes.txt #8;
+// what is left is the load -> barrier -> pass -> barrier -> pass -> store chain, not arithmetic).  Every output is still
+// accumulated tap by tap in ascending order with the same fused multiply-adds: the maps and the gradient are bit-identical.
 constexpr int FW = 32, FH = 16;               // tile of the refinement kernels
 constexpr int FEW = FW + 2 * RH, FEH = FH + 2 * RH;   // 42 x 26 with halo
 constexpr int FHG = FW / 4;                   // horizontal work items per row (4 outputs each)
