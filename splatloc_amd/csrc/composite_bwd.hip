@@ -68,10 +68,6 @@
 
 namespace sr {
 
-
-#define BP_T(v)
-#define BP_ADD(i, x)
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NC, bool SP, bool AUX = true>
