@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 9
+#define SPLATRASTER_ABI_VERSION 10
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
@@ -548,6 +548,12 @@ int splatraster_debug_set_small_panel_max_waves(int waves);
  * four for the backward (the forward checkpoints every pixel's state at the quarter points of its tile's list; DESIGN.md §6.3, HISTORY.md §11).
  * 0 = never, < 0 or > 6144 = the built-in default 6144 (one 640x480 frame).  Must not change between a forward and its backward. */
 int splatraster_debug_set_split_max_waves(int waves);
+/* A/B / test hook: the forward of narrow layouts (C <= 4) walks the longest tile lists of a launch with a TEAM of four waves per
+ * quadrant (two evaluate alpha for a step of candidates, one runs the transmittance chain a step behind, one accumulates
+ * another step behind).  -1 (default): on the launches that are also split for the backward (at most 6144
+ * quadrant lists: one 640x480 frame), 0: never, 1: every narrow launch of at most 32768 quadrant lists, 2 (tests): the same and a team for each of the 64 longest lists
+ * whether or not they stand out.  Results never depend on it (bit-identical images, T, n_contrib, segment records). */
+int splatraster_debug_set_fwd_team(int mode);
 /* A/B / test hook: instance count from which the per-instance payload is written with streaming (non-temporal) stores
  * (HISTORY.md §11); < 0 restores the built-in default (8 Mi instances), 0 = always.  Results never depend on it. */
 int splatraster_debug_set_payload_stream_min(int64_t instances);

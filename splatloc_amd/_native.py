@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 9   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 10   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 WARN_LOOKBACK_STALL = 5   # splatraster_poll_errors() only; not an error of any frame
@@ -99,6 +99,7 @@ SYMBOLS = {
     "splatraster_get_window_image_layout": (C.c_int, [_i32, _i32, _i32, C.POINTER(ImageLayout)]),
     "splatraster_debug_set_small_panel_max_waves": (C.c_int, [C.c_int]),
     "splatraster_debug_set_split_max_waves": (C.c_int, [C.c_int]),
+    "splatraster_debug_set_fwd_team": (C.c_int, [C.c_int]),
     "splatraster_debug_set_front_end": (C.c_int, [C.c_int]),
     "splatraster_debug_set_tile_sort_cap": (C.c_int, [C.c_int]),
     "splatraster_debug_set_payload_stream_min": (C.c_int, [C.c_int64]),
@@ -183,6 +184,8 @@ def load(build_if_missing: bool = True):
     # A/B knobs for perf experiments (process-wide debug switches of the library; never set in production)
     if os.environ.get("SPLATRASTER_SPLIT_MAX_WAVES"):
         lib.splatraster_debug_set_split_max_waves(int(os.environ["SPLATRASTER_SPLIT_MAX_WAVES"]))
+    if os.environ.get("SPLATRASTER_FWD_TEAM"):     # -1 auto, 0 one wave per quadrant, 1 teams wherever a launch order exists
+        lib.splatraster_debug_set_fwd_team(int(os.environ["SPLATRASTER_FWD_TEAM"]))
     if os.environ.get("SPLATRASTER_FRONT_END"):   # -1 auto, 0 radix sorts, 1 binned whenever the shape allows
         lib.splatraster_debug_set_front_end(int(os.environ["SPLATRASTER_FRONT_END"]))
     if os.environ.get("SPLATRASTER_TILE_SORT_CAP"):

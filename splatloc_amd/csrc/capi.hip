@@ -752,6 +752,12 @@ int splatraster_debug_set_split_max_waves(int waves)
     return SPLATRASTER_OK;
 }
 
+int splatraster_debug_set_fwd_team(int mode)
+{
+    set_fwd_team(mode < 0 ? -1 : (mode > 2 ? 2 : mode));
+    return SPLATRASTER_OK;
+}
+
 int splatraster_mark_visible(int32_t P, const float* means3D, const float* viewmatrix,
                              const float* projmatrix, uint8_t* present, void* stream)
 {

@@ -224,6 +224,7 @@ constexpr int SPLIT_MAX_WAVES = SR_SPLIT_MAX_WAVES;
 constexpr int SPLIT_MIN_LIST = 256;
 constexpr int SPLIT_PARTS = 4;
 void set_split_max_waves(int waves);   // A/B hook (< 0: default)
+void set_fwd_team(int mode);           // A/B hook: teams of four waves for the longest lists of a narrow launch (-1 automatic, 0 never, 1 whenever possible)
 void set_payload_stream_min(int64_t instances);   // test hook (< 0: default)
 int split_max_waves();
 static inline bool split_lists(int C, int V, int tiles) { return C <= 4 && 4 * V * tiles <= split_max_waves(); }

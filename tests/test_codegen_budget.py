@@ -43,11 +43,15 @@ def _kernel(usage, prefix):
 def test_forward_kernels_have_no_scratch_and_keep_their_occupancy():
     u = _usage("composite_fwd.hip")
     fwd = {int(re.search(r"composite_fwd_kernelILi(\d+)E", k).group(1)): v for k, v in u.items() if "composite_fwd_kernel" in k}
-    assert sorted(fwd) == [1, 2, 3, 4, 8, 16, 32, 35]
-    for nc, k in fwd.items():
+    narrow = {int(re.search(r"composite_fwd_narrow_kernelILi(\d+)E", k).group(1)): v for k, v in u.items() if "composite_fwd_narrow_kernel" in k}
+    mixed = {int(re.search(r"composite_fwd_mixed_kernelILi(\d+)E", k).group(1)): v for k, v in u.items() if "composite_fwd_mixed_kernel" in k}
+    assert sorted(fwd) == [8, 16, 32, 35] and sorted(narrow) == [1, 2, 3, 4] and sorted(mixed) == [1, 2, 3, 4]
+    for nc, k in list(fwd.items()) + list(narrow.items()) + list(mixed.items()):
         assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0, (nc, k)
-    for nc in (1, 2, 3, 4):                      # narrow layouts: 64 registers, 8 waves per SIMD
-        assert fwd[nc]["VGPRs"] <= 64 and fwd[nc]["Occupancy"] == 8, (nc, fwd[nc])
+    for nc in (1, 2, 3, 4):
+        assert narrow[nc]["VGPRs"] <= 64 and narrow[nc]["Occupancy"] == 8, (nc, narrow[nc])     # 64 registers, 8 waves per SIMD
+        # one workgroup of four waves per tile / per quadrant of a long list: five workgroups per CU by LDS, never fewer by registers
+        assert mixed[nc]["VGPRs"] <= 96 and mixed[nc]["Occupancy"] >= 5 and mixed[nc]["LDS Size"] <= 28 * 1024, (nc, mixed[nc])
     assert fwd[35]["VGPRs"] <= 96 and fwd[35]["Occupancy"] >= 5, fwd[35]      # the headline layout: 5 waves per SIMD
     assert fwd[35]["LDS Size"] <= 5700, fwd[35]                               # 28 workgroups per CU by LDS
 

@@ -265,6 +265,44 @@ def test_split_backward_matches_unsplit(C, aux):
     assert_grad_close("dL_dcolors vs oracle", b.np(b.colors.grad), bo["dL_dcolors"])
 
 
+@pytest.mark.parametrize("C,W,H,P,scale", [(4, 256, 256, 40_000, 0.05), (3, 250, 130, 6_000, 0.12), (1, 64, 48, 3_000, 0.3), (2, 16, 16, 700, 0.25)])
+def test_team_forward_changes_nothing(C, W, H, P, scale):
+    """Narrow layouts on a frame that does not fill the machine run the forward with a TEAM of four waves per quadrant (two
+    evaluate alpha for a step of candidates into LDS, one runs the transmittance chain a step behind and leaves the weights,
+    one accumulates colours / depth / segment sums another step behind; composite_fwd.hip).
+    Same operations in the same order as the one-wave kernel: images, depth, alpha, final_T, n_contrib and the segment
+    records the split backward starts from (hence its gradients, in the deterministic-free default mode up to the atomics'
+    order; here compared in the deterministic mode, which does not split, bit for bit) — on deep lists (several steps and
+    chunks per tile), ragged frames, steps with an odd number of candidates and frames with a single tile."""
+    from splatloc_amd import _native
+    lib = _native.load()
+    sc = make_scene(P, W, H, C, seed=300 + C, scale_median=scale)
+    runs = {}
+    try:
+        for mode in (0, 2):     # one wave per quadrant | a team for each of the 64 longest lists, one workgroup per other tile
+            lib.splatraster_debug_set_fwd_team(mode)
+            _native.set_deterministic(True)
+            runs[mode, "det"] = HipRun(sc)
+            _native.set_deterministic(False)
+            runs[mode, "fast"] = HipRun(sc)
+    finally:
+        lib.splatraster_debug_set_fwd_team(-1)
+        _native.set_deterministic(False)
+    for kind in ("det", "fast"):
+        a, b = runs[0, kind], runs[2, kind]
+        assert torch.equal(a.color, b.color) and torch.equal(a.depth, b.depth) and torch.equal(a.alpha, b.alpha), kind
+        assert torch.equal(a.state["n_contrib"], b.state["n_contrib"]) and torch.equal(a.state["final_T"], b.state["final_T"])
+    a, b = runs[0, "det"], runs[2, "det"]
+    for n in ("means3D", "means2D", "opacities", "colors", "scales", "rotations"):
+        assert torch.equal(getattr(a, n).grad, getattr(b, n).grad), n
+    a, b = runs[0, "fast"], runs[2, "fast"]     # (split backward from the segment records of either forward)
+    for n in ("means3D", "opacities", "colors", "scales", "rotations"):
+        assert_grad_close(n, getattr(b, n).grad.cpu().numpy(), getattr(a, n).grad.cpu().numpy(), rtol=1e-4, atol_scale=2e-5)
+    rng = a.state["ranges"].long()
+    if P >= 40_000:
+        assert int((rng[:, 1] - rng[:, 0]).max()) >= 4 * 256
+
+
 def test_streaming_payload_stores_change_nothing():
     """Lists of >= 8 Mi instances write the per-instance payload with non-temporal stores (binning.hip); the hook forces that
     path on a small scene: same payload, images and (deterministic-sum mode) gradients, bit for bit."""

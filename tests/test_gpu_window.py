@@ -138,6 +138,21 @@ def test_window_matches_per_view_calls(cfg):
     _compare(make_scene(**cfg), V)
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+def test_window_with_and_without_forward_teams(mode):
+    """A window of small narrow frames is a launch that does not fill the machine: its longest lists may be walked by teams of
+    four waves (composite_fwd.hip).  Forced on (a team for each of the 64 longest (view, tile) lists, view boundaries inside the
+    launch order) and forced off, the window equals the per-view calls bit for bit, like in the default mode above."""
+    from splatloc_amd import _native
+    lib = _native.load()
+    lib.splatraster_debug_set_fwd_team(mode)
+    try:
+        _compare(make_scene(P=9000, W=176, H=144, C=4, seed=411, scale_median=0.06), 3)
+        _compare(make_scene(P=2000, W=64, H=64, C=3, seed=412, scale_median=0.2), 2)
+    finally:
+        lib.splatraster_debug_set_fwd_team(-1)
+
+
 def test_window_of_4k_frames_takes_three_tile_sort_passes():
     """3840 x 2160 is 32 400 tiles per view: three views are 97 200 (view, tile) keys — 17 bits, so the tile sort runs THREE
     8-bit passes and ends in the other buffer of its ping-pong pair (every other test stays within 16 bits); one view alone is
