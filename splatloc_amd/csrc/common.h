@@ -222,7 +222,10 @@ __host__ __device__ static inline int gacc_row_floats(int C) { return (gacc_mome
 #endif
 constexpr int SPLIT_MAX_WAVES = SR_SPLIT_MAX_WAVES;
 constexpr int SPLIT_MIN_LIST = 256;
-constexpr int SPLIT_PARTS = 4;
+#ifndef SR_SPLIT_PARTS
+#define SR_SPLIT_PARTS 4
+#endif
+constexpr int SPLIT_PARTS = SR_SPLIT_PARTS;
 void set_split_max_waves(int waves);   // A/B hook (< 0: default)
 void set_fwd_team(int mode);           // A/B hook: teams of four waves for the longest lists of a narrow launch (-1 automatic, 0 never, 1 whenever possible)
 void set_payload_stream_min(int64_t instances);   // test hook (< 0: default)

@@ -36,8 +36,17 @@ def bwd_kernel_us():
                      for e in prof.key_averages() if "composite_bwd_kernel" in e.key), 1)
 
 
-workload = sys.argv[2] if len(sys.argv) > 2 else "S2"
-sc = make_workload(workload)
+workload = sys.argv[2] if len(sys.argv) > 2 else "S2"     # a named workload, or P,W,H,C[,noaux] (e.g. 500000,640,480,3,noaux: the refinement frame)
+if "," in workload:
+    from splatloc_amd.synthetic import make_scene
+    f = workload.split(",")
+    sc = make_scene(int(f[0]), int(f[1]), int(f[2]), int(f[3]), seed=2, scale_median=float(os.environ.get("SCALE_MEDIAN", "0.00627")))
+    AUX = not (len(f) > 4 and f[4] == "noaux")
+else:
+    sc = make_workload(workload)
+    AUX = True
+_HipRun = HipRun
+HipRun = lambda sc_, backward=True: _HipRun(sc_, backward=backward, use_depth=AUX, use_alpha=AUX)  # noqa: E731
 raw = C.CDLL(os.environ["SPLATRASTER_LIB"])
 out = (C.c_ulonglong * 17)()
 if VARIANT == "base":

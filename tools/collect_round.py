@@ -22,7 +22,8 @@ names = {"bench_S2.json": "bench.json", "bench_S0.json": "bench_S0.json", "bench
          "stage_pose_refine.json": "stage_pose_refine.json", "scene.json": "scene.json", "scene_replica_scale.json": "scene_replica_scale.json",
          "scene_radix_front_end.json": "scene_radix_front_end.json", "refine_idle.json": "refine_idle.json", "refine_idle_S0.json": "refine_idle_S0.json",
          "refine_idle_radix_front_end.json": "refine_idle_radix_front_end.json", "scene_lists.json": "scene_lists.json",
-         "scene_lists_radix_front_end.json": "scene_lists_radix_front_end.json"}
+         "scene_lists_radix_front_end.json": "scene_lists_radix_front_end.json",
+         "scene_lists_one_wave_forward.json": "scene_lists_one_wave_forward.json", "lone_wave.json": "lone_wave.json"}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p):

@@ -36,5 +36,7 @@ if want idle; then
   SPLATRASTER_FRONT_END=0 python tools/refine_idle.py S2-ref-layout 300 > $O/refine_idle_radix_front_end.json 2>/dev/null
   python tools/scene_lists.py 60 200000 300 > $O/scene_lists.json 2>/dev/null
   SPLATRASTER_FRONT_END=0 python tools/scene_lists.py 60 200000 300 > $O/scene_lists_radix_front_end.json 2>/dev/null
+  SPLATRASTER_FWD_TEAM=0 python tools/scene_lists.py 60 200000 300 > $O/scene_lists_one_wave_forward.json 2>/dev/null
+  python tools/lone_wave.py 4 1000 2000 4000 > $O/lone_wave.json 2>/dev/null
 fi
 ls $O
