@@ -303,6 +303,29 @@ def test_team_forward_changes_nothing(C, W, H, P, scale):
         assert int((rng[:, 1] - rng[:, 0]).max()) >= 4 * 256
 
 
+def test_team_forward_soak():
+    """Random shapes through both forwards of the narrow layouts (tools/soak_team_forward.py runs hundreds): a team's waves meet at
+    barriers and hand values over through LDS — a race would be a rare mismatch, not a reproducible one."""
+    from splatloc_amd import _native
+    lib = _native.load()
+    rng = np.random.default_rng(77)
+    try:
+        for it in range(40):
+            C, W, H = int(rng.integers(1, 5)), int(rng.integers(8, 300)), int(rng.integers(8, 200))
+            sc = make_scene(int(rng.integers(1, 12000)), W, H, C, seed=int(rng.integers(1 << 30)), scale_median=float(rng.choice([0.01, 0.05, 0.2, 0.5])))
+            if it % 2:
+                sc.opacities = sc.opacities * float(rng.choice([0.02, 0.1, 0.5]))
+            outs = {}
+            for mode in (0, 2):
+                lib.splatraster_debug_set_fwd_team(mode)
+                r = HipRun(sc, backward=False)
+                outs[mode] = (r.color, r.depth, r.alpha, r.state["n_contrib"], r.state["final_T"])
+            for a, b in zip(outs[0], outs[2]):
+                assert torch.equal(a, b), (it, C, W, H)
+    finally:
+        lib.splatraster_debug_set_fwd_team(-1)
+
+
 def test_streaming_payload_stores_change_nothing():
     """Lists of >= 8 Mi instances write the per-instance payload with non-temporal stores (binning.hip); the hook forces that
     path on a small scene: same payload, images and (deterministic-sum mode) gradients, bit for bit."""
