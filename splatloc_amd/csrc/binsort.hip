@@ -145,165 +145,6 @@ bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __re
 }
 
 // ---- per-tile sort -------------------------------------------------------------------------
-// Bitonic network on N = THREADS * E keys held E per thread, "blocked": thread t owns elements t E ... t E + E - 1
-// (pads = ~0).  Element i of a merge of size k sorts ascending iff (i & k) == 0; a step of distance j compares i with
-// i ^ j.  Distances below E are compare-exchanges between a thread's own registers (5 VALU instructions per pair),
-// distances inside a wave move the partner's key with DPP / the gfx950 permlane swaps, distances across waves go through
-// LDS.  A wave64 VALU instruction occupies its SIMD for 4 cycles and the first version of this file (256 threads per list,
-// 4 keys per thread, every distance >= 4 an exchange between lanes: 3 700 VALU instructions per wave, 18 M per frame) was
-// bound by exactly that; one wave per list with 16 - 32 keys per lane keeps most distances inside the registers.
-// Keys are distinct — (depth bits, row) — except the pads, which are interchangeable: "take the partner's key" is (y < x)
-// for the keeper of the minimum and its negation for the keeper of the maximum: one 64-bit compare and a mask xor.
-
-// value of lane (l ^ D) for D = 1, 2, 4, 8, 16, 32: DPP for the distances inside a row of 16 lanes, the permlane swaps of
-// gfx950 for 16 and 32
-template <int D>
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
-{
-    const int iv = (int)v;
-    if (D == 1) return (uint32_t)__builtin_amdgcn_mov_dpp(iv, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
-    if (D == 2) return (uint32_t)__builtin_amdgcn_mov_dpp(iv, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
-    if (D == 4) {   // banks 0, 2 read lane + 4 (row_ror:12), banks 1, 3 read lane - 4 (row_ror:4)
-        const int a = __builtin_amdgcn_mov_dpp(iv, 0x12C, 0xf, 0x5, true);
-        return (uint32_t)__builtin_amdgcn_update_dpp(a, iv, 0x124, 0xf, 0xA, false);
-    }
-    if (D == 8) return (uint32_t)__builtin_amdgcn_mov_dpp(iv, 0x128, 0xf, 0xf, true);   // row_ror:8
-    if (D == 16) {  // rows 0 <-> 1, 2 <-> 3
-        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-        return ((__lane_id() & 16) == 0) ? r[1] : r[0];
-    }
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return ((__lane_id() & 32) == 0) ? r[1] : r[0];
-}
-template <int D>
-__device__ __forceinline__ uint64_t lane_xor64(uint64_t v)
-{
-    return ((uint64_t)lane_xor<D>((uint32_t)(v >> 32)) << 32) | lane_xor<D>((uint32_t)v);
-}
-// One distance between lanes.  All partner keys are fetched, then all compares issued, then all selects: a compare writes a lane
-// mask that a scalar xor and two selects consume — written element by element that chain (VALU -> SALU -> VALU) stalls the wave
-// at every link (SQ_WAIT_INST_ANY was as large as the VALU time itself with one or two waves per SIMD).
-template <int E, int D>
-__device__ __forceinline__ void lane_step(uint64_t (&x)[E], bool keep_max)
-{
-    if constexpr (D >= 16) {
-        // the permlane swaps hand BOTH partners' keys to both lanes: L (the lane with bit D clear) and H.  The keeper of the
-        // minimum takes H iff H < L, the keeper of the maximum iff not: one compare, one mask xor, two selects per key
-        uint64_t L[E], H[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t lo = (uint32_t)x[e], hi = (uint32_t)(x[e] >> 32);
-            if constexpr (D == 16) {
-                const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-                const auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-                L[e] = ((uint64_t)c[0] << 32) | a[0];
-                H[e] = ((uint64_t)c[1] << 32) | a[1];
-            } else {
-                const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-                const auto c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-                L[e] = ((uint64_t)c[0] << 32) | a[0];
-                H[e] = ((uint64_t)c[1] << 32) | a[1];
-            }
-        }
-        bool th[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) th[e] = (H[e] < L[e]) != keep_max;
-#pragma unroll
-        for (int e = 0; e < E; ++e) x[e] = th[e] ? H[e] : L[e];
-    } else {
-        uint64_t y[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) y[e] = lane_xor64<D>(x[e]);
-        bool take[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) take[e] = (y[e] < x[e]) != keep_max;
-#pragma unroll
-        for (int e = 0; e < E; ++e) x[e] = take[e] ? y[e] : x[e];
-    }
-}
-__device__ __forceinline__ void cmpx_reg(uint64_t& a, uint64_t& b, bool desc)
-{
-    const bool sw = (a > b) != desc;
-    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
-    a = lo;
-    b = hi;
-}
-// one distance J inside the thread: all compares, then all selects
-template <int E, int J>
-__device__ __forceinline__ void reg_step(uint64_t (&x)[E], bool desc)
-{
-    bool sw[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (!(e & J)) sw[e] = (x[e] > x[e | J]) != desc;
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (!(e & J)) {
-            const uint64_t a = x[e], b = x[e | J];
-            x[e] = sw[e] ? b : a;
-            x[e | J] = sw[e] ? a : b;
-        }
-}
-
-template <int E, int THREADS>
-__device__ __forceinline__ void sort_regs(uint64_t (&x)[E], uint64_t* s /*LDS [THREADS * min(E, BIN_EX_REGS)], THREADS > 64 only*/)
-{
-    constexpr uint32_t N = (uint32_t)THREADS * E;
-    const uint32_t t = threadIdx.x, i0 = t * E;
-    // merges inside the thread (sizes 2 ... E/2): every direction is a compile-time constant
-#pragma unroll
-    for (int k = 2; k < E; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                if (!(e & j)) cmpx_reg(x[e], x[e | j], (e & k) != 0);
-        }
-    }
-#pragma unroll 1
-    for (uint32_t k = (E > 1 ? E : 2); k <= N; k <<= 1) {
-        const bool desc = (i0 & k) != 0;   // k >= E: one direction per thread
-#pragma unroll 1
-        for (uint32_t j = k >> 1; j >= (uint32_t)E; j >>= 1) {
-            const uint32_t d = j / E;                           // thread distance
-            const bool keep_max = (((t & d) == 0) == desc);     // the lower partner keeps the minimum of an ascending merge
-            if (THREADS == WAVE || d < (uint32_t)WAVE) {
-                switch (d) {
-                    case 1: lane_step<E, 1>(x, keep_max); break;
-                    case 2: lane_step<E, 2>(x, keep_max); break;
-                    case 4: lane_step<E, 4>(x, keep_max); break;
-                    case 8: lane_step<E, 8>(x, keep_max); break;
-                    case 16: lane_step<E, 16>(x, keep_max); break;
-                    default: lane_step<E, 32>(x, keep_max); break;
-                }
-            } else {   // across waves: through LDS, BIN_EX_REGS registers at a time (element e of thread t at s[(e % G) * THREADS + t])
-                constexpr int G = E < BIN_EX_REGS ? E : BIN_EX_REGS;
-#pragma unroll
-                for (int e0 = 0; e0 < E; e0 += G) {
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < G; ++e) s[e * THREADS + t] = x[e0 + e];
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < G; ++e) {
-                        const uint64_t y = s[e * THREADS + (t ^ d)];
-                        const bool take = (y < x[e0 + e]) != keep_max;
-                        x[e0 + e] = take ? y : x[e0 + e];
-                    }
-                }
-            }
-        }
-        if (E > 8) reg_step<E, (E > 8 ? 8 : 0)>(x, desc);
-        if (E > 4) reg_step<E, (E > 4 ? 4 : 0)>(x, desc);
-        if (E > 2) reg_step<E, (E > 2 ? 2 : 0)>(x, desc);
-        if (E > 1) reg_step<E, (E > 1 ? 1 : 0)>(x, desc);
-    }
-}
-
-// LDS index of list position i for the rows' transposition (blocked in, striped out): one pad word per 32 keeps both the
-// writes of thread t (positions t E + e) and the reads (positions r THREADS + t) free of bank conflicts
-__device__ __forceinline__ uint32_t pad32(uint32_t i) { return i + (i >> 5); }
-
 // what payload_kernel (binning.hip) writes for the sorted list of one (view, tile), plus the lists themselves; row_at(q) =
 // the row of list position q.  The record gathers of U positions are requested before the first one is used.
 template <int THREADS, typename RowAt>
@@ -343,24 +184,6 @@ __device__ __forceinline__ void write_tile(RowAt row_at, uint32_t n, uint32_t st
 }
 
 // loads the list (blocked), sorts it in registers and leaves the rows in LDS at pad32(list position)
-template <int E, int THREADS>
-__device__ __forceinline__ void sort_list(const uint64_t* __restrict__ keys, uint32_t n, uint64_t* s_ex, uint32_t* s_rows)
-{
-    uint64_t x[E];
-    const uint32_t i0 = threadIdx.x * E;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const uint32_t i = i0 + e;
-        const uint64_t v = keys[i < n ? i : n - 1];
-        x[e] = i < n ? v : ~0ull;
-    }
-    sort_regs<E, THREADS>(x, s_ex);
-    if (THREADS > WAVE) __syncthreads();   // (s_rows may alias the exchange buffer)
-#pragma unroll
-    for (int e = 0; e < E; ++e) s_rows[pad32(i0 + e)] = (uint32_t)x[e] & 0xFFFFFFu;
-    if (THREADS > WAVE) __syncthreads(); else wave_order();
-}
-
 // Normalised bitonic network on n keys in GLOBAL memory (lists beyond the 16 384 keys the work-list launch holds in
 // registers): merge size k = 2, 4, ...; the first step of a merge pairs i with its MIRROR inside the k-block, the following
 // steps pair i with i + j, j = k/4 ... 1.  Every compare-exchange is ascending (minimum to the lower index), so elements
@@ -605,27 +428,44 @@ bin_sort_tile_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* 
     SR_STAMP(5);
 }
 
-// Second sort launch: a few 1024-thread blocks stride over the work list; up to BIN_SORT_BIG keys in registers (8 or 16 per
-// thread), the global network beyond.
+// Second sort launch: 1024-thread blocks stride over the work list; up to BIN_SORT_BIG keys with the SAME LDS network as the tile
+// kernel (139 KB of the CU's 160 KB: one block per CU), the global network beyond.  (Round 5 first held these lists in the
+// registers of the block — 8 or 16 keys per thread, 64-bit integer compares, every distance beyond a wave exchanged through LDS
+// four registers at a time: ~70 us per list, 87 us of a refinement iteration at Replica scale where 15 - 40 lists of a frame
+// exceed 4 096 keys; profiles/r05_ab_probes.txt #11.)
 __global__ void __launch_bounds__(1024)
 bin_sort_big_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* __restrict__ table,
                     const uint32_t* __restrict__ total, uint64_t* __restrict__ keys, const float4* __restrict__ rec, BinView b,
                     const uint32_t* __restrict__ big_count, const uint32_t* __restrict__ big_list)
 {
-    constexpr int ROWS_WORDS = BIN_SORT_BIG + BIN_SORT_BIG / 32, EX_WORDS = 2 * 1024 * BIN_EX_REGS;
-    __shared__ uint64_t s_buf[(ROWS_WORDS > EX_WORDS ? ROWS_WORDS : EX_WORDS) / 2];
-    uint32_t* s_rows = reinterpret_cast<uint32_t*>(s_buf);
-    const uint32_t nwork = *big_count;
+    __shared__ double s_keys[BIN_SORT_BIG + BIN_SORT_BIG / 16];
+    uint64_t* s_bits = reinterpret_cast<uint64_t*>(s_keys);
+    const uint32_t nwork = *big_count, t = threadIdx.x;
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         const uint32_t gt = big_list[wi];
         uint32_t start, n;
         tile_span(gt, gtiles, nchunk, table, total, start, n);
         if (n <= (uint32_t)BIN_SORT_BIG) {
+            uint32_t M = 4;
+            while ((1u << M) < n) ++M;
+            const uint32_t N = 1u << M;
             const uint64_t* src = keys + start;
-            if (n <= 4096u) sort_list<4, 1024>(src, n, s_buf, s_rows);
-            else if (n <= 8192u) sort_list<8, 1024>(src, n, s_buf, s_rows);
-            else sort_list<16, 1024>(src, n, s_buf, s_rows);
-            write_tile<1024>([&](uint32_t q) { return s_rows[pad32(q)]; }, n, start, gt, gx, tiles, rec, b);
+            for (uint32_t i0 = t; i0 < N; i0 += 8 * 1024) {   // eight loads in flight per lane
+                uint64_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t i = i0 + u * 1024;
+                    v[u] = src[i < n ? i : n - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t i = i0 + u * 1024;
+                    if (i < N) s_bits[pidx(i)] = i < n ? v[u] : 0x7FF0000000000000ull;   // pad: +infinity
+                }
+            }
+            __syncthreads();
+            sort_lds_f64<true>(s_keys, M);
+            write_tile<1024>([&](uint32_t q) { return (uint32_t)s_bits[pidx(q)] & 0xFFFFFFu; }, n, start, gt, gx, tiles, rec, b);
         } else {
             uint64_t* list = keys + start;
             bitonic_sort_global<1024>(list, n);

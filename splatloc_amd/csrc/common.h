@@ -178,8 +178,7 @@ constexpr int BIN_AUTO_MAX_TILES = SR_BIN_AUTO_MAX_TILES;
 constexpr int BIN_SORT_TILE_NARROW = 2048, BIN_SORT_TILE_WIDE = 4096;   // longest list of the per-tile launch's two instantiations
 constexpr int BIN_WIDE_FRAMES = 64;         // frames the wide instantiation stays selected after a list beyond 2048 was seen
 void set_bin_tile_cap(int cap);             // test / A-B hook: 2048 or 4096 forces an instantiation, anything else: follow the hint
-constexpr int BIN_EX_REGS = 4;              // keys per thread that cross waves through LDS at a time
-constexpr int BIN_SORT_BIG = 16384, BIN_BIG_BLOCKS = 32; // the work-list launch for longer lists (keys in registers of 1024 threads, blocks)
+constexpr int BIN_SORT_BIG = 16384, BIN_BIG_BLOCKS = 128; // the work-list launch for longer lists (keys in 139 KB of LDS, 1024 threads; blocks)
 void set_bin_mode(int mode);   // -1 auto, 0 radix front end always, 1 binned whenever the shape allows
 size_t bin_table_entries(int32_t P, int32_t V, int tiles);
 size_t bin_scratch_bytes(int32_t P, int32_t V, int tiles);
