@@ -26,8 +26,8 @@
 //                          32 keys per lane 73 us; this form 39 us, of which ~20 us are the 92 MB of payload traffic.)
 // (depth bits, row) is unique inside a tile, so the sorted list is THE (tile, depth, index) order of the lineage's stable
 // 64-bit sort — bit-identical point lists and ranges to the radix front end (tests/test_gpu_binsort.py runs both).
-// Lists beyond the first launch's capacity go to a work list served by a second launch (1024 threads x 4 ... 16 keys in
-// registers, DPP / LDS exchanges; beyond 16 384 keys a normalised network runs on the global buffer: slow, correct).
+// Lists beyond the first launch's capacity go to a work list served by a second launch (1024 threads, the same LDS network on
+// up to 16 384 keys in 139 KB of LDS; beyond 16 384 keys a normalised network runs on the global buffer: slow, correct).
 //
 // Compiled with -ffp-contract=off like preprocess.hip / binning.hip: the rect arithmetic must round like preprocess's.
 #include <mutex>
