@@ -551,7 +551,7 @@ int splatraster_debug_set_split_max_waves(int waves);
 /* A/B / test hook: the forward of narrow layouts (C <= 4) walks the longest tile lists of a launch with a TEAM of four waves per
  * quadrant (two evaluate alpha for a step of candidates, one runs the transmittance chain a step behind, one accumulates
  * another step behind).  -1 (default): on the launches that are also split for the backward (at most 6144
- * quadrant lists: one 640x480 frame), 0: never, 1: every narrow launch of at most 32768 quadrant lists, 2 (tests): the same and a team for each of the 64 longest lists
+ * quadrant lists: one 640x480 frame), 0: never, 1: every narrow launch of at most 32768 quadrant lists, 2 (tests): the same and a team for each of the 128 longest lists
  * whether or not they stand out.  Results never depend on it (bit-identical images, T, n_contrib, segment records). */
 int splatraster_debug_set_fwd_team(int mode);
 /* A/B / test hook: instance count from which the per-instance payload is written with streaming (non-temporal) stores

@@ -854,7 +854,7 @@ __device__ __forceinline__ void team_quadrant(SR_FWD_PARAMS, int gtile, int quad
 // the team's buffers).  A team costs ~1.7 x the SIMD time of a lone wave and finishes its list 2.3 x sooner: worth it for the lists
 // the whole launch waits for, a loss for all of them (a uniform cloud: forward 69 -> 86 us with a team for every list).
 #ifndef SR_FWD_TEAM_MAX
-#define SR_FWD_TEAM_MAX 64
+#define SR_FWD_TEAM_MAX 128   // (32: room 97.6 / Replica scale 180.1 us of forward; 64: 84.7 / 157.7; 128: 82.3 / 147.1; 256: 81.5 / 141.0, uniform cloud 68.1 -> 71.4)
 #endif
 #ifndef SR_FWD_TEAM_MIN_LIST
 #define SR_FWD_TEAM_MIN_LIST 512

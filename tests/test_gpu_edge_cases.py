@@ -279,7 +279,7 @@ def test_team_forward_changes_nothing(C, W, H, P, scale):
     sc = make_scene(P, W, H, C, seed=300 + C, scale_median=scale)
     runs = {}
     try:
-        for mode in (0, 2):     # one wave per quadrant | a team for each of the 64 longest lists, one workgroup per other tile
+        for mode in (0, 2):     # one wave per quadrant | a team for each of the 128 longest lists, one workgroup per other tile
             lib.splatraster_debug_set_fwd_team(mode)
             _native.set_deterministic(True)
             runs[mode, "det"] = HipRun(sc)

@@ -141,7 +141,7 @@ def test_window_matches_per_view_calls(cfg):
 @pytest.mark.parametrize("mode", [0, 2])
 def test_window_with_and_without_forward_teams(mode):
     """A window of small narrow frames is a launch that does not fill the machine: its longest lists may be walked by teams of
-    four waves (composite_fwd.hip).  Forced on (a team for each of the 64 longest (view, tile) lists, view boundaries inside the
+    four waves (composite_fwd.hip).  Forced on (a team for each of the 128 longest (view, tile) lists, view boundaries inside the
     launch order) and forced off, the window equals the per-view calls bit for bit, like in the default mode above."""
     from splatloc_amd import _native
     lib = _native.load()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak of the narrow-layout forward's team mode (composite_fwd.hip): random scenes (1 - 4 channels, 8 - 400 x 8 - 300 pixels, 1 - 30 000
-Gaussians, five scale classes, translucent or not) rendered with one wave per quadrant and with a team for each of the 64 longest
+Gaussians, five scale classes, translucent or not) rendered with one wave per quadrant and with a team for each of the 128 longest
 lists; images, depth, alpha, n_contrib and final_T must be bit-identical.  The roles of a team meet at barriers and exchange values
 through LDS: a race would show up here as a rare mismatch.     usage: python tools/soak_team_forward.py [seed=0] [scenes=150]"""
 import sys, torch, numpy as np
