@@ -93,11 +93,14 @@ bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __re
     uint32_t* col = table + (size_t)v * tiles * nchunk + chunk;
     if (!SCATTER && big_count && t == 0 && chunk == 0 && v == 0) *big_count = 0u;
     if (t == 0) s_qn = 0u;
-    const int i0 = chunk * (BIN_THREADS * ROWS);
+    // A block's rows are 64-row groups INTERLEAVED over the whole view (group j of the block = group j nchunk + chunk of the view):
+    // a map's rows are spatially coherent — one 2048-row run can be a near wall whose every Gaussian covers hundreds of tiles —
+    // and a block of consecutive rows then walks a hundred times the rects of its neighbours (Replica scale: scatter 49 us).
+    auto row_of = [&](int k) { return ((k * (BIN_THREADS / WAVE) + (t >> 6)) * nchunk + chunk) * WAVE + (t & (WAVE - 1)); };
     float4 p[ROWS];   // every row's record is requested before the first one is used
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
-        const int i = i0 + k * BIN_THREADS + t;
+        const int i = row_of(k);
         p[k] = i < P ? rec[2 * ((size_t)v * P + i)] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int k = t; k < tiles; k += BIN_THREADS) s_bin[k] = SCATTER ? col[(size_t)k * nchunk] : 0u;
@@ -105,7 +108,7 @@ bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __re
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         if (!(p[k].w > 0.0f)) continue;   // culled rows (and the padding beyond P) carry radius 0
-        const uint32_t g = (uint32_t)v * (uint32_t)P + (uint32_t)(i0 + k * BIN_THREADS + t);
+        const uint32_t g = (uint32_t)v * (uint32_t)P + (uint32_t)row_of(k);
         const Rect r = rect_of(p[k], gx, gy);
         const uint64_t key = ((uint64_t)__float_as_uint(p[k].z) << 32) | g;
         const int w = r.x1 - r.x0, h = r.y1 - r.y0;
@@ -481,7 +484,7 @@ void set_bin_mode(int mode) { g_bin_mode = mode < 0 ? -1 : (mode > 1 ? 1 : mode)
 
 size_t bin_table_entries(int32_t P, int32_t V, int tiles)
 {
-    return (size_t)(V > 0 ? V : 1) * (size_t)tiles * (size_t)bin_chunks(P, tiles);
+    return (size_t)(V > 0 ? V : 1) * (size_t)tiles * (size_t)bin_chunks(P, V, tiles);
 }
 
 size_t bin_scratch_bytes(int32_t P, int32_t V, int tiles)
@@ -506,15 +509,14 @@ int launch_bin_count(const splatraster_settings& s, int32_t P, int32_t V, const 
                      hipStream_t stream)
 {
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
-    const int tiles = gx * gy, nchunk = bin_chunks(P, tiles);
-    if (bin_chunk_rows(tiles) == BIN_THREADS * 2)
-        hipLaunchKernelGGL((bin_walk_kernel<2, false>), dim3((unsigned)nchunk, (unsigned)V), dim3(BIN_THREADS),
-                           (size_t)tiles * sizeof(uint32_t), stream, P, tiles, gx, gy, nchunk, g.rec, table,
-                           (uint64_t*)nullptr, g.total + 2);
-    else
-        hipLaunchKernelGGL((bin_walk_kernel<8, false>), dim3((unsigned)nchunk, (unsigned)V), dim3(BIN_THREADS),
-                           (size_t)tiles * sizeof(uint32_t), stream, P, tiles, gx, gy, nchunk, g.rec, table,
-                           (uint64_t*)nullptr, g.total + 2);
+    const int tiles = gx * gy, nchunk = bin_chunks(P, V, tiles);
+#define SR_BIN_WALK(ROWS, SC, ...) hipLaunchKernelGGL((bin_walk_kernel<ROWS, SC>), dim3((unsigned)nchunk, (unsigned)V), dim3(BIN_THREADS), \
+                                                      (size_t)tiles * sizeof(uint32_t), stream, P, tiles, gx, gy, nchunk, g.rec, __VA_ARGS__)
+    switch (bin_rows_per_thread(P, V, tiles)) {
+        case 1: SR_BIN_WALK(1, false, table, (uint64_t*)nullptr, g.total + 2); break;
+        case 2: SR_BIN_WALK(2, false, table, (uint64_t*)nullptr, g.total + 2); break;
+        default: SR_BIN_WALK(8, false, table, (uint64_t*)nullptr, g.total + 2); break;
+    }
     SR_LAUNCH_CHECK();
     return exclusive_scan_u32((int64_t)bin_table_entries(P, V, tiles), table, g.total, scan_tmp, stream, true);
 }
@@ -545,17 +547,15 @@ int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V,
                             const uint32_t* table, const BinView& b, uint64_t* keys, uint32_t* big_list, hipStream_t stream)
 {
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
-    const int tiles = gx * gy, nchunk = bin_chunks(P, tiles);
+    const int tiles = gx * gy, nchunk = bin_chunks(P, V, tiles);
     const int gtiles = V * tiles;
     (void)R;
-    if (bin_chunk_rows(tiles) == BIN_THREADS * 2)
-        hipLaunchKernelGGL((bin_walk_kernel<2, true>), dim3((unsigned)nchunk, (unsigned)V), dim3(BIN_THREADS),
-                           (size_t)tiles * sizeof(uint32_t), stream, P, tiles, gx, gy, nchunk, g.rec,
-                           const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr);
-    else
-        hipLaunchKernelGGL((bin_walk_kernel<8, true>), dim3((unsigned)nchunk, (unsigned)V), dim3(BIN_THREADS),
-                           (size_t)tiles * sizeof(uint32_t), stream, P, tiles, gx, gy, nchunk, g.rec,
-                           const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr);
+    switch (bin_rows_per_thread(P, V, tiles)) {
+        case 1: SR_BIN_WALK(1, true, const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr); break;
+        case 2: SR_BIN_WALK(2, true, const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr); break;
+        default: SR_BIN_WALK(8, true, const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr); break;
+    }
+#undef SR_BIN_WALK
     SR_LAUNCH_CHECK();
     uint32_t* big_count = g.total + 2;
     int dev = 0;

@@ -166,10 +166,20 @@ int exclusive_scan_u32(int64_t n, uint32_t* inout, uint32_t* total, void* tmp, h
 
 // ---- tile-binned front end (binsort.hip): counting sort by (view, tile) + one LDS sort per tile ----------------
 constexpr int BIN_THREADS = 1024;           // threads of a count / scatter block
-// rows of one view per count / scatter block: 2048 (2 per thread) — every CU gets a block at SplatLoc's sizes — unless the frame
-// has so many tiles that the (tile, chunk) table would outgrow the rows it describes: then 8192 (8 per thread)
-static inline int bin_chunk_rows(int tiles) { return BIN_THREADS * (tiles <= 2048 ? 2 : 8); }
-static inline int bin_chunks(int32_t P, int tiles) { return (P + bin_chunk_rows(tiles) - 1) / bin_chunk_rows(tiles); }
+// rows of one view per count / scatter block: 2048 (2 per thread), 1024 when that would leave CUs without a block (one frame of a
+// 200k-Gaussian map: 96 blocks of 2048 rows on 256 CUs), 8192 (8 per thread) when the frame has so many tiles that the
+// (tile, chunk) table would outgrow the rows it describes
+#ifndef SR_BIN_SMALL_BLOCKS
+#define SR_BIN_SMALL_BLOCKS 128      // launches with fewer 2048-row blocks than this use 1024-row blocks (196k rows: walk + scan 39.5 -> 32.9 us; 500k: 29.8 -> 35.5)
+#endif
+static inline int bin_rows_per_thread(int32_t P, int32_t V, int tiles)
+{
+    if (tiles > 2048) return 8;
+    const int64_t blocks2 = (int64_t)(V > 0 ? V : 1) * ((P + 2 * BIN_THREADS - 1) / (2 * BIN_THREADS));
+    return blocks2 < SR_BIN_SMALL_BLOCKS ? 1 : 2;
+}
+static inline int bin_chunk_rows(int32_t P, int32_t V, int tiles) { return BIN_THREADS * bin_rows_per_thread(P, V, tiles); }
+static inline int bin_chunks(int32_t P, int32_t V, int tiles) { return (P + bin_chunk_rows(P, V, tiles) - 1) / bin_chunk_rows(P, V, tiles); }
 constexpr int BIN_MAX_TILES = 16384;        // tiles per view: the LDS histogram of a count / scatter block (64 KB)
 #ifndef SR_BIN_AUTO_MAX_TILES
 #define SR_BIN_AUTO_MAX_TILES 6144          // (view, tile) lists up to which the binned front end is the default
