@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-tile list lengths and the refinement iteration's kernel table on a RECONSTRUCTED synthetic room (splatloc_amd.scene):
 what the tile lists of a map look like (a room is not the uniform cloud of the S* workloads), and which front end serves them.
-usage: python tools/scene_lists.py [keyframes=60] [truth=200000] [refine=300]      (front end: SPLATRASTER_FRONT_END)"""
+usage: python tools/scene_lists.py [keyframes=60] [truth=200000] [refine=300] [W=640] [H=480]      (front end: SPLATRASTER_FRONT_END)"""
 import json
 import os
 import sys
@@ -21,7 +21,9 @@ def main():
     truth = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000
     refine = int(sys.argv[3]) if len(sys.argv) > 3 else 300
     dev = torch.device("cuda:0")
-    frames, _ = synthetic_keyframes(K, 640, 480, P_truth=truth, seed=0, device=dev)
+    W = int(sys.argv[4]) if len(sys.argv) > 4 else 640
+    H = int(sys.argv[5]) if len(sys.argv) > 5 else 480
+    frames, _ = synthetic_keyframes(K, W, H, P_truth=truth, seed=0, device=dev)
     pipe = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
     bg = torch.zeros(3, device=dev)
     model = SceneModel(DEFAULT_CONFIG, dev)
@@ -35,7 +37,7 @@ def main():
                                            model._opacity, extra=model._kp_score)
         act = {"scales": sca, "rotations": rot, "opacities": opa, "colors": col}
     for f in frames[:: max(K // 6, 1)]:
-        rs = GaussianRasterizationSettings(480, 640, f.tanfovx, f.tanfovy, bg, 1.0, f.world_view_transform, f.full_proj_transform,
+        rs = GaussianRasterizationSettings(H, W, f.tanfovx, f.tanfovy, bg, 1.0, f.world_view_transform, f.full_proj_transform,
                                            0, f.camera_center, False, False)
         m3 = model._xyz.detach().requires_grad_(True)
         color, depth, alpha, radii = GaussianRasterizer(raster_settings=rs)(
@@ -43,7 +45,7 @@ def main():
             scales=act["scales"], rotations=act["rotations"], cov3D_precomp=None)
         fn = color.grad_fn
         sv = fn.saved_tensors
-        st = introspect.forward_state((sv[12], sv[13], sv[14]), P, 640, 480, fn.num_rendered)
+        st = introspect.forward_state((sv[12], sv[13], sv[14]), P, W, H, fn.num_rendered)
         lens = (st["ranges"][:, 1] - st["ranges"][:, 0]).long().cpu()
         out["views"].append({"uid": f.uid, "R": int(fn.num_rendered), "mean": round(float(lens.float().mean()), 1),
                              "max": int(lens.max()), "over_1024": int((lens > 1024).sum()), "over_2048": int((lens > 2048).sum()),
