@@ -61,7 +61,9 @@ def _check_vs_lineage_literal(run: HipRun, f: dict, b: dict, grad_frac: float):
     dd = np.abs(run.np(run.depth)[0] - f["depth"][0])
     assert (dd > IMG_TOL * dscale).mean() <= FLIP_FRAC and dd.max() <= (FLIP_STEP + 1e-5) * dscale
     # gradients: a flipped (pixel, Gaussian) pair moves that Gaussian's sums by one pixel's worth
-    kw = dict(allow_frac=grad_frac, outlier_factor=50.0)
+    # (measured, tools/lineage_stats.py: no element off at S0 and S2-ref-layout; at S2 at most 1.3e-6 of the elements, by at most
+    #  7.7 x the tolerance)
+    kw = dict(allow_frac=grad_frac, outlier_factor=20.0)
     assert_grad_close("dL_dmeans3D", run.np(run.means3D.grad), b["dL_dmeans3D"], **kw)
     assert_grad_close("dL_dmeans2D", run.np(run.means2D.grad), b["dL_dmeans2D"], **kw)
     assert_grad_close("dL_dopacities", run.np(run.opacities.grad), b["dL_dopacities"], **kw)
@@ -77,7 +79,7 @@ def test_hip_vs_lineage_literal_oracle_mode(name):
     sc = make_workload(name)
     f, b = _mode1(sc)
     run = HipRun(sc)
-    _check_vs_lineage_literal(run, f, b, grad_frac=1e-3)
+    _check_vs_lineage_literal(run, f, b, grad_frac=2e-5)
 
 
 def _dense_case(P, W, H, C, seed, use_sh=False, deg=0, use_cov=False, mod=1.0):
