@@ -60,12 +60,13 @@ struct StageTimer {
 };
 
 // ---- host landing slot of the early instance count ---------------------------------------
-// One pinned buffer + one event per host thread (and device): the copy of the per-block sums is
-// enqueued right after preprocess, the depth sort and scan are enqueued behind it, and the
-// host waits on the EVENT only — the GPU keeps working while the caller sizes and allocates
-// the binning buffer.
+// One pinned, device-mapped buffer + one event per host thread (and device): preprocess_kernel writes its per-(view, block)
+// sums straight into it (round 5: a 4-us copy operation used to sit between preprocess and the next kernel of every frame), the
+// event is recorded behind preprocess, the depth sort and scan are enqueued behind it, and the host waits on the EVENT only —
+// the GPU keeps working while the caller sizes and allocates the binning buffer.
 struct HostSlot {
-    uint32_t* p = nullptr;
+    uint32_t* p = nullptr;    // host address
+    uint32_t* dp = nullptr;   // the same memory as the device addresses it
     size_t cap = 0;  // elements
     hipEvent_t ev = nullptr;
     int device = -1;
@@ -80,9 +81,11 @@ static int host_slot(size_t n, HostSlot** out)
     if (s.cap < n) {
         if (s.p) (void)hipHostFree(s.p);
         s.p = nullptr;
+        s.dp = nullptr;
         s.cap = 0;
         const size_t cap = n < 4096 ? 4096 : n + n / 2;
-        SR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.p), sizeof(uint32_t) * cap, hipHostMallocPortable));
+        SR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.p), sizeof(uint32_t) * cap, hipHostMallocMapped | hipHostMallocPortable));
+        SR_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dp), s.p, 0));
         s.cap = cap;
     }
     if (!s.ev || s.device != dev) {
@@ -398,6 +401,11 @@ static int window_geometry(const splatraster_settings* s, int32_t V, const splat
     char* base = reinterpret_cast<char*>(geometry);
     const WinCams cams = make_cams(V, views);
     const BinScratch bins = bin_scratch(*s, P, V, geometry);
+    HostSlot* slot = nullptr;
+    const size_t nblk = (size_t)preprocess_blocks(P);
+    st = host_slot(nblk * (size_t)V, &slot);
+    if (st) return st;
+    g.block_tiles = slot->dp;     // the per-(view, block) instance sums land in host memory
     {
         StageTimer t(SPLATRASTER_STAGE_PREPROCESS, stream);
         // the look-back state of the depth sort and of the scan is cleared by preprocess_kernel
@@ -411,11 +419,6 @@ static int window_geometry(const splatraster_settings* s, int32_t V, const splat
                                    reinterpret_cast<uint32_t*>(base + L.scan_tmp), (uint32_t)(scan_state_bytes(n) / 4), stream);
     }
     if (st) return st;
-    HostSlot* slot = nullptr;
-    const size_t nblk = (size_t)preprocess_blocks(P);
-    st = host_slot(nblk * (size_t)V, &slot);
-    if (st) return st;
-    SR_HIP_CHECK(hipMemcpyAsync(slot->p, g.block_tiles, sizeof(uint32_t) * nblk * (size_t)V, hipMemcpyDeviceToHost, stream));
     SR_HIP_CHECK(hipEventRecord(slot->ev, stream));
     if (bins.on) {
         // binned front end (binsort.hip): per-(tile, chunk) counts + their scan instead of the depth sort + offsets scan
