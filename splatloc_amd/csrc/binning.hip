@@ -8,6 +8,7 @@
 //   2. instances are emitted IN DEPTH ORDER, one thread per instance (coalesced writes);
 //   3. a stable sort of the R instances on the tile id only (<= 16 bits, 2 passes).
 // Because both sorts are stable, ties resolve exactly as in the 64-bit formulation.
+#include "tile_order.h"
 #include "composite_common.h"
 
 namespace sr {
@@ -208,41 +209,12 @@ int launch_payload(const splatraster_settings& s, int32_t V, int64_t R, const Ge
 // 338 us ideal).  One small block buckets the (view, tile) lists by length (16 entries per bucket, longest first); the
 // compositing kernels map block -> tile_order[block's tile slot].  Which tile a wave works on changes, never what it computes.
 // Only for launches of a few rounds (use_tile_order, common.h).
-constexpr int ORDER_THREADS = 1024, ORDER_BUCKETS = 1024;
 __global__ void __launch_bounds__(ORDER_THREADS)
 tile_order_kernel(int T, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t s_cnt[ORDER_BUCKETS];
     __shared__ uint32_t s_wsum[ORDER_THREADS / WAVE];
-    const int t = threadIdx.x;
-    s_cnt[t] = 0u;
-    __syncthreads();
-    for (int i = t; i < T; i += ORDER_THREADS) {
-        const uint32_t len = ranges[2 * i + 1] - ranges[2 * i];
-        atomicAdd(&s_cnt[ORDER_BUCKETS - 1 - min((uint32_t)(ORDER_BUCKETS - 1), len >> 4)], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the 1024 bucket counts (one per thread)
-    const uint32_t c = s_cnt[t];
-    uint32_t incl = c;
-    const int lane = t & (WAVE - 1), w = t / WAVE;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, WAVE);
-        if (lane >= d) incl += o;
-    }
-    if (lane == WAVE - 1) s_wsum[w] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (int k = 0; k < w; ++k) before += s_wsum[k];
-    __syncthreads();
-    s_cnt[t] = before + incl - c;
-    __syncthreads();
-    for (int i = t; i < T; i += ORDER_THREADS) {
-        const uint32_t len = ranges[2 * i + 1] - ranges[2 * i];
-        const uint32_t pos = atomicAdd(&s_cnt[ORDER_BUCKETS - 1 - min((uint32_t)(ORDER_BUCKETS - 1), len >> 4)], 1u);
-        order[pos] = (uint32_t)i;
-    }
+    tile_order_block(T, ranges, order, s_cnt, s_wsum);
 }
 
 int launch_tile_order(const splatraster_settings& s, int32_t V, const BinView& b, hipStream_t stream)

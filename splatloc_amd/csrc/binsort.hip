@@ -33,6 +33,7 @@
 #include <mutex>
 
 #include "composite_common.h"
+#include "tile_order.h"
 #ifdef SR_BIN_TIMING   // tools/micro/tilesort_bench.hip: s_memtime stamps of every phase of a block
 namespace sr { __device__ unsigned long long* g_bin_dbg = nullptr; }
 #define SR_STAMP(k) do { if (threadIdx.x == 0 && g_bin_dbg) g_bin_dbg[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -439,11 +440,19 @@ bin_sort_tile_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* 
 __global__ void __launch_bounds__(1024)
 bin_sort_big_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* __restrict__ table,
                     const uint32_t* __restrict__ total, uint64_t* __restrict__ keys, const float4* __restrict__ rec, BinView b,
-                    const uint32_t* __restrict__ big_count, const uint32_t* __restrict__ big_list)
+                    const uint32_t* __restrict__ big_count, const uint32_t* __restrict__ big_list,
+                    uint32_t* __restrict__ order /*launch order of the compositing grids (tile_order.h), or null*/)
 {
     __shared__ double s_keys[BIN_SORT_BIG + BIN_SORT_BIG / 16];
     uint64_t* s_bits = reinterpret_cast<uint64_t*>(s_keys);
     const uint32_t nwork = *big_count, t = threadIdx.x;
+    static_assert(ORDER_THREADS == 1024, "the last block of this launch computes the launch order");
+    if (order && blockIdx.x == gridDim.x - 1) {   // every range is final: the tile kernel wrote them all (also the long lists')
+        __shared__ uint32_t s_cnt[ORDER_BUCKETS];
+        __shared__ uint32_t s_wsum[ORDER_THREADS / WAVE];
+        tile_order_block(gtiles, b.ranges, order, s_cnt, s_wsum);
+        __syncthreads();
+    }
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         const uint32_t gt = big_list[wi];
         uint32_t start, n;
@@ -577,7 +586,7 @@ int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V,
                            stream, gtiles, tiles, gx, nchunk, table, g.total, keys, g.rec, b, big_count, big_list);
     SR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bin_sort_big_kernel, dim3(BIN_BIG_BLOCKS), dim3(1024), 0, stream, gtiles, tiles, gx, nchunk, table,
-                       g.total, keys, g.rec, b, big_count, big_list);
+                       g.total, keys, g.rec, b, big_count, big_list, use_tile_order(V, tiles) ? b.tile_order : (uint32_t*)nullptr);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

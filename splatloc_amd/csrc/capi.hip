@@ -524,7 +524,8 @@ static int window_render(const splatraster_settings* s, int32_t V, const splatra
         }
     }
     if (st) return st;
-    {   // launch order of the compositing grids (the range table is final here, also when nothing was emitted)
+    if (!(R > 0 && bins.on)) {   // launch order of the compositing grids (the range table is final here, also when nothing was
+                                 // emitted); the binned front end's last launch has computed it (binsort.hip)
         StageTimer t(SPLATRASTER_STAGE_RANGES, stream);
         st = launch_tile_order(*s, V, b, stream);
     }

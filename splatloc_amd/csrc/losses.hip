@@ -254,10 +254,33 @@ refine_fwd_kernel(int H, int W, const float* __restrict__ img, const float* __re
     }
 }
 
+// the loss values out of refine_fwd_kernel's per-block partial sums (a fixed order: deterministic): run by ONE block of
+// refine_bwd_kernel — the values depend on the forward launch only, and a launch of their own cost the stream 4.7 us
+__device__ __forceinline__ void refine_finish_block(int blocks, double n_total, float lambda, const double* __restrict__ partial,
+                                                    float* __restrict__ out /*[3] = l1, ssim, loss*/)
+{
+    __shared__ double s_red[LOSS_BLOCK / WAVE][2];
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < blocks; i += LOSS_BLOCK) { a += partial[2 * (size_t)i]; b += partial[2 * (size_t)i + 1]; }
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { a += __shfl_xor(a, d, WAVE); b += __shfl_xor(b, d, WAVE); }
+    if ((threadIdx.x & (WAVE - 1)) == 0) { s_red[threadIdx.x / WAVE][0] = a; s_red[threadIdx.x / WAVE][1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = 0, l = 0;
+        for (int w = 0; w < LOSS_BLOCK / WAVE; ++w) { m += s_red[w][0]; l += s_red[w][1]; }
+        const double ssim = m / n_total, l1 = l / n_total;
+        out[0] = (float)l1;
+        out[1] = (float)ssim;
+        out[2] = (float)((1.0 - (double)lambda) * l1 + (double)lambda * (1.0 - ssim));
+    }
+}
+
 __global__ void __launch_bounds__(256)
 refine_bwd_kernel(int H, int W, float n_total, float lambda, const float* __restrict__ img,
                   const float* __restrict__ gt, RefineWindow win, const float* __restrict__ dm_dmu1,
-                  const float* __restrict__ dm_ds1, const float* __restrict__ dm_ds12, float* __restrict__ g_img)
+                  const float* __restrict__ dm_ds1, const float* __restrict__ dm_ds12, float* __restrict__ g_img,
+                  int blocks, double n_total_d, const double* __restrict__ partial, float* __restrict__ out)
 {
     __shared__ float s_m[3][FEH][FEW + 1];
     __shared__ float s_h[3][FEH][FW + 1];
@@ -319,27 +342,7 @@ refine_bwd_kernel(int H, int W, float n_total, float lambda, const float* __rest
         const float inv_n = 1.0f / n_total;
         g_img[oo] = (1.0f - lambda) * sgn(x - y) * inv_n - lambda * inv_n * (b0 + 2.0f * x * b1 + y * b2);
     }
-}
-
-__global__ void __launch_bounds__(LOSS_BLOCK)
-refine_finish_kernel(int blocks, double n_total, float lambda, const double* __restrict__ partial,
-                     float* __restrict__ out /*[3] = l1, ssim, loss*/)
-{
-    __shared__ double s_red[LOSS_BLOCK / WAVE][2];
-    double a = 0, b = 0;
-    for (int i = threadIdx.x; i < blocks; i += blockDim.x) { a += partial[2 * (size_t)i]; b += partial[2 * (size_t)i + 1]; }
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) { a += __shfl_xor(a, d, WAVE); b += __shfl_xor(b, d, WAVE); }
-    if ((threadIdx.x & (WAVE - 1)) == 0) { s_red[threadIdx.x / WAVE][0] = a; s_red[threadIdx.x / WAVE][1] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double m = 0, l = 0;
-        for (int w = 0; w < LOSS_BLOCK / WAVE; ++w) { m += s_red[w][0]; l += s_red[w][1]; }
-        const double ssim = m / n_total, l1 = l / n_total;
-        out[0] = (float)l1;
-        out[1] = (float)ssim;
-        out[2] = (float)((1.0 - (double)lambda) * l1 + (double)lambda * (1.0 - ssim));
-    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) refine_finish_block(blocks, n_total_d, lambda, partial, out);
 }
 
 static RefineWindow refine_window()
@@ -506,10 +509,7 @@ int launch_refinement_loss(int32_t C, int32_t H, int32_t W, float lambda, const 
                        maps + 2 * n, partial);
     SR_LAUNCH_CHECK();
     hipLaunchKernelGGL(refine_bwd_kernel, grid, dim3(256), 0, stream, H, W, (float)n, lambda, image, gt, win, maps,
-                       maps + n, maps + 2 * n, g_image);
-    SR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(refine_finish_kernel, dim3(1), dim3(LOSS_BLOCK), 0, stream, blocks, (double)n, lambda, partial,
-                       out);
+                       maps + n, maps + 2 * n, g_image, blocks, (double)n, partial, out);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }
