@@ -111,7 +111,7 @@ def mapping_loss_window(config, pkgs, viewpoints, initialization: bool = False):
     ex_all = None
     if not initialization and all(getattr(vp, "exposure_a", None) is not None for vp in viewpoints):
         ex_all = torch.cat([t.reshape(1) for vp in viewpoints for t in (vp.exposure_a, vp.exposure_b)]).to(torch.float32).detach()
-    tensors, grads = [], []
+    tensors, grads, pending = [], [], []
     with torch.no_grad():
         for v, (pkg, vp) in enumerate(zip(pkgs, viewpoints)):
             gt_depth = vp.depth
@@ -127,12 +127,16 @@ def mapping_loss_window(config, pkgs, viewpoints, initialization: bool = False):
             tensors += [pkg["render"], pkg["depth"], pkg["kp_prob"]]
             grads += [g_image, g_depth, g_marker]
             if ex is not None:
-                for prm, col in ((vp.exposure_a, 2), (vp.exposure_b, 3)):
-                    if isinstance(prm, torch.Tensor) and prm.requires_grad:
-                        gpart = table[v, col:col + 1].reshape(prm.shape)
-                        # its own two-float storage: an in-place op on one parameter's .grad (clip_grad_norm_, ...) must not
-                        # write into the table the other views' gradients alias
-                        prm.grad = gpart.clone() if prm.grad is None else prm.grad + gpart
+                pending += [(prm, v, col) for prm, col in ((vp.exposure_a, 2), (vp.exposure_b, 3))
+                            if isinstance(prm, torch.Tensor) and prm.requires_grad]
+        if pending:
+            # the exposure gradients leave the table in ONE copy (a 4-byte clone per parameter was two 5-us copy operations per view
+            # in the stream of a map step); every parameter's .grad is its own element of that copy: an in-place op on one of them
+            # (clip_grad_norm_, ...) touches neither the table nor another parameter's gradient
+            gex = table[:, 2:4].clone()
+            for prm, v, col in pending:
+                gpart = gex[v, col - 2:col - 1].reshape(prm.shape)
+                prm.grad = gpart if prm.grad is None else prm.grad + gpart
         value = table[:, :2].sum()
     return tensors, grads, value
 

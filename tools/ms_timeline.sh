@@ -16,7 +16,7 @@ kt = [t for t in tabs if t == "kernels"] or [t for t in tabs if "kernel" in t.lo
 rows = con.execute(f"select name, start, end from {kt[0]} order by start").fetchall()
 names = [r[0].split("(")[0].replace("void sr::", "").replace("sr::", "").replace("void ", "") for r in rows]
 # one step of OUR map_step = from one fused Adam launch to the next
-idx = [i for i, n in enumerate(names) if n.startswith("adam_kernel")]
+idx = [i for i, n in enumerate(names) if n.startswith("adam_")]
 a, b = idx[len(idx) // 2], idx[len(idx) // 2 + 1]
 t0 = rows[a + 1][1]; prev = t0; busy = 0
 for (name, s, e), n in zip(rows[a + 1:b + 1], names[a + 1:b + 1]):
