@@ -224,6 +224,40 @@ def test_adam_key_gate_and_missing_grads():
     assert torch.equal(pa[2], pb[2]) and len(fused.state.get(pa[2], {})) == 0
 
 
+def test_adam_unaligned_tensors_take_the_scalar_kernel_and_agree():
+    """The fused step reads and writes 16 bytes at a time when every tensor of every group is 16-byte aligned (torch allocations
+    are), and element by element otherwise (densify.hip): the same per-element arithmetic — a model whose tensors are views one
+    float into their storage ends bit-identical to an aligned twin, gate and partial last quad included."""
+    from splatloc_amd.optim import Adam
+    g = torch.Generator().manual_seed(19)
+    P = 5_003
+    xyz0, op0 = torch.randn(P, 3, generator=g), torch.randn(P, 1, generator=g)
+    marker = ((torch.rand(P, 1, generator=g) < 0.4).float() * torch.rand(P, 1, generator=g)).to(DEV)
+
+    def shifted(t):     # the same values, one float into a larger buffer: 4-byte aligned only
+        buf = torch.empty(t.numel() + 1, device=DEV)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 != 0 and v.is_contiguous()
+        return v
+
+    pa = [torch.nn.Parameter(xyz0.clone().to(DEV)), torch.nn.Parameter(op0.clone().to(DEV))]
+    pb = [torch.nn.Parameter(shifted(xyz0.to(DEV))), torch.nn.Parameter(shifted(op0.to(DEV)))]
+    mk = lambda ps: Adam([{"params": [ps[0]], "lr": 1e-2, "name": "xyz"}, {"params": [ps[1]], "lr": 5e-2, "name": "opacity"}], lr=0.0, eps=1e-15)  # noqa: E731
+    oa, ob = mk(pa), mk(pb)
+    oa.set_key_gate(marker, 0.005)
+    ob.set_key_gate(marker, 0.005)
+    for it in range(3):
+        gx, go = (torch.randn(P, 3, generator=g) * 1e-3).to(DEV), (torch.randn(P, 1, generator=g) * 1e-3).to(DEV)
+        pa[0].grad, pa[1].grad = gx.clone(), go.clone()
+        pb[0].grad, pb[1].grad = shifted(gx), shifted(go)
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a.detach(), b.detach())
+        assert torch.equal(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"])
+
+
 def test_isotropic_loss_matches_reference_expression():
     from splatloc_amd.losses import isotropic_loss
     g = torch.Generator().manual_seed(4)
