@@ -542,7 +542,7 @@ static int wide_hint_init(int dev)
     std::lock_guard<std::mutex> lk(g_wide_mu);
     if (g_wide_host[dev]) return SPLATRASTER_OK;
     uint32_t* h = nullptr;
-    SR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped | hipHostMallocPortable));
+    SR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
     *h = 0u;
     uint32_t* d = nullptr;
     SR_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0));

@@ -84,7 +84,7 @@ static int host_slot(size_t n, HostSlot** out)
         s.dp = nullptr;
         s.cap = 0;
         const size_t cap = n < 4096 ? 4096 : n + n / 2;
-        SR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.p), sizeof(uint32_t) * cap, hipHostMallocMapped | hipHostMallocPortable));
+        SR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.p), sizeof(uint32_t) * cap, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
         SR_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dp), s.p, 0));
         s.cap = cap;
     }
