@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 10
+#define SPLATRASTER_ABI_VERSION 11
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
@@ -414,6 +414,11 @@ typedef struct splatraster_adam_group {
 } splatraster_adam_group;
 int splatraster_adam_step(int32_t n_groups, const splatraster_adam_group* groups, double beta1, double beta2, double eps,
                           float row_gate_threshold, void* stream);
+/* splatraster_adam_step and, in the same launch, the statistics line of SplatLoc.color_refinement (train_gaussians.py:293-294):
+ * max_radii2D[i] = max(max_radii2D[i], radii[i]) wherever radii[i] > 0 (radii: the int32 [P] output of the frame's forward).
+ * n_groups may be 0 (only the statistics). */
+int splatraster_adam_step_radii(int32_t n_groups, const splatraster_adam_group* groups, double beta1, double beta2, double eps,
+                                float row_gate_threshold, int32_t P, const int32_t* radii, float* max_radii2D, void* stream);
 
 /* Isotropic scale regulariser of SplatLoc.map (train_gaussians.py:222-228):
  *   mask = marker > 0.005;  loss = mean_{mask} | mean_k scaling[i,k] / (0.02 (1 - marker_i)) - 1 |

@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 10   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 11   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 WARN_LOOKBACK_STALL = 5   # splatraster_poll_errors() only; not an error of any frame
@@ -127,6 +127,7 @@ SYMBOLS = {
                                             _vp, _vp, _vp]),
     "splatraster_model_append": (C.c_int, [C.POINTER(Model)] * 7 + [_vp]),
     "splatraster_adam_step": (C.c_int, [_i32, C.POINTER(AdamGroup), C.c_double, C.c_double, C.c_double, C.c_float, _vp]),
+    "splatraster_adam_step_radii": (C.c_int, [_i32, C.POINTER(AdamGroup), C.c_double, C.c_double, C.c_double, C.c_float, _i32, _vp, _vp, _vp]),
     "splatraster_isotropic_loss_workspace_bytes": (_sz, [_i32]),
     "splatraster_isotropic_loss": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_mapping_loss_workspace_bytes": (_sz, [_i32]),

@@ -276,7 +276,18 @@ struct AdamTable {
     int n;
     float beta1, beta2, eps, gate_thr;
     float omb1, omb2;                          // 1 - beta formed in double on the host, like torch's python floats
+    // optional tail of the launch: max_radii[i] = max(max_radii[i], radii[i]) for radii[i] > 0 — the statistics line of
+    // SplatLoc.color_refinement (train_gaussians.py:293-294), a launch of its own otherwise
+    int radii_n;
+    const int* radii;
+    float* max_radii;
 };
+
+__device__ __forceinline__ void radii_update(const AdamTable& T, unsigned long long i)
+{
+    const int r = T.radii[i];
+    if (r > 0) T.max_radii[i] = fmaxf(T.max_radii[i], (float)r);
+}
 
 __device__ __forceinline__ void adam_element(const AdamTable& T, int gq, float g, float& m, float& v, float& p)
 {
@@ -291,8 +302,9 @@ __device__ __forceinline__ void adam_element(const AdamTable& T, int gq, float g
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamTable T, unsigned long long total)
 {
-    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total + (unsigned long long)T.radii_n;
          e += (unsigned long long)gridDim.x * blockDim.x) {
+        if (e >= total) { radii_update(T, e - total); continue; }
         int gq = 0;
 #pragma unroll 1
         while (gq + 1 < T.n && e >= T.end[gq]) ++gq;
@@ -317,8 +329,14 @@ struct AdamQuads {
 __global__ void __launch_bounds__(256)
 adam_quad_kernel(AdamTable T, AdamQuads Q, unsigned long long total_quads)
 {
-    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < total_quads;
+    const unsigned long long radii_quads = ((unsigned long long)T.radii_n + 3ull) / 4ull;
+    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < total_quads + radii_quads;
          q += (unsigned long long)gridDim.x * blockDim.x) {
+        if (q >= total_quads) {
+            const unsigned long long i0 = (q - total_quads) * 4ull;
+            for (unsigned long long i = i0; i < i0 + 4ull && i < (unsigned long long)T.radii_n; ++i) radii_update(T, i);
+            continue;
+        }
         int gq = 0;
 #pragma unroll 1
         while (gq + 1 < T.n && q >= Q.qend[gq]) ++gq;
@@ -369,7 +387,7 @@ adam_quad_kernel(AdamTable T, AdamQuads Q, unsigned long long total_quads)
 }
 
 int adam_step(int n, const splatraster_adam_group* groups, double beta1, double beta2, double eps, float gate_thr,
-              hipStream_t stream)
+              int32_t radii_n, const int32_t* radii, float* max_radii, hipStream_t stream)
 {
     AdamTable T{};
     AdamQuads Q{};
@@ -391,16 +409,20 @@ int adam_step(int n, const splatraster_adam_group* groups, double beta1, double 
         T.inv_bc2_sqrt[used] = (float)(1.0 / sqrt(bc2));
         ++used;
     }
-    if (used == 0) return SPLATRASTER_OK;
+    const bool with_radii = radii_n > 0 && radii && max_radii;
+    if (used == 0 && !with_radii) return SPLATRASTER_OK;
+    T.radii_n = with_radii ? radii_n : 0;
+    T.radii = radii;
+    T.max_radii = max_radii;
     T.n = used; T.beta1 = (float)beta1; T.beta2 = (float)beta2; T.eps = (float)eps; T.gate_thr = gate_thr;
     T.omb1 = (float)(1.0 - beta1);   // torch: python-float `1 - beta` rounded to fp32 once
     T.omb2 = (float)(1.0 - beta2);
     if (aligned) {
-        unsigned long long blocks = (total_quads + 255) / 256;
+        unsigned long long blocks = (total_quads + ((unsigned long long)T.radii_n + 3ull) / 4ull + 255) / 256;
         if (blocks > 4096) blocks = 4096;   // grid-stride: 16 workgroups per CU
         hipLaunchKernelGGL(adam_quad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, T, Q, total_quads);
     } else {
-        unsigned long long blocks = (total + 255) / 256;
+        unsigned long long blocks = (total + (unsigned long long)T.radii_n + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, T, total);
     }
@@ -610,7 +632,15 @@ int splatraster_adam_step(int32_t n_groups, const splatraster_adam_group* groups
 {
     if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || (n_groups > 0 && !groups)) return SPLATRASTER_ERR_BAD_ARG;
     if (n_groups == 0) return SPLATRASTER_OK;
-    return adam_step(n_groups, groups, beta1, beta2, eps, row_gate_threshold, reinterpret_cast<hipStream_t>(stream));
+    return adam_step(n_groups, groups, beta1, beta2, eps, row_gate_threshold, 0, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int splatraster_adam_step_radii(int32_t n_groups, const splatraster_adam_group* groups, double beta1, double beta2, double eps,
+                                float row_gate_threshold, int32_t P, const int32_t* radii, float* max_radii2D, void* stream)
+{
+    if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || (n_groups > 0 && !groups) || P < 0 || (P > 0 && (!radii || !max_radii2D)))
+        return SPLATRASTER_ERR_BAD_ARG;
+    return adam_step(n_groups, groups, beta1, beta2, eps, row_gate_threshold, P, radii, max_radii2D, reinterpret_cast<hipStream_t>(stream));
 }
 
 size_t splatraster_isotropic_loss_workspace_bytes(int32_t P) { return isotropic_workspace_bytes(P); }

@@ -24,6 +24,7 @@ class Adam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
         self.key_gate = None        # (gate tensor with one value per xyz row, threshold, group name)
+        self._radii_update = None   # (radii, max_radii2D) for the next step() — set_radii_update
 
     def set_key_gate(self, gate: torch.Tensor, threshold: float = 0.005, group: str = "xyz") -> None:
         """Rows of `group` whose gate value exceeds `threshold` see a zero gradient in step()."""
@@ -87,13 +88,37 @@ class Adam(torch.optim.Adam):
                 entries.append(_native.AdamGroup(
                     p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                     None if gate is None else gate.data_ptr(), n, max(width, 1), float(grp["lr"]), step_val))
-        if entries:
-            if len(entries) > 16:
-                raise RuntimeError("splatloc_amd.optim.Adam: at most 16 parameters per step")
-            arr = (_native.AdamGroup * len(entries))(*entries)
+        radii_update, self._radii_update = getattr(self, "_radii_update", None), None
+        if len(entries) > 16:
+            raise RuntimeError("splatloc_amd.optim.Adam: at most 16 parameters per step")
+        if entries or radii_update is not None:
+            arr = (_native.AdamGroup * max(len(entries), 1))(*entries)
             thr = gate_spec[1] if gate_spec is not None else 0.0
-            with _on_device(dev):
-                _native.check(lib.splatraster_adam_step(len(entries), arr, C.c_double(betas[0]), C.c_double(betas[1]),
-                                                        C.c_double(eps), C.c_float(thr), _stream(dev)), "adam_step")
+            if betas is None:
+                betas, eps = (0.9, 0.999), 1e-8
+            if radii_update is not None:      # the frame's max_radii2D line rides this launch (set_radii_update)
+                radii, max_radii = radii_update
+                dev = radii.device if dev is None else dev
+                with _on_device(dev):
+                    _native.check(lib.splatraster_adam_step_radii(len(entries), arr, C.c_double(betas[0]), C.c_double(betas[1]),
+                                                                  C.c_double(eps), C.c_float(thr), int(radii.numel()), radii.data_ptr(),
+                                                                  max_radii.data_ptr(), _stream(dev)), "adam_step_radii")
+            else:
+                with _on_device(dev):
+                    _native.check(lib.splatraster_adam_step(len(entries), arr, C.c_double(betas[0]), C.c_double(betas[1]),
+                                                            C.c_double(eps), C.c_float(thr), _stream(dev)), "adam_step")
         del keep
         return loss
+
+    def set_radii_update(self, radii, max_radii2D):
+        """The NEXT `step()` also performs `max_radii2D[vis] = max(max_radii2D[vis], radii[vis])` (vis = radii > 0), the statistics
+        line of SplatLoc.color_refinement (train_gaussians.py:293-294), inside its one launch."""
+        if radii is None:
+            self._radii_update = None
+            return
+        if radii.dtype != torch.int32 or not radii.is_contiguous() or not radii.is_cuda:
+            raise RuntimeError("set_radii_update: `radii` must be the contiguous int32 device tensor of a forward")
+        if (max_radii2D.dtype != torch.float32 or not max_radii2D.is_contiguous() or max_radii2D.numel() != radii.numel()
+                or max_radii2D.device != radii.device):
+            raise RuntimeError("set_radii_update: `max_radii2D` must be a contiguous float32 tensor with one element per Gaussian")
+        self._radii_update = (radii, max_radii2D)

@@ -91,7 +91,10 @@ def _color_refinement_step_direct(viewpoint_cam, gaussians, background, lambda_d
                 gaussians._xyz.grad[key_mask] = 0
         elif hasattr(opt, "set_key_gate"):
             opt.set_key_gate(None)
-        add_densification_stats_window(None, [radii], None, None, gaussians.max_radii2D)
+        if hasattr(opt, "set_radii_update") and radii.dtype == torch.int32 and radii.is_contiguous():
+            opt.set_radii_update(radii, gaussians.max_radii2D)      # the statistics line rides the fused Adam launch
+        else:
+            add_densification_stats_window(None, [radii], None, None, gaussians.max_radii2D)
         opt.step()
         opt.zero_grad(set_to_none=True)
         update_learning_rate(gaussians, iteration)

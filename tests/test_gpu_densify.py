@@ -258,6 +258,36 @@ def test_adam_unaligned_tensors_take_the_scalar_kernel_and_agree():
         assert torch.equal(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"])
 
 
+def test_adam_step_carries_the_max_radii_line():
+    """`set_radii_update`: the next fused step also performs SplatLoc.color_refinement's statistics line (train_gaussians.py:
+    293-294) — same parameters as a plain step, the same max_radii2D as the statistics launch; also with no gradient at all."""
+    from splatloc_amd.densify import add_densification_stats_window
+    from splatloc_amd.optim import Adam
+    g = torch.Generator().manual_seed(23)
+    P = 7_777
+    x0 = torch.randn(P, 3, generator=g)
+    radii = (torch.randint(0, 40, (P,), generator=g) * (torch.rand(P, generator=g) < 0.6)).to(torch.int32).to(DEV)
+    m0 = (torch.rand(P, generator=g) * 30).to(DEV)
+    pa, pb = torch.nn.Parameter(x0.clone().to(DEV)), torch.nn.Parameter(x0.clone().to(DEV))
+    oa = Adam([{"params": [pa], "lr": 1e-2, "name": "xyz"}], lr=0.0, eps=1e-15)
+    ob = Adam([{"params": [pb], "lr": 1e-2, "name": "xyz"}], lr=0.0, eps=1e-15)
+    ma, mb = m0.clone(), m0.clone()
+    for it in range(3):
+        gx = (torch.randn(P, 3, generator=g) * 1e-3).to(DEV)
+        pa.grad, pb.grad = gx.clone(), gx.clone()
+        oa.set_radii_update(radii, ma)
+        oa.step()
+        add_densification_stats_window(None, [radii], None, None, mb)
+        ob.step()
+    assert torch.equal(pa.detach(), pb.detach()) and torch.equal(ma, mb)
+    assert torch.equal(ma, torch.where(radii > 0, torch.maximum(m0, radii.float()), m0))
+    pa.grad = None
+    r2 = (radii + 50) * (radii > 0)
+    oa.set_radii_update(r2.to(torch.int32), ma)
+    oa.step()                                   # no gradient anywhere: the statistics alone
+    assert torch.equal(ma, torch.where(radii > 0, r2.float(), m0)) and torch.equal(pa.detach(), pb.detach())
+
+
 def test_isotropic_loss_matches_reference_expression():
     from splatloc_amd.losses import isotropic_loss
     g = torch.Generator().manual_seed(4)
