@@ -156,7 +156,7 @@ GeomView geom_view(void* base, int32_t P, int32_t V)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, ipack, featp, gacc, ckpt, tile_order, big_list, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, ipack, featp, gacc, pose_acc, ckpt, tile_order, big_list, bytes;
 };
 static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t H, int32_t C)
 {
@@ -177,6 +177,7 @@ static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t 
     // padded feature table only when the rows are not already 16-byte aligned (shared by the views)
     L.featp = take((C % 4) ? (size_t)(P > 0 ? P : 1) * padded_channels(C) * sizeof(float) : 16);
     L.gacc = take((size_t)(P > 0 ? P : 1) * nv * gacc_row_floats(C) * sizeof(float));
+    L.pose_acc = take(POSE_ACC_BYTES);      // (directly behind gacc: the backward zeroes both with one fill)
     // (the deterministic debug mode's 64-bit accumulator is NOT part of this buffer: it is a stream-ordered
     //  allocation made by the backward only while that mode is on)
     // mid-list checkpoints of the forward for split launches (small frames, narrow layouts): the maximum is reserved
@@ -204,6 +205,7 @@ BinView bin_view(void* base, int32_t P, int32_t V, int64_t R, int32_t W, int32_t
     v.ipack = reinterpret_cast<uint32_t*>(b + L.ipack);
     v.featp = reinterpret_cast<float*>(b + L.featp);
     v.gacc = reinterpret_cast<float*>(b + L.gacc);
+    v.pose_acc = reinterpret_cast<float*>(b + L.pose_acc);
     v.ckpt = reinterpret_cast<float*>(b + L.ckpt);
     v.tile_order = reinterpret_cast<uint32_t*>(b + L.tile_order);
     v.big_list = reinterpret_cast<uint32_t*>(b + L.big_list);
@@ -607,7 +609,11 @@ static int window_backward(const splatraster_settings* s, int32_t V, const splat
         SR_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&gacc64), sizeof(long long) * gacc_n, stream));
         SR_HIP_CHECK(hipMemsetAsync(gacc64, 0, sizeof(long long) * gacc_n, stream));
     }
-    SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, sizeof(float) * gacc_n, stream));
+    const bool pose = dL_dviewmatrix && dL_dprojmatrix;
+    // (one fill: the camera-gradient accumulator sets lie directly behind the rows)
+    const size_t fill = pose ? (size_t)(reinterpret_cast<char*>(b.pose_acc) - reinterpret_cast<char*>(b.gacc)) + POSE_ACC_BYTES
+                             : sizeof(float) * gacc_n;
+    SR_HIP_CHECK(hipMemsetAsync(b.gacc, 0, fill, stream));
     grads.bg = bg;
     grads.bg_channels = bg ? s->bg_channels : 0;
     {
@@ -627,7 +633,7 @@ static int window_backward(const splatraster_settings* s, int32_t V, const splat
                                  b.gacc, C, shs ? nullptr : dL_dcolors, dL_dmeans3D, dL_dopacities,
                                  cov3D_precomp ? nullptr : dL_dscales, cov3D_precomp ? nullptr : dL_drotations,
                                  cov3D_precomp ? dL_dcov3D : nullptr, dL_dshs, dL_dviewmatrix, dL_dprojmatrix, dL_dcampos,
-                                 stream);
+                                 b.pose_acc, stream);
 }
 
 }  // namespace sr

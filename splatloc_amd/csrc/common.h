@@ -114,6 +114,7 @@ struct BinView {
                           //     ONE word per entry is all a compositing wave prefetches
     float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows); shared by the views
     float* gacc;          // [V * P * gacc_row_floats(C)] backward gradient accumulator rows (one per row)
+    float* pose_acc;      // right behind gacc (one fill zeroes both): POSE_SETS replicated accumulator sets of the camera gradients + the ticket word
     float* ckpt;          // [V][SPLIT_PARTS][C + 2][H * W] segment records of the forward (T in front of the segment, its own colours, depth), split launches only
     uint32_t* tile_order; // [V * tiles] global tile ids, longest list first: the launch order of the compositing kernels
     uint32_t* big_list;   // [V * tiles] binned front end: the (view, tile) lists too long for the first sort launch
@@ -142,7 +143,7 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, c
                           float* dL_dmeans3D, float* dL_dopacities, float* dL_dscales,
                           float* dL_drotations, float* dL_dcov3D, float* dL_dshs,
                           float* dL_dview /*[16] or null; V == 1 only*/, float* dL_dproj, float* dL_dcampos,
-                          hipStream_t stream);
+                          float* pose_acc /*BinView::pose_acc, zeroed by the caller; needed with dL_dview*/, hipStream_t stream);
 int launch_mark_visible(int32_t P, const float* means3D, const float* view, uint8_t* present,
                         hipStream_t stream);
 
@@ -209,6 +210,10 @@ static inline int padded_channels(int C) { return (C + 3) & ~3; }
 // float atomics of one Gaussian land in as few memory-side requests as possible):
 //   [0, C) dL/dfeature, [MO, MO + 7) moment record, padded to a multiple of 16 floats.
 // The moments share the last 64-byte line of the features when they fit.
+// camera-gradient accumulators of preprocess_bwd_kernel<true>: block b adds its 27 partial sums to set b % POSE_SETS (sixteen sets on
+// sixteen 256-byte lines instead of 27 words every block hits), the LAST block to finish (ticket) sums the sets and writes the outputs
+constexpr int POSE_SETS = 16, POSE_SET_FLOATS = 64;
+constexpr size_t POSE_ACC_BYTES = (size_t)POSE_SETS * POSE_SET_FLOATS * sizeof(float) + 256;   // + the ticket's own line
 __host__ __device__ static inline int gacc_moment_offset(int C) { return ((C & 15) + 7 <= 16) ? C : ((C + 15) & ~15); }
 __host__ __device__ static inline int gacc_row_floats(int C) { return (gacc_moment_offset(C) + 7 + 15) & ~15; }
 // One small frame alone (SplatLoc's color_refinement: 640x480, one view) is 4 800 quadrant-waves on a machine with room

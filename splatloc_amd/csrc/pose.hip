@@ -13,6 +13,36 @@ namespace sr {
 
 constexpr int L1_THREADS = 256;
 
+// one plane set (colour or depth): |x - t| w summed, the gradient plane written; 16 bytes per access when the three pointers allow it
+__device__ __forceinline__ float l1_region(int64_t n, const float* __restrict__ x, const float* __restrict__ t, float w,
+                                           float* __restrict__ g, int64_t tid, int64_t nthreads)
+{
+    float acc = 0.0f;
+    auto one = [&](float xv, float tv) -> float {
+        const float d = xv - tv;
+        acc += fabsf(d) * w;
+        return d > 0.0f ? w : (d < 0.0f ? -w : 0.0f);
+    };
+    const bool vec = (((uintptr_t)x | (uintptr_t)t | (uintptr_t)g) & 15u) == 0;
+    const int64_t nq = vec ? n / 4 : 0;
+    for (int64_t q = tid; q < nq; q += nthreads) {
+        const float4 xv = reinterpret_cast<const float4*>(x)[q], tv = reinterpret_cast<const float4*>(t)[q];
+        float4 gv;
+        gv.x = one(xv.x, tv.x);
+        gv.y = one(xv.y, tv.y);
+        gv.z = one(xv.z, tv.z);
+        gv.w = one(xv.w, tv.w);
+        if (g) reinterpret_cast<float4*>(g)[q] = gv;
+    }
+    for (int64_t e = 4 * nq + tid; e < n; e += nthreads) {
+        const float gv = one(x[e], t[e]);
+        if (g) g[e] = gv;
+    }
+    return acc;
+}
+
+// (round 5's first version: one element per thread and iteration, 1 200 blocks each ending in an atomic on the one loss word —
+//  23.6 us for 1.2 M elements, most of it the atomics' queue; now at most 256 blocks and 16-byte accesses)
 __global__ void __launch_bounds__(L1_THREADS)
 l1_rgbd_loss_kernel(int64_t n_color, const float* __restrict__ color, const float* __restrict__ tgt_c, int64_t n_depth,
                     const float* __restrict__ depth, const float* __restrict__ tgt_d, float depth_weight,
@@ -20,19 +50,12 @@ l1_rgbd_loss_kernel(int64_t n_color, const float* __restrict__ color, const floa
 {
     __shared__ float s_sum[L1_THREADS / WAVE];
     const float wc = 1.0f / (float)n_color, wd = (tgt_d && n_depth) ? depth_weight / (float)n_depth : 0.0f;
-    float acc = 0.0f;
-    const int64_t n = n_color + n_depth;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        if (e < n_color) {
-            const float d = color[e] - tgt_c[e];
-            acc += fabsf(d) * wc;
-            g_color[e] = d > 0.0f ? wc : (d < 0.0f ? -wc : 0.0f);
-        } else {
-            const int64_t k = e - n_color;
-            const float d = tgt_d ? depth[k] - tgt_d[k] : 0.0f;
-            acc += fabsf(d) * wd;
-            if (g_depth) g_depth[k] = d > 0.0f ? wd : (d < 0.0f ? -wd : 0.0f);
-        }
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+    float acc = l1_region(n_color, color, tgt_c, wc, g_color, tid, nthreads);
+    if (tgt_d) {
+        acc += l1_region(n_depth, depth, tgt_d, wd, g_depth, tid, nthreads);
+    } else if (g_depth) {
+        for (int64_t e = tid; e < n_depth; e += nthreads) g_depth[e] = 0.0f;
     }
 #pragma unroll
     for (int o = WAVE / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
@@ -51,8 +74,8 @@ int launch_l1_rgbd_loss(int64_t n_color, const float* color, const float* tgt_c,
                         hipStream_t stream)
 {
     const int64_t n = n_color + n_depth;
-    int blocks = (int)((n + L1_THREADS * 4 - 1) / (L1_THREADS * 4));
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    int blocks = (int)((n + L1_THREADS * 16 - 1) / (L1_THREADS * 16));
+    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
     hipLaunchKernelGGL(l1_rgbd_loss_kernel, dim3(blocks), dim3(L1_THREADS), 0, stream, n_color, color, tgt_c, n_depth, depth,
                        tgt_d, depth_weight, g_color, g_depth, loss_out);
     SR_LAUNCH_CHECK();

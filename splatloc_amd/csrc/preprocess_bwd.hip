@@ -98,19 +98,19 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
                       float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dshs, float* __restrict__ dL_dview, float* __restrict__ dL_dproj,
-                      float* __restrict__ dL_dcampos)
+                      float* __restrict__ dL_dcampos, float* __restrict__ pose_acc /*POSE: zeroed sets + ticket (common.h)*/)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // pose partials of this Gaussian: dV[4c + r] (r < 3), dPM[4c + k] (k = 0, 1, 3), dcampos   (V == 1 only)
     float pose[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) pose[k] = 0.f;
-    if (i < P) {
     float dmean[3] = {0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dop = 0.f;
+    if (i < P) {
     bool any_visible = false;
     const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
     // 3D covariance (recomputed; same formula as the forward) — view independent
@@ -317,6 +317,58 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
             drot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
     }
+    }  // i < P
+    if (POSE) {
+        // 27 partials summed over the wave with the packed butterfly, then over the block in LDS, then one atomic per value per
+        // block into set blockIdx.x % POSE_SETS (every block on the same 27 words queued the atomics of 2 000 blocks on three
+        // lines: 13 us of this kernel at 500k Gaussians); the last block to take a ticket sums the sets and writes the outputs,
+        // all 16 + 16 + 3 entries of them — nothing to zero beforehand but the sets, which lie behind the accumulator rows
+        __shared__ float s_pose[4][32];
+        __shared__ bool s_last;
+        const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+        const float tot = wave_reduce_pack<27>(pose, lane);
+        const int slot = (int)(__brev((unsigned)lane) >> 26);
+        if (slot < 27) s_pose[w][slot] = tot;
+        __syncthreads();
+        if (threadIdx.x < 27) {
+            const int k = threadIdx.x;
+            const float v = s_pose[0][k] + s_pose[1][k] + s_pose[2][k] + s_pose[3][k];
+            const float before = atomicAdd(&pose_acc[(blockIdx.x & (POSE_SETS - 1)) * POSE_SET_FLOATS + k], v);
+            asm volatile("" ::"v"(before));     // (returned: the addition is done at the memory side before the ticket below)
+        }
+        __syncthreads();
+        // two-level ticket (2 000 increments of ONE word would queue for ~40 us): the set's own counter in the last word of its
+        // line, then — by the last block of every set — the counter behind the sets
+        if (threadIdx.x == 0) {
+            const unsigned q = blockIdx.x & (POSE_SETS - 1);
+            const unsigned in_set = (gridDim.x - q + (POSE_SETS - 1)) / POSE_SETS;       // blocks that add to set q
+            const unsigned nsets = gridDim.x < (unsigned)POSE_SETS ? gridDim.x : (unsigned)POSE_SETS;
+            unsigned* set_ticket = reinterpret_cast<unsigned*>(pose_acc + q * POSE_SET_FLOATS + (POSE_SET_FLOATS - 1));
+            unsigned* ticket = reinterpret_cast<unsigned*>(pose_acc + POSE_SETS * POSE_SET_FLOATS);
+            bool last = false;
+            if (atomicAdd(set_ticket, 1u) == in_set - 1) last = atomicAdd(ticket, 1u) == nsets - 1;
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last && threadIdx.x < 35) {
+            const int e = threadIdx.x;      // output entry: dV[0..15], dPM[16..31], dcampos[32..34]
+            int k = -1;                     // its partial (dV[4c + r], r < 3: 3c + r; dPM[4c + j], j = 0, 1, 3: 12 + 3c + (j == 3 ? 2 : j))
+            if (e < 16) { if ((e & 3) < 3) k = 3 * (e >> 2) + (e & 3); }
+            else if (e < 32) { const int j = (e - 16) & 3; if (j != 2) k = 12 + 3 * ((e - 16) >> 2) + (j == 3 ? 2 : j); }
+            else k = 24 + (e - 32);
+            float sum = 0.0f;
+            if (k >= 0) {
+                for (int q = 0; q < POSE_SETS; ++q)
+                    sum += __hip_atomic_load(&pose_acc[q * POSE_SET_FLOATS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (e < 16) dL_dview[e] = sum;
+            else if (e < 32) dL_dproj[e - 16] = sum;
+            else if (dL_dcampos) dL_dcampos[e - 32] = sum;
+        }
+    }
+    // the per-Gaussian gradients are written AFTER the camera sums went out: the set atomics return into registers and nothing
+    // but loads precedes them — behind the stores below, waiting for them would wait for the stores as well (vmcnt counts both)
+    if (i < P) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = dmean[k];
     dL_dopacities[i] = dop;
@@ -329,28 +381,6 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
 #pragma unroll
         for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = dcov[k];
     }
-    }  // i < P
-    if (POSE) {
-        // 27 partials summed over the wave with the packed butterfly, then over the block in
-        // LDS, then one atomic per value per block
-        __shared__ float s_pose[4][32];
-        const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-        const float tot = wave_reduce_pack<27>(pose, lane);
-        const int slot = (int)(__brev((unsigned)lane) >> 26);
-        if (slot < 27) s_pose[w][slot] = tot;
-        __syncthreads();
-        if (threadIdx.x < 27) {
-            const int k = threadIdx.x;
-            const float v = s_pose[0][k] + s_pose[1][k] + s_pose[2][k] + s_pose[3][k];
-            if (k < 12) {
-                atomicAdd(&dL_dview[4 * (k / 3) + (k % 3)], v);
-            } else if (k < 24) {
-                const int kk = k - 12, c = kk / 3, j = kk % 3;
-                atomicAdd(&dL_dproj[4 * c + (j == 2 ? 3 : j)], v);
-            } else if (dL_dcampos) {
-                atomicAdd(&dL_dcampos[k - 24], v);
-            }
-        }
     }
 }
 
@@ -401,7 +431,7 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, c
                           const float* cov3D_precomp, const uint8_t* clamped, const float4* rec, const float* gacc, int C,
                           float* dL_dcolors, float* dL_dmeans3D, float* dL_dopacities, float* dL_dscales,
                           float* dL_drotations, float* dL_dcov3D, float* dL_dshs, float* dL_dview,
-                          float* dL_dproj, float* dL_dcampos, hipStream_t stream)
+                          float* dL_dproj, float* dL_dcampos, float* pose_acc, hipStream_t stream)
 {
     if (P == 0) return SPLATRASTER_OK;
     if (dL_dcolors) {
@@ -410,17 +440,13 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, c
                            gacc_row_floats(C), V, (int64_t)P, gacc, dL_dcolors);
         SR_LAUNCH_CHECK();
     }
-    const bool pose = dL_dview && dL_dproj;
-    if (pose) {
-        SR_HIP_CHECK(hipMemsetAsync(dL_dview, 0, 16 * sizeof(float), stream));
-        SR_HIP_CHECK(hipMemsetAsync(dL_dproj, 0, 16 * sizeof(float), stream));
-        if (dL_dcampos) SR_HIP_CHECK(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), stream));
-    }
+    const bool pose = dL_dview && dL_dproj;      // (the accumulator sets behind gacc were zeroed with the rows: capi.hip)
+    if (pose && !pose_acc) return SPLATRASTER_ERR_BAD_ARG;
 #define SR_PBWD_ARGS                                                                                              \
     P, V, s.image_width, s.image_height, s.scale_modifier, s.sh_degree, s.sh_coeffs, cams, grads, means3D,         \
         shs, scales, rotations, cov3D_precomp, clamped, rec, gacc, C, gacc_row_floats(C),                          \
         gacc_moment_offset(C), dL_dmeans3D, dL_dopacities, dL_dscales, dL_drotations,                              \
-        dL_dcov3D, dL_dshs, dL_dview, dL_dproj, dL_dcampos
+        dL_dcov3D, dL_dshs, dL_dview, dL_dproj, dL_dcampos, pose_acc
     if (pose)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, SR_PBWD_ARGS);
     else

@@ -247,7 +247,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         want_pose = any(ctx.needs_input_grad[9:12]) if len(ctx.needs_input_grad) >= 12 else False
         d_view = torch.empty((4, 4), **f32) if want_pose else None
         d_proj = torch.empty((4, 4), **f32) if want_pose else None
-        d_cam = torch.zeros((3,), **f32) if (want_pose and campos is not None) else None
+        d_cam = torch.empty((3,), **f32) if (want_pose and campos is not None) else None   # (written in full by the backward)
         with _on_device(dev):
             _native.check(lib.splatraster_backward(
                 C.byref(st), P, ctx.num_rendered, _ptr(bg), _ptr(m3), _ptr(shs), _ptr(col), _ptr(opa),
