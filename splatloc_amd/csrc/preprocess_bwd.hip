@@ -425,22 +425,6 @@ gather_dcolors_kernel(int64_t n, int C, int GROW, int V, int64_t P, const float*
     for (int v = 1; v < V; ++v) sum += gacc[(v * P + i) * GROW + ch];   // the feature table is shared by the views
     dL_dcolors[e] = sum;
 }
-// layouts of <= 4 channels: one thread per Gaussian, the row's first 16 bytes in one access (the rows are 64-byte aligned)
-__global__ void __launch_bounds__(256)
-gather_dcolors4_kernel(int64_t P, int C, int GROW, int V, const float* __restrict__ gacc, float* __restrict__ dL_dcolors)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    float4 sum = *reinterpret_cast<const float4*>(gacc + i * GROW);
-    for (int v = 1; v < V; ++v) {
-        const float4 r = *reinterpret_cast<const float4*>(gacc + (v * P + i) * GROW);
-        sum.x += r.x; sum.y += r.y; sum.z += r.z; sum.w += r.w;
-    }
-    const float out[4] = {sum.x, sum.y, sum.z, sum.w};
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch)
-        if (ch < C) dL_dcolors[i * C + ch] = out[ch];
-}
 
 int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const WinGrad& grads,
                           const float* means3D, const float* shs, const float* scales, const float* rotations,
@@ -452,12 +436,8 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, c
     if (P == 0) return SPLATRASTER_OK;
     if (dL_dcolors) {
         const int64_t n = (int64_t)P * C;
-        if (C <= 4)
-            hipLaunchKernelGGL(gather_dcolors4_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, (int64_t)P, C,
-                               gacc_row_floats(C), V, gacc, dL_dcolors);
-        else
-            hipLaunchKernelGGL(gather_dcolors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, C,
-                               gacc_row_floats(C), V, (int64_t)P, gacc, dL_dcolors);
+        hipLaunchKernelGGL(gather_dcolors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, C,
+                           gacc_row_floats(C), V, (int64_t)P, gacc, dL_dcolors);
         SR_LAUNCH_CHECK();
     }
     const bool pose = dL_dview && dL_dproj;      // (the accumulator sets behind gacc were zeroed with the rows: capi.hip)
