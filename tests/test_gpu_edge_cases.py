@@ -303,6 +303,28 @@ def test_team_forward_changes_nothing(C, W, H, P, scale):
         assert int((rng[:, 1] - rng[:, 0]).max()) >= 4 * 256
 
 
+def test_team_forward_full_size():
+    """The three forwards of a narrow single frame at BASELINE's reference layout (500k Gaussians, 640x480, C = 4: 4 800 quadrant
+    lists of ~1 000 entries): one wave per quadrant, the default (teams for the lists that stand out) and a team for each of the
+    128 longest lists — identical images, depth, alpha, final_T and n_contrib."""
+    from splatloc_amd import _native
+    from splatloc_amd.synthetic import make_workload
+    lib = _native.load()
+    sc = make_workload("S2-ref-layout")
+    outs = {}
+    try:
+        for mode in (0, -1, 2):
+            lib.splatraster_debug_set_fwd_team(mode)
+            r = HipRun(sc, backward=False)
+            outs[mode] = (r.color, r.depth, r.alpha, r.state["n_contrib"], r.state["final_T"])
+    finally:
+        lib.splatraster_debug_set_fwd_team(-1)
+    for mode in (-1, 2):
+        for a, b in zip(outs[0], outs[mode]):
+            assert torch.equal(a, b), mode
+    assert int(outs[0][3].max()) > 500      # deep lists: hundreds of contributors per pixel
+
+
 def test_team_forward_soak():
     """Random shapes through both forwards of the narrow layouts (tools/soak_team_forward.py runs hundreds): a team's waves meet at
     barriers and hand values over through LDS — a race would be a rare mismatch, not a reproducible one."""
