@@ -323,6 +323,18 @@ def test_team_forward_full_size():
         for a, b in zip(outs[0], outs[mode]):
             assert torch.equal(a, b), mode
     assert int(outs[0][3].max()) > 500      # deep lists: hundreds of contributors per pixel
+    # the split backward starts its later waves from the forward's segment records: those a team wrote (B: T at the boundaries,
+    # C: the segments' sums) against the one-wave kernel's
+    grads = {}
+    try:
+        for mode in (0, 2):
+            lib.splatraster_debug_set_fwd_team(mode)
+            r = HipRun(sc)
+            grads[mode] = {n: getattr(r, n).grad.cpu().numpy() for n in ("means3D", "opacities", "colors", "scales", "rotations")}
+    finally:
+        lib.splatraster_debug_set_fwd_team(-1)
+    for n, g0 in grads[0].items():
+        assert_grad_close(n, grads[2][n], g0, rtol=1e-4, atol_scale=2e-5)
 
 
 def test_team_forward_soak():
