@@ -691,7 +691,7 @@ def bench_scene(args, dev, rank=0, world=1):
     from splatloc_amd.ply import save_ply
     from splatloc_amd.scene import DEFAULT_CONFIG, SceneModel, do_recon, synthetic_keyframes
     K, W, H = args.keyframes, 640, 480
-    replicas = bool(args.replicas) and world > 1
+    replicas = bool(args.replicas) and DIST_ON
     scene_seed = rank if replicas else 0
     t0 = time.perf_counter()
     frames, _ = synthetic_keyframes(K, W, H, P_truth=args.truth, seed=scene_seed, device=dev)
@@ -701,11 +701,11 @@ def bench_scene(args, dev, rank=0, world=1):
     bg = torch.zeros(3, device=dev)
     model = SceneModel(DEFAULT_CONFIG, dev)
     torch.cuda.reset_peak_memory_stats(dev)
-    if world > 1:
+    if DIST_ON:
         dist.barrier()
         torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
-    grp = None if (replicas or world == 1) else dist.group.WORLD
+    grp = None if (replicas or not DIST_ON) else dist.group.WORLD
     stats = do_recon(model, frames, pipe, bg, DEFAULT_CONFIG, refine_iterations=args.refine, seed=scene_seed,
                      batched=not args.no_window, group=grp, distributed=not replicas)
     t_recon = time.perf_counter() - t1
@@ -723,7 +723,7 @@ def bench_scene(args, dev, rank=0, world=1):
     per_rank = [{"rank": rank, "recon_s": round(t_recon, 3), "map_s": round(stats["map_seconds"], 3),
                  "refine_s": round(stats["refine_seconds"], 3), "rows_final": stats["rows_final"],
                  "mean_psnr": round(ev["mean_psnr"], 3), "peak_memory_GB": round(stats["peak_memory_bytes"] / 2 ** 30, 3)}]
-    if world > 1:
+    if DIST_ON:
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])       # reporting only (control plane): after the timed schedule
         per_rank = gathered
@@ -731,7 +731,7 @@ def bench_scene(args, dev, rank=0, world=1):
         return
     t_max = max(r["recon_s"] for r in per_rank)
     n_scenes = world if replicas else 1
-    mode = "replicas" if replicas else ("frame-parallel" if world > 1 else "single")
+    mode = "replicas" if replicas else ("frame-parallel" if DIST_ON else "single")
     print(json.dumps({
         "metric": "SplatLoc.do_recon scenes/hour on synthetic key-frames (whole schedule; secondary figure, NOT the BASELINE metric)",
         "value": round(3600.0 * n_scenes / t_max, 3), "unit": "scenes/h", "n_gpus": world, "steps": 1, "warmup": 0,
@@ -742,9 +742,10 @@ def bench_scene(args, dev, rank=0, world=1):
                                f"{args.refine} color_refinement iterations; save_ply; eval_rendering",
                    "launch_mode": "per-view calls" if args.no_window else "window-batched",
                    "multi_gpu_mode": mode, "scenes": n_scenes,
-                   "collectives_on_the_data_path": 0 if (replicas or world == 1) else "2 payload + 1 header per map step, 1 broadcast after the refinement",
-                   "reduce": None if (replicas or world == 1) else args.reduce,
-                   "dist_backend": None if world == 1 else os.environ.get("SPLATLOC_DIST_BACKEND", "nccl")},
+                   "collectives_on_the_data_path": 0 if (replicas or not DIST_ON) else "2 payload + 1 header per map step, 1 broadcast after the refinement",
+                   "reduce": None if (replicas or not DIST_ON) else args.reduce,
+                   "dist_backend": None if not DIST_ON else dist.get_backend(),
+                   "dist_env": dist_env_report() if DIST_ON else None},
         "per_rank": per_rank,
         "seconds": {"synthetic_keyframes": round(t_data, 2), "map_phase": round(stats["map_seconds"], 2),
                     "refine_phase": round(stats["refine_seconds"], 2), "save_ply": round(t_ply, 3), "eval_rendering": round(t_eval, 3)},
@@ -895,6 +896,21 @@ def bench_eval_rendering(args, dev):
     }), flush=True)
 
 
+DIST_ON = False      # a process group exists (N > 1 ranks, or --force-process-group's group of one)
+
+
+def dist_env_report() -> dict:
+    """What the collectives of this run ran on: backend, RCCL version, the IPC mode variable RCCL needs on this pool."""
+    rep = {"backend": dist.get_backend() if dist.is_initialized() else None, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+           "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+           "NCCL_DEBUG": os.environ.get("NCCL_DEBUG"), "torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+    try:
+        rep["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:  # noqa: BLE001
+        rep["rccl_version"] = f"unavailable ({type(e).__name__})"
+    return rep
+
+
 def count_gpus_without_hip() -> int:
     """GPUs of this node as the KFD driver lists them (/sys/class/kfd/kfd/topology/nodes/*/properties: a node with
     simd_count > 0 is a GPU), narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES — read without
@@ -972,6 +988,10 @@ def main():
                          "frame-parallel by the N ranks")
     ap.add_argument("--reduce", default="ring", choices=["ring", "rs_ag"],
                     help="N > 1: the SUM exchange of a step as one all-reduce (ring) or as reduce-scatter + all-gather (rs_ag)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="--gpus 1: create a world-size-1 RCCL ('nccl') process group with device_id= and issue EVERY collective of the "
+                         "N > 1 path on it (in-place span SUM, MAX, header, barrier; --reduce rs_ag: the aliased reduce-scatter + "
+                         "all-gather pair) — first contact with RCCL on a one-GPU box; values are unchanged by construction")
     ap.add_argument("--truth", type=int, default=200_000, help="--stage scene: Gaussians of the synthetic ground-truth room")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of K steps is repeated this many times; value = the MEDIAN region (min / max reported)")
@@ -995,8 +1015,21 @@ def main():
     dev_index = local_rank % max(ndev, 1)   # > 1 rank per GPU only in the single-GPU plumbing test
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    global DIST_ON
+    DIST_ON = world > 1 or args.force_process_group
+    if DIST_ON:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1 and "MASTER_PORT" not in os.environ:     # --force-process-group without a launcher: a group of one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if args.force_process_group:
+            from splatloc_amd import frame_parallel as _fp
+            _fp.FORCE_COLLECTIVES = True
         # "nccl" is RCCL on ROCm (xGMI); SPLATLOC_DIST_BACKEND=gloo lets tests drive this exact
         # code path with several ranks on one GPU.
         backend = os.environ.get("SPLATLOC_DIST_BACKEND", "nccl")
@@ -1007,7 +1040,7 @@ def main():
 
     from splatloc_amd import training as _training
     _training.REDUCE_MODE = args.reduce
-    if args.stage == "scene" and world > 1:
+    if args.stage == "scene" and DIST_ON:
         bench_scene(args, dev, rank, world)
         dist.barrier()
         dist.destroy_process_group()
@@ -1017,7 +1050,7 @@ def main():
             {"activations": bench_activations, "loss": bench_loss, "map_step": bench_map_step,
              "refine_step": bench_refine_step, "scene": bench_scene, "eval_rendering": bench_eval_rendering,
              "pose_refine": bench_pose_refine}[args.stage](args, dev)
-        if world > 1:
+        if DIST_ON:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -1070,7 +1103,7 @@ def main():
         # gradients in-kernel, then the per-view densification statistics (train_gaussians.py:238-245)
         block = torch.zeros((len(views),) + tuple(means3D.shape), dtype=means3D.dtype, device=means3D.device)
         carriers = [block[k].requires_grad_(True) for k in range(len(views))]       # render(): screenspace_points per view (one zero fill)
-        span = [] if world > 1 else None    # N > 1: the backward's gradient allocation ends with a [2, P] tail for the statistics increments
+        span = [] if DIST_ON else None    # N > 1: the backward's gradient allocation ends with a [2, P] tail for the statistics increments
         outs = rasterize_window([rs for _, _, rs in views], means3D, carriers, colors, opac, scales=scales, rotations=rots,
                                 grad_span=span)
         if record:
@@ -1104,7 +1137,7 @@ def main():
         for p in params:
             p.grad = None
         inc = None
-        if world > 1 and not (mode["window"] and views):
+        if DIST_ON and not (mode["window"] and views):
             accum.zero_()      # the per-view paths accumulate the step's increments here (summed over the ranks below)
             denom.zero_()
         if mode["window"] and views:
@@ -1124,7 +1157,7 @@ def main():
         else:
             for rast, g_out, _ in views:   # every frame one forward + one backward, parameter gradients accumulate
                 one_view(rast, g_out, record)
-        if not args.fwd_only and world > 1:
+        if not args.fwd_only and DIST_ON:
             # TWO collectives per step (frame_parallel.reduce_step): ONE SUM all-reduce over [accumulated parameter gradients |
             # increments of xyz_gradient_accum, denom] — in place in the backward's own allocation on the window path — and
             # ONE MAX all-reduce of max_radii2D, so that every replica would take the same optimizer step and densify identically
@@ -1150,7 +1183,7 @@ def main():
             info["reduce_path"] = red
 
     def barrier():
-        if world > 1:
+        if DIST_ON:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -1182,7 +1215,7 @@ def main():
         regions_unix.append([u0, time.time()])
     _native.timing_enable(False)
     stages[dom] = _native.timing_collect()[dom]
-    if world > 1:       # MAX over the ranks, region by region
+    if DIST_ON:       # MAX over the ranks, region by region
         t = torch.tensor(regions, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         regions = [float(x) for x in t.tolist()]
@@ -1330,10 +1363,11 @@ def main():
                            "bytes of this implementation's stage (actual_GBps is quoted on it; P-sized inputs are "
                            "shared by the 5 views of a step and may be served by the 256-MiB Infinity Cache)",
         }
-        if world > 1:
+        if DIST_ON:
             red = info.get("reduce_path") or {}
             out["rccl_ranks"] = dist.get_world_size()
             out["dist_backend"] = dist.get_backend()
+            out["dist_env"] = dist_env_report()
             out["reduce_path"] = red.get("sum_path")
             out["collectives_per_step"] = red.get("collectives")
             out["config"]["grad_allreduce_path"] = red
@@ -1344,7 +1378,7 @@ def main():
             if args.workload == "S0":      # BASELINE config 1: the PyTorch-CPU autograd reference, timed beside the oracle
                 out["cpu_baseline"]["pytorch_cpu_autograd"] = cpu_baseline_torch_dense("S0")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if DIST_ON:
         dist.barrier()
         dist.destroy_process_group()
 

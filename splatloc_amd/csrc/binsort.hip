@@ -84,7 +84,7 @@ template <int ROWS, bool SCATTER>
 __global__ void __launch_bounds__(BIN_THREADS)
 bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __restrict__ rec,
                 uint32_t* __restrict__ table /*[(v * tiles + t) * nchunk + chunk]: COUNT out / exclusive prefix in*/,
-                uint64_t* __restrict__ keys /*SCATTER: [R]*/, uint32_t* __restrict__ big_count /*COUNT: zeroed here*/)
+                uint64_t* __restrict__ keys /*SCATTER: [R]*/, uint32_t* __restrict__ big_count /*zeroed here, by both walks*/)
 {
     extern __shared__ uint32_t s_bin[];
     __shared__ uint64_t s_qkey[BIN_QUEUE];
@@ -92,7 +92,9 @@ bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __re
     __shared__ uint32_t s_qn;
     const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
     uint32_t* col = table + (size_t)v * tiles * nchunk + chunk;
-    if (!SCATTER && big_count && t == 0 && chunk == 0 && v == 0) *big_count = 0u;
+    // the work list of the tile kernel (the launch behind the SCATTER walk) starts empty on EVERY render of this geometry: a
+    // second render stage on the same geometry buffer must not append behind the first one's entries
+    if (big_count && t == 0 && chunk == 0 && v == 0) *big_count = 0u;
     if (t == 0) s_qn = 0u;
     // A block's rows are 64-row groups INTERLEAVED over the whole view (group j of the block = group j nchunk + chunk of the view):
     // a map's rows are spatially coherent — one 2048-row run can be a near wall whose every Gaussian covers hundreds of tiles —
@@ -560,9 +562,9 @@ int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V,
     const int gtiles = V * tiles;
     (void)R;
     switch (bin_rows_per_thread(P, V, tiles)) {
-        case 1: SR_BIN_WALK(1, true, const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr); break;
-        case 2: SR_BIN_WALK(2, true, const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr); break;
-        default: SR_BIN_WALK(8, true, const_cast<uint32_t*>(table), keys, (uint32_t*)nullptr); break;
+        case 1: SR_BIN_WALK(1, true, const_cast<uint32_t*>(table), keys, g.total + 2); break;
+        case 2: SR_BIN_WALK(2, true, const_cast<uint32_t*>(table), keys, g.total + 2); break;
+        default: SR_BIN_WALK(8, true, const_cast<uint32_t*>(table), keys, g.total + 2); break;
     }
 #undef SR_BIN_WALK
     SR_LAUNCH_CHECK();

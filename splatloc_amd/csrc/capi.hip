@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -354,12 +355,35 @@ static WinCams make_cams(int32_t V, const splatraster_window_view* views)
 // The binned front end (binsort.hip) keeps its (tile, chunk) table and the state of its scan where the radix front end
 // keeps the depth-sort buffers (sort_keys ... scan_tmp): the geometry buffer's size does not depend on the path.
 struct BinScratch { bool on; uint32_t* table; void* scan_tmp; int64_t entries; };
-static BinScratch bin_scratch(const splatraster_settings& s, int32_t P, int32_t V, void* geometry)
+
+// Which front end the GEOMETRY stage chose for a geometry buffer: the render stage is a separate public call and must follow
+// that choice, not re-derive it from the process-wide debug switch (splatraster_debug_set_front_end between the two stages
+// would otherwise make the render read a (tile, chunk) table that was never built).  Host-side, keyed by the buffer's address;
+// an address the geometry stage has not seen (or that was dropped when the map was trimmed) falls back to use_bins().
+static std::mutex g_front_end_mu;
+static std::unordered_map<const void*, bool> g_front_end;
+static void front_end_record(const void* geometry, bool on)
+{
+    std::lock_guard<std::mutex> lk(g_front_end_mu);
+    if (g_front_end.size() > (1u << 14)) g_front_end.clear();
+    g_front_end[geometry] = on;
+}
+static int front_end_recorded(const void* geometry)   // -1 unknown, 0 radix, 1 binned
+{
+    std::lock_guard<std::mutex> lk(g_front_end_mu);
+    auto it = g_front_end.find(geometry);
+    return it == g_front_end.end() ? -1 : (it->second ? 1 : 0);
+}
+
+static BinScratch bin_scratch(const splatraster_settings& s, int32_t P, int32_t V, void* geometry, bool geometry_stage)
 {
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE, tiles = gx * gy;
     const GeomLayout L = geom_layout(P, V);
     BinScratch b{};
-    b.on = geometry && use_bins(P, V, gx, gy, L.total - L.sort_keys);
+    if (!geometry || P <= 0) return b;
+    const int recorded = geometry_stage ? -1 : front_end_recorded(geometry);
+    b.on = recorded >= 0 ? recorded == 1 : use_bins(P, V, gx, gy, L.total - L.sort_keys);
+    if (geometry_stage) front_end_record(geometry, b.on);
     if (!b.on) return b;
     char* base = reinterpret_cast<char*>(geometry);
     b.entries = (int64_t)bin_table_entries(P, V, tiles);
@@ -402,12 +426,19 @@ static int window_geometry(const splatraster_settings* s, int32_t V, const splat
     GeomView g = geom_view(geometry, P, V);
     char* base = reinterpret_cast<char*>(geometry);
     const WinCams cams = make_cams(V, views);
-    const BinScratch bins = bin_scratch(*s, P, V, geometry);
+    const BinScratch bins = bin_scratch(*s, P, V, geometry, true);
     HostSlot* slot = nullptr;
     const size_t nblk = (size_t)preprocess_blocks(P);
     st = host_slot(nblk * (size_t)V, &slot);
     if (st) return st;
     g.block_tiles = slot->dp;     // the per-(view, block) instance sums land in host memory
+    // preprocess_kernel stores into the thread's pinned slot: an error return between its launch and the wait below must not
+    // leave the kernel writing a slot the next call on this thread may free, reallocate or read (state 1: launched, wait for
+    // the stream; 2: the event behind the kernel is recorded, wait for that; 0: nothing in flight)
+    struct SlotGuard {
+        HostSlot* slot; hipStream_t stream; int state;
+        ~SlotGuard() { if (state == 2) (void)hipEventSynchronize(slot->ev); else if (state == 1) (void)hipStreamSynchronize(stream); }
+    } guard{slot, stream, 1};
     {
         StageTimer t(SPLATRASTER_STAGE_PREPROCESS, stream);
         // the look-back state of the depth sort and of the scan is cleared by preprocess_kernel
@@ -422,6 +453,7 @@ static int window_geometry(const splatraster_settings* s, int32_t V, const splat
     }
     if (st) return st;
     SR_HIP_CHECK(hipEventRecord(slot->ev, stream));
+    guard.state = 2;
     if (bins.on) {
         // binned front end (binsort.hip): per-(tile, chunk) counts + their scan instead of the depth sort + offsets scan
         StageTimer t(SPLATRASTER_STAGE_DEPTH_SORT, stream);
@@ -444,7 +476,8 @@ static int window_geometry(const splatraster_settings* s, int32_t V, const splat
     }
     if (st) return st;
     }
-    SR_HIP_CHECK(hipEventSynchronize(slot->ev));  // the copy only: sort and scan may still be running
+    SR_HIP_CHECK(hipEventSynchronize(slot->ev));  // preprocess only: sort and scan may still be running
+    guard.state = 0;
     uint64_t total = 0;
     for (int v = 0; v < V; ++v) {
         uint64_t tv = 0;
@@ -489,7 +522,7 @@ static int window_render(const splatraster_settings* s, int32_t V, const splatra
     uint32_t* v0 = (passes & 1) ? b.vals_tmp : b.point_list;
     uint32_t* k1 = (passes & 1) ? b.tile_list : b.keys_tmp;
     uint32_t* v1 = (passes & 1) ? b.point_list : b.vals_tmp;
-    const BinScratch bins = bin_scratch(*s, P, V, geometry);
+    const BinScratch bins = bin_scratch(*s, P, V, geometry, false);
     if (R > 0 && bins.on) {
         // binned front end: scatter the 64-bit keys into their (tile, chunk) pieces, sort every tile's list in LDS and write
         // the payload + lists + ranges (binsort.hip); the keys live where the radix path keeps its unsorted pairs

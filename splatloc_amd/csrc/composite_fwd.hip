@@ -515,7 +515,8 @@ __device__ __forceinline__ void narrow_quadrant(SR_FWD_PARAMS, int gtile, int qu
 }
 
 template <int NC>
-__global__ void __launch_bounds__(WAVE, 7)   // 72 registers: at 64 the four-channel instantiation spills 12
+__global__ void __launch_bounds__(WAVE, 7)   // the budget is 72 registers / 7 waves per SIMD (pinned by tests/test_codegen_budget.py); ROCm 7.2 lands
+                                             // at 64 / 8 by itself, while a bound of 8 makes the allocator spill the four-channel instantiation
 composite_fwd_narrow_kernel(SR_FWD_PARAMS, const uint32_t* __restrict__ tile_order /*launch order (binning.hip), or null*/)
 {
     __shared__ __attribute__((aligned(16))) float4 s_rec0[WAVE + 1];

@@ -345,12 +345,16 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
             const unsigned nsets = gridDim.x < (unsigned)POSE_SETS ? gridDim.x : (unsigned)POSE_SETS;
             unsigned* set_ticket = reinterpret_cast<unsigned*>(pose_acc + q * POSE_SET_FLOATS + (POSE_SET_FLOATS - 1));
             unsigned* ticket = reinterpret_cast<unsigned*>(pose_acc + POSE_SETS * POSE_SET_FLOATS);
+            // release / acquire at agent scope on both tickets: this block's additions (ordered before this thread by the
+            // barrier above) happen-before the winner's loads of the sets by the memory model, not only by today's codegen
             bool last = false;
-            if (atomicAdd(set_ticket, 1u) == in_set - 1) last = atomicAdd(ticket, 1u) == nsets - 1;
+            if (__hip_atomic_fetch_add(set_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == in_set - 1)
+                last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nsets - 1;
             s_last = last;
         }
         __syncthreads();
         if (s_last && threadIdx.x < 35) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const int e = threadIdx.x;      // output entry: dV[0..15], dPM[16..31], dcampos[32..34]
             int k = -1;                     // its partial (dV[4c + r], r < 3: 3c + r; dPM[4c + j], j = 0, 1, 3: 12 + 3c + (j == 3 ? 2 : j))
             if (e < 16) { if ((e & 3) < 3) k = 3 * (e >> 2) + (e & 3); }

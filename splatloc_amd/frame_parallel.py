@@ -18,10 +18,27 @@ xGMI is point-to-point (7 links/GPU): the payload (64 B/Gaussian at the referenc
 """
 from __future__ import annotations
 
+import os
+import time
 from typing import Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+# A process group of ONE rank normally exchanges nothing (every function below returns early).  `force=True` (or
+# SPLATLOC_FORCE_COLLECTIVES=1 for code that cannot pass the argument) issues every collective anyway: a world-size-1 RCCL
+# group on the one GPU a builder box has exercises the exact calls the 8-GPU run makes — the in-place span SUM on the
+# backward's own allocation, the MAX, the aliased reduce-scatter + all-gather pair, the header, the broadcast
+# (tests/test_gpu_rccl.py, bench.py --force-process-group).  A SUM / MAX / broadcast over one rank leaves the values unchanged.
+FORCE_COLLECTIVES = os.environ.get("SPLATLOC_FORCE_COLLECTIVES", "0") == "1"
+
+
+def collectives_active(group=None, force: bool = False) -> bool:
+    """True when the functions of this module will issue collectives: a process group exists and has more than one rank
+    (or `force` / FORCE_COLLECTIVES asks for them on a group of one)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or force or FORCE_COLLECTIVES
 
 
 def shard_views(view_ids: Sequence[int], rank: int, world_size: int) -> List[int]:
@@ -66,7 +83,7 @@ def _shared_spans(ts: List[torch.Tensor]):
     return spans, rest
 
 
-def allreduce_grads(tensors: Iterable[Optional[torch.Tensor]], group=None, bucket_bytes: int = 256 << 20):
+def allreduce_grads(tensors: Iterable[Optional[torch.Tensor]], group=None, bucket_bytes: int = 256 << 20, force: bool = False):
     """SUM-all-reduce gradient tensors in place, as few large buffers.
 
     Gradients that already live side by side in one allocation (see _shared_spans) are
@@ -79,7 +96,7 @@ def allreduce_grads(tensors: Iterable[Optional[torch.Tensor]], group=None, bucke
     views as `.grad` (it does when a parameter's first gradient of the step is one of them); a silent
     fall-back to the staged bucket path would otherwise go unnoticed (None when not distributed).
     """
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not collectives_active(group, force):
         return None
     with torch.no_grad():
         spans, ts = _shared_spans([t for t in tensors if t is not None])
@@ -121,10 +138,10 @@ def allreduce_grads(tensors: Iterable[Optional[torch.Tensor]], group=None, bucke
 
 
 def sync_densification_stats(grad_accum_inc: torch.Tensor, denom_inc: torch.Tensor, max_radii2D: torch.Tensor,
-                             group=None) -> None:
+                             group=None, force: bool = False) -> None:
     """Make every replica densify identically: SUM the per-step increments of
     xyz_gradient_accum / denom and MAX max_radii2D (in place)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not collectives_active(group, force):
         return
     packed = torch.cat([grad_accum_inc.reshape(-1), denom_inc.reshape(-1)])
     w1 = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -176,7 +193,7 @@ def _sum_all_ranks(buf: torch.Tensor, group, mode: str):
 
 
 def reduce_step(grads: Sequence[torch.Tensor], sum_extras: Sequence[torch.Tensor] = (),
-                max_extras: Sequence[torch.Tensor] = (), group=None, mode: str = "ring"):
+                max_extras: Sequence[torch.Tensor] = (), group=None, mode: str = "ring", force: bool = False):
     """Everything one frame-parallel optimisation step exchanges, in at most TWO collectives:
 
       (1) ONE SUM all-reduce over [grads | sum_extras] — the parameter gradients and the increments of
@@ -197,9 +214,11 @@ def reduce_step(grads: Sequence[torch.Tensor], sum_extras: Sequence[torch.Tensor
 
     Returns (grads_out, sum_extras_out, info): tensors holding the reduced values (the inputs themselves on the in-place
     path) and info = {"collectives", "sum_path": "in-place span" | "packed", "sum_bytes", "max_bytes", "mode"}.
-    Single process / no process group: returns the inputs unchanged, info["collectives"] = 0."""
+    Single process / no process group: returns the inputs unchanged, info["collectives"] = 0 (`force=True`: a group of
+    one rank issues every collective anyway — first contact with RCCL on one GPU).  info["header_ms"] is what the length
+    check cost this rank: it reads its result on the host, so the stream is drained once per step in front of the payload."""
     grads, sum_extras, max_extras = list(grads), list(sum_extras), list(max_extras)
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not collectives_active(group, force):
         return grads, sum_extras, {"collectives": 0, "sum_path": None, "sum_bytes": 0, "max_bytes": 0}
     if mode not in ("ring", "rs_ag"):
         raise ValueError(f"reduce_step: mode {mode!r}")
@@ -226,8 +245,10 @@ def reduce_step(grads: Sequence[torch.Tensor], sum_extras: Sequence[torch.Tensor
                 buf = packed = torch.cat(parts)
                 info["sum_path"] = "packed"
         max_len = sum(t.numel() for t in max_extras)
+        t_h = time.perf_counter()
         _check_same_layout((buf.numel(), max_len), buf.device, group)   # both payload lengths in one header
         info["header_collectives"] = 1
+        info["header_ms"] = round(1e3 * (time.perf_counter() - t_h), 4)
         info["sum_bytes"] = buf.numel() * buf.element_size()
         pending.append(_sum_all_ranks(buf, group, mode))
         info["collectives"] += 2 if (mode == "rs_ag" and _backend_of(group) != "gloo") else 1
@@ -237,8 +258,10 @@ def reduce_step(grads: Sequence[torch.Tensor], sum_extras: Sequence[torch.Tensor
         with torch.no_grad():
             mbuf = mx[0].view(-1) if (len(mx) == 1 and mx[0].is_contiguous()) else torch.cat([t.reshape(-1) for t in mx])
         if not members:
+            t_h = time.perf_counter()
             _check_same_layout((0, mbuf.numel()), mbuf.device, group)
             info["header_collectives"] = 1
+            info["header_ms"] = round(1e3 * (time.perf_counter() - t_h), 4)
         info["max_bytes"] = mbuf.numel() * mbuf.element_size()
         pending.append(dist.all_reduce(mbuf, op=dist.ReduceOp.MAX, group=group, async_op=True))
         info["collectives"] += 1
@@ -261,13 +284,13 @@ def reduce_step(grads: Sequence[torch.Tensor], sum_extras: Sequence[torch.Tensor
     return outs[:len(grads)], outs[len(grads):], info
 
 
-def broadcast_model(gaussians, src: int = 0, group=None) -> int:
+def broadcast_model(gaussians, src: int = 0, group=None, force: bool = False) -> int:
     """Re-establish bit-identical replicas from rank `src`: every parameter, Adam moment and step counter, the xyz learning
     rate and the densification statistics, packed into ONE broadcast.  Used after a phase that every rank ran redundantly on
     its own replica — SplatLoc.color_refinement is one view per step (train_gaussians.py:269-297): it does not shard, and
     float-atomic rounding makes redundant replicas drift apart in the last bits.  Returns the bytes broadcast (0 when not
     distributed)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not collectives_active(group, force):
         return 0
     opt = gaussians.optimizer
     tensors, scalars = [], []

@@ -239,11 +239,12 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
     Returns the rank's loss tensor (None on a rank without work)."""
     import torch.distributed as dist
     from .densify import densify_and_prune, reset_opacity_nonvisible
-    from .frame_parallel import reduce_step, shard_views
+    from .frame_parallel import collectives_active, reduce_step, shard_views
     from .losses import isotropic_loss, mapping_loss_window
     # `distributed=False`: this rank reconstructs its OWN scene although a process group exists (one scene per GPU,
-    # /root/reference/replica.sh; bench.py --stage scene --replicas): no collective at all
-    multi = distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    # /root/reference/replica.sh; bench.py --stage scene --replicas): no collective at all.  (A group of ONE rank exchanges
+    # nothing either, unless SPLATLOC_FORCE_COLLECTIVES=1 asks for the collectives anyway: the one-GPU RCCL contact test.)
+    multi = distributed and collectives_active(group)
     rank = dist.get_rank(group) if multi else 0
     world = dist.get_world_size(group) if multi else 1
     primitive_reg = bool(config["Training"].get("primitive_reg", True))
@@ -300,7 +301,7 @@ def map_step(viewpoints, gaussians, pipe, background, config, iteration_count: i
                 add_densification_stats_window(grads2d, radii, inc[0], inc[1], gaussians.max_radii2D)
             g_out, inc_out, info = reduce_step([p.grad for p in live], sum_extras=[inc[0], inc[1]],
                                                max_extras=[gaussians.max_radii2D] + ([seen] if seen is not None else []),
-                                               group=group, mode=REDUCE_MODE)
+                                               group=group, mode=REDUCE_MODE, force=True)
             for p, g in zip(live, g_out):
                 p.grad = g          # views of the reduced buffer: no copy back
             gaussians.xyz_gradient_accum += inc_out[0]

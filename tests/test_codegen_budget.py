@@ -49,7 +49,8 @@ def test_forward_kernels_have_no_scratch_and_keep_their_occupancy():
     for nc, k in list(fwd.items()) + list(narrow.items()) + list(mixed.items()):
         assert k["ScratchSize"] == 0 and k["VGPRs Spill"] == 0, (nc, k)
     for nc in (1, 2, 3, 4):
-        assert narrow[nc]["VGPRs"] <= 64 and narrow[nc]["Occupancy"] == 8, (nc, narrow[nc])     # 64 registers, 8 waves per SIMD
+        # the declared budget, __launch_bounds__(WAVE, 7): <= 72 registers, >= 7 waves per SIMD (today's toolchain: 64 / 8)
+        assert narrow[nc]["VGPRs"] <= 72 and narrow[nc]["Occupancy"] >= 7, (nc, narrow[nc])
         # one workgroup of four waves per tile / per quadrant of a long list: five workgroups per CU by LDS, never fewer by registers
         assert mixed[nc]["VGPRs"] <= 96 and mixed[nc]["Occupancy"] >= 5 and mixed[nc]["LDS Size"] <= 28 * 1024, (nc, mixed[nc])
     assert fwd[35]["VGPRs"] <= 96 and fwd[35]["Occupancy"] >= 5, fwd[35]      # the headline layout: 5 waves per SIMD

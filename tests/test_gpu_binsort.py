@@ -143,3 +143,70 @@ def test_window_of_views_binned_equals_radix():
         assert torch.equal(a["final_T"].view(torch.int32), b["final_T"].view(torch.int32))
         for i in range(3):
             assert torch.equal(outs[0][0][v][i].view(torch.int32), outs[1][0][v][i].view(torch.int32))
+
+
+def _two_stage_forward(sc, flip_front_end_between_stages=None, renders=2):
+    """The two public forward stages called directly (include/splatraster.h): ONE geometry stage, then `renders` render stages
+    on the same geometry buffer, each with a FRESH (garbage-filled) binning buffer.  Returns the images of every render."""
+    import ctypes as C
+    from splatloc_amd.rasterizer import _ptr, _stream
+    lib = _native.load()
+    dev = torch.device("cuda:0")
+    cam = sc.camera
+    P, H, W, Cn = sc.means3D.shape[0], cam.image_height, cam.image_width, sc.features.shape[1]
+    t = lambda x: x.to(dev).contiguous().float()  # noqa: E731
+    m3, col, opa, sca, rot = t(sc.means3D), t(sc.features), t(sc.opacities), t(sc.scales), t(sc.rotations)
+    view, proj, campos, bg = t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center), t(sc.bg)
+    st = _native.Settings(H, W, float(cam.tanfovx), float(cam.tanfovy), 1.0, 0, 0, Cn, int(bg.numel()), 0, 0)
+    geom = torch.empty((lib.splatraster_geometry_bytes(P),), dtype=torch.uint8, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    stream = _stream(dev)
+    R = C.c_int64(0)
+    _native.check(lib.splatraster_forward_geometry(C.byref(st), P, _ptr(m3), None, _ptr(opa), _ptr(sca), _ptr(rot), None, _ptr(view),
+                                                   _ptr(proj), _ptr(campos), _ptr(geom), _ptr(radii), C.byref(R), stream), "geometry")
+    if flip_front_end_between_stages is not None:
+        _native.set_front_end(flip_front_end_between_stages)
+    outs = []
+    for k in range(renders):
+        nbytes = lib.splatraster_binning_bytes(P, R.value, W, H, Cn)
+        binning = torch.full((nbytes,), 0xA5 if k else 0x5A, dtype=torch.uint8, device=dev)      # never zero-initialised
+        img = torch.empty((lib.splatraster_image_bytes(W, H),), dtype=torch.uint8, device=dev)
+        color = torch.empty((Cn, H, W), device=dev)
+        depth = torch.empty((1, H, W), device=dev)
+        alpha = torch.empty((1, H, W), device=dev)
+        _native.check(lib.splatraster_forward_render(C.byref(st), P, R.value, _ptr(bg), _ptr(col), _ptr(geom), _ptr(binning), _ptr(img),
+                                                     _ptr(color), _ptr(depth), _ptr(alpha), stream), "render")
+        torch.cuda.synchronize()
+        outs.append((color, depth, alpha))
+    return outs, int(R.value)
+
+
+def test_second_render_stage_on_the_same_geometry_starts_with_an_empty_work_list():
+    """Round-5 advisor finding: the work-list counter of the binned front end lives in the GEOMETRY buffer and was zeroed only
+    by the geometry stage; a second `splatraster_forward_render` on the same geometry (other features, a fresh binning buffer)
+    appended behind the first render's entries and then walked uninitialised tile ids.  `one_long_list` puts a 9 000-key list
+    on the work list.  Three renders with garbage-filled binning buffers: identical images, equal to the oracle's."""
+    sc = CASES["one_long_list"]()
+    f = oracle_forward(sc)
+    _native.set_front_end(1)
+    outs, R = _two_stage_forward(sc, renders=3)
+    assert R == int(f["num_rendered"])
+    for color, depth, alpha in outs:
+        assert np.abs(color.cpu().numpy() - f["color"]).max() <= 1e-4
+        assert np.abs(alpha.cpu().numpy().reshape(f["alpha"].shape) - f["alpha"]).max() <= 1e-4
+    for k in (1, 2):
+        for a, b in zip(outs[0], outs[k]):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.parametrize("first,then", [(1, 0), (0, 1)])
+def test_render_stage_follows_the_front_end_the_geometry_stage_chose(first, then):
+    """`splatraster_debug_set_front_end` between the two stages: the render stage must keep the geometry stage's choice (the
+    binned render needs the (tile, chunk) table the geometry stage built; the radix render needs the depth order)."""
+    sc = CASES["deep_lists"]()
+    f = oracle_forward(sc)
+    _native.set_front_end(first)
+    outs, _ = _two_stage_forward(sc, flip_front_end_between_stages=then, renders=1)
+    color, depth, alpha = outs[0]
+    assert np.abs(color.cpu().numpy() - f["color"]).max() <= 1e-4
+    assert np.abs(alpha.cpu().numpy().reshape(f["alpha"].shape) - f["alpha"]).max() <= 1e-4

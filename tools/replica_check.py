@@ -21,26 +21,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--P", type=int, default=20000)
-    ap.add_argument("--window", type=int, default=5, help="views per window (1: every rank but the first has no work)")
-    args = ap.parse_args()
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
-    torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SPLATLOC_DIST_BACKEND", "nccl")
-        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+def make_replica(dev, P=20000, W=320, H=240):
+    """One seeded replica of a small SplatLoc model (the reference's parameter groups, fused Adam) + 10 views with ground-truth
+    images — what every rank of a frame-parallel run holds.  Returns (pc, views, bg, pipe, cfg, dens)."""
     from splatloc_amd.camera import PinholeCamera
     from splatloc_amd.optim import Adam
     from splatloc_amd.synthetic import make_scene
-    from splatloc_amd import training
-    from splatloc_amd.training import map_step
-    W, H, P = 320, 240, args.P
     sc = make_scene(P, W, H, 4, seed=77, scale_median=0.03)
     g = torch.Generator().manual_seed(5)
     names = ("xyz", "f_dc", "f_rest", "opacity", "marker", "kp_score", "scaling", "rotation")
@@ -75,6 +61,26 @@ def main():
     pipe = types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
     cfg = {"Training": {"rgb_boundary_threshold": 0.01, "primitive_reg": True}}
     dens = dict(grad_threshold=0.0002, min_opacity=0.005, extent=6.0, size_threshold=20, every=3, offset=2)
+    return pc, views, bg, pipe, cfg, dens
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--P", type=int, default=20000)
+    ap.add_argument("--window", type=int, default=5, help="views per window (1: every rank but the first has no work)")
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("SPLATLOC_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    from splatloc_amd import training
+    from splatloc_amd.training import map_step
+    pc, views, bg, pipe, cfg, dens = make_replica(dev, args.P)
     rows, colls = [], []
     for it in range(1, args.steps + 1):
         perm = torch.randperm(len(views), generator=torch.Generator().manual_seed(1000 + it))[:args.window]   # the same draw on every rank
