@@ -896,6 +896,39 @@ def bench_eval_rendering(args, dev):
     }), flush=True)
 
 
+def start_gpu_sampler(hz: float = 40.0):
+    """tools/gpu_sampler.py as a child process (amdsmi only, no HIP); returns (Popen, path) or None when it cannot start."""
+    import subprocess
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"splatloc_gpu_samples_{os.getpid()}.json")
+    try:
+        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gpu_sampler.py"), path, str(hz)], stdin=subprocess.PIPE,
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
+    except OSError:
+        return None
+    return p, path
+
+
+def stop_gpu_sampler(sampler, spans):
+    """Close the sampler's stdin (it writes its samples and exits) and reduce the samples inside `spans`."""
+    p, path = sampler
+    try:
+        p.stdin.close()
+        p.wait(timeout=20)
+        with open(path) as f:
+            data = json.load(f)
+        os.remove(path)
+    except Exception as ex:  # noqa: BLE001
+        try:
+            p.kill()
+        except Exception:  # noqa: BLE001
+            pass
+        return {"available": False, "why": f"sampler: {ex!r}"[:160]}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gpu_sampler import summarize
+    return summarize(data, spans)
+
+
 DIST_ON = False      # a process group exists (N > 1 ranks, or --force-process-group's group of one)
 
 
@@ -992,6 +1025,8 @@ def main():
                     help="--gpus 1: create a world-size-1 RCCL ('nccl') process group with device_id= and issue EVERY collective of the "
                          "N > 1 path on it (in-place span SUM, MAX, header, barrier; --reduce rs_ag: the aliased reduce-scatter + "
                          "all-gather pair) — first contact with RCCL on a one-GPU box; values are unchanged by construction")
+    ap.add_argument("--no-telemetry", action="store_true",
+                    help="do not start tools/gpu_sampler.py (amdsmi activity / clock / power samples across the timed regions)")
     ap.add_argument("--truth", type=int, default=200_000, help="--stage scene: Gaussians of the synthetic ground-truth room")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of K steps is repeated this many times; value = the MEDIAN region (min / max reported)")
@@ -1009,6 +1044,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
                          "the JSON line's n_gpus must be what was asked for")
+    # telemetry: a separate process samples the amdsmi metrics table (busy %, shader clock, socket power) across the run; it is
+    # started HERE, before anything in this process touches the GPU, and it never loads HIP itself
+    sampler = None
+    if rank == 0 and args.stage == "raster" and not args.no_telemetry:
+        sampler = start_gpu_sampler()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     ndev = torch.cuda.device_count()
@@ -1220,6 +1260,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         regions = [float(x) for x in t.tolist()]
     elapsed = sorted(regions)[len(regions) // 2]     # value = the MEDIAN region
+    telemetry = stop_gpu_sampler(sampler, regions_unix) if sampler is not None else None
 
     # Secondary figure (N = 1): the same step with the window's views spread over K HIP streams
     # (splatloc_amd.fused.render_window does this for the product path).  Not `value`: kernel durations
@@ -1326,6 +1367,9 @@ def main():
                         "frames_per_s_max": round(frames_per_step * args.steps / min(regions), 3),
                         "ms_per_step_all": [round(1e3 * r / args.steps, 4) for r in regions]},
             "timed_regions_unix": [[round(a, 3), round(b, 3)] for a, b in regions_unix],   # for tools/clock_trace.py
+            # what the GPU did DURING the timed regions, from an independent source (amdsmi, sampled by a separate process)
+            "gpu_busy_in_timed_regions": (telemetry or {}).get("busy_pct_mean"),
+            "gpu_telemetry_in_timed_regions": telemetry,
             "config": {"workload": f"{args.workload}: P={P} Gaussians, {W}x{H}, C={C} channels "
                                    f"(3 RGB + {C - 3} feature) + depth + alpha, seed {wl['seed']}; "
                                    f"{args.views} different cameras per window",

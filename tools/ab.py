@@ -10,7 +10,11 @@ variant: mean, standard deviation and the 95 % confidence interval of the mean (
 compositing stages; per variant against base: the mean of the PAIRED differences (same round), its 95 % interval and the
 two-sided p-value of the paired t-test — a gain is real when the interval excludes 0.  Round 4 compared 3 + 3 un-interleaved
 runs on different boxes; box-to-box spread is +-2 %, run-to-run on one box +-0.3 %: only same-box, interleaved, paired
-comparisons resolve a 1 % effect (VERDICT r4 #4).  --parity runs the quick parity subset once per variant first."""
+comparisons resolve a 1 % effect (VERDICT r4 #4).  --parity runs the quick parity subset once per variant first.
+Every bench run carries its own telemetry (bench.py starts tools/gpu_sampler.py: amdsmi samples inside the timed regions), so
+each variant also gets mean shader clock, socket power, PPT-limit residency and busy %, and the per-run scatter of (clock,
+power) against (fwd ms, bwd ms) is kept: a forward / backward coupling that is a POWER effect shows up as a clock / power
+difference between the variants (VERDICT r5 #3)."""
 import json
 import math
 import os
@@ -87,7 +91,8 @@ def main():
                 raise SystemExit(f"missing variant library {env['SPLATRASTER_LIB']} (tools/ablate.py builds it)")
         return env
 
-    res = {n: {"fps": [], "fwd_ms": [], "bwd_ms": [], "ms_per_step": []} for n in names}
+    res = {n: {"fps": [], "fwd_ms": [], "bwd_ms": [], "ms_per_step": [], "sclk_mhz": [], "power_w": [], "ppt_residency": [], "busy_pct": []}
+           for n in names}
     par = {}
     if parity:
         for n in names:
@@ -108,25 +113,43 @@ def main():
             res[n]["ms_per_step"].append(d["ms_per_step"])
             res[n]["fwd_ms"].append(d["stages"]["composite_fwd"]["avg_ms"])
             res[n]["bwd_ms"].append(d["stages"]["composite_bwd"]["avg_ms"])
+            tel = d.get("gpu_telemetry_in_timed_regions") or {}
+            if tel.get("available"):
+                res[n]["sclk_mhz"].append((tel.get("sclk_mhz") or {}).get("mean"))
+                res[n]["power_w"].append((tel.get("socket_power_w") or {}).get("mean"))
+                res[n]["ppt_residency"].append(tel.get("ppt_limit_residency_first_to_last_sample"))
+                res[n]["busy_pct"].append(tel.get("busy_pct_mean"))
         print(f"round {r_i + 1}/{runs}: " + "  ".join(f"{n} {res[n]['fps'][-1]:.1f}" for n in names), flush=True)
     out = {"workload": workload, "runs_per_variant": runs, "interleaved": True, "bench": "default 5-region bench (value = median region)",
            "parity": par or None, "variants": {}, "vs_base": {}}
+    tel_keys = ("sclk_mhz", "power_w", "ppt_residency", "busy_pct")
     for n in names:
-        out["variants"][n] = {k: summary(v) for k, v in res[n].items()}
+        clean = {k: [x for x in v if isinstance(x, (int, float))] for k, v in res[n].items()}
+        out["variants"][n] = {k: summary(v) for k, v in clean.items() if v and (k not in tel_keys or len(v) == runs)}
         out["variants"][n]["fps_all"] = [round(x, 2) for x in res[n]["fps"]]
+        if all(len(clean[k]) == runs for k in ("sclk_mhz", "power_w")):
+            # the per-run scatter: does a run's kernel time follow its clock / power?
+            out["variants"][n]["per_run"] = [{"fwd_ms": a, "bwd_ms": b, "sclk_mhz": c, "power_w": w}
+                                             for a, b, c, w in zip(res[n]["fwd_ms"], res[n]["bwd_ms"], clean["sclk_mhz"], clean["power_w"])]
     for n in names[1:]:
         out["vs_base"][n] = {"fps_diff": paired(res["base"]["fps"], res[n]["fps"]),
                              "fwd_ms_diff": paired(res["base"]["fwd_ms"], res[n]["fwd_ms"]),
                              "bwd_ms_diff": paired(res["base"]["bwd_ms"], res[n]["bwd_ms"])}
+        for k in ("sclk_mhz", "power_w", "ppt_residency"):
+            a = [x for x in res["base"][k] if isinstance(x, (int, float))]
+            b = [x for x in res[n][k] if isinstance(x, (int, float))]
+            if len(a) == runs and len(b) == runs:
+                out["vs_base"][n][k + "_diff"] = paired(a, b)
     txt = json.dumps(out, indent=1)
     if out_path:
         with open(out_path, "w") as f:
             f.write(txt + "\n")
     print(txt)
-    print("\nvariant          frames/s mean (95 % CI)            fwd ms    bwd ms    paired d(frames/s) vs base (95 % CI)      p")
+    print("\nvariant          frames/s mean (95 % CI)            fwd ms    bwd ms   sclk MHz  power W    paired d(frames/s) vs base (95 % CI)      p")
     for n in names:
         v = out["variants"][n]
         row = f"{n:14s} {v['fps']['mean']:9.2f} ({v['fps']['ci95'][0]:.2f} .. {v['fps']['ci95'][1]:.2f})   {v['fwd_ms']['mean']:8.4f}  {v['bwd_ms']['mean']:8.4f}"
+        row += f"  {v['sclk_mhz']['mean']:8.1f}  {v['power_w']['mean']:7.1f}" if "sclk_mhz" in v and "power_w" in v else "         -        -"
         if n != "base":
             d = out["vs_base"][n]["fps_diff"]
             row += f"    {d['mean']:+7.2f} ({d['ci95'][0]:+.2f} .. {d['ci95'][1]:+.2f})  p = {d['p_two_sided']}  {'SIGNIFICANT' if d['significant_at_5pct'] else 'not significant'}"
