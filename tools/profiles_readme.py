@@ -29,7 +29,15 @@ WHAT = [   # (file name regex, description; {placeholders} are filled by the ext
     (r"r\d+_hostprof_.*\.txt$", "cProfile of the host side of a refinement / map step (`tools/hostprof_steps.py`)"),
     (r"r\d+_ab_probes\.txt$", "A/B and timing-probe log of the round (one box per block)"),
     (r"r\d+_knn\.json$", "`distCUDA2` wall times, brute force vs exact grid"),
-    (r"r\d+_scene\.json$", "`bench.py --stage scene`: the whole reconstruction schedule as one run: {bench}"),
+    (r"r\d+_scene_lists.*\.json$", "one `color_refinement` iteration on a RECONSTRUCTED room (list-length distribution, per-kernel table; `tools/scene_lists.py`; suffix = the forced variant): {scenelists}"),
+    (r"r\d+_scene.*\.json$", "`bench.py --stage scene`: the whole reconstruction schedule as one run (suffix: `replica_scale` = 180 key-frames of a 600k-Gaussian room, `radix_front_end` = SPLATRASTER_FRONT_END=0): {bench}{scene}"),
+    (r"r\d+_ab_.*\.json$", "`tools/ab.py`: interleaved same-box A/B of variant libraries, paired statistics: {ab}"),
+    (r"r\d+_bwd_profile\.txt$", "per-phase cycle counters of the wide backward's waves (`tools/bwd_prof.py`, `-DSR_BWD_PROFILE` variant from `tools/patches/r05_variants.patch`)"),
+    (r"r\d+_lone_wave\.json$", "one wave alone on its SIMD walking one list of N entries (`tools/lone_wave.py`): us per 1 000 list entries of the narrow forward, one-wave vs four-wave team"),
+    (r"r\d+_perview_idle.*\.json$", "the literal per-view drop-in loop (5 x `GaussianRasterizer.__call__` + backward) against the window: wall vs GPU busy time (`tools/perview_idle.py`): {perview}"),
+    (r"r\d+_map_idle.*\.json$", "live GPU idle and raster / non-raster kernel split of one `training.map_step` (`tools/map_idle.py`): {mapidle}"),
+    (r"r\d+_rccl_contact\.json$", "`tools/rccl_contact.py` on one MI355X: a world-size-1 `nccl` (RCCL) process group drives every collective call of the frame-parallel path (in-place span SUM, MAX, reduce-scatter + all-gather, header, broadcast_model): {rccl}"),
+    (r"r\d+_bench_force_process_group.*\.json$", "`bench.py --gpus 1 --force-process-group`: the BASELINE step with its collectives issued on a world-size-1 RCCL group: {bench}"),
     (r"traffic\.json$", "per-stage HBM bytes per launch that `bench.py` replays as `roofline.traffic` (recorded workload / launch mode inside)"),
     (r"valu\.json$", "VALU / MFMA / SALU wave-instructions, busy fractions of the two compositing kernels per launch (replayed by `bench.py` as `frame_valu` / `roofline_valu`)"),
     (r"r01_v1_first_.*", "round 1: the first correct pipeline (per-value DPP reductions, no reach masks)"),
@@ -124,7 +132,56 @@ def idle(path):
             f"idle {j.get('idle_us_per_iteration')} us, host enqueue {j.get('host_enqueue_us_per_iteration')} us")
 
 
-EXTRACT = {"kstats": kstats, "hbm": hbm, "sq": sq, "timeline": timeline, "bench": bench, "clocks": clocks, "gradbars": gradbars, "idle": idle}
+def scenelists(path):
+    j = _load(path) or {}
+    top = ", ".join(f"{k['kernel'].split('(')[0].replace('void sr::', '').replace('sr::', '')[:28]} {k['us']}" for k in (j.get("kernels") or [])[:3]
+                    if isinstance(k, dict) and "kernel" in k and "us" in k)
+    return (f"{j.get('keyframes')} key-frames, {j.get('rows')} rows, front end {j.get('front_end')}: refinement {j.get('refine_us_per_iteration')} us / iteration"
+            + (f"; largest kernels (us): {top}" if top else ""))
+
+
+def scene(path):
+    j = _load(path) or {}
+    if "map_ms_per_iteration" not in j:
+        return ""
+    return (f"; map {j['map_ms_per_iteration']} ms / iteration, refinement {j.get('refine_ms_per_iteration')} ms / iteration, "
+            f"{j.get('rows_final')} rows, peak {j.get('peak_memory_GB')} GB")
+
+
+def ab(path):
+    j = _load(path) or {}
+    out = []
+    for n, v in (j.get("variants") or {}).items():
+        s_ = f"{n} {v['fps']['mean']:.1f} frames/s"
+        d = (j.get("vs_base") or {}).get(n)
+        if d:
+            f = d["fps_diff"]
+            s_ += f" ({f['mean']:+.2f}, CI {f['ci95'][0]:+.2f} .. {f['ci95'][1]:+.2f}{', significant' if f.get('significant_at_5pct') else ''})"
+        if "sclk_mhz" in v:
+            s_ += f" at {v['sclk_mhz']['mean']:.0f} MHz / {v['power_w']['mean']:.0f} W"
+        out.append(s_)
+    return f"{j.get('workload')}, {j.get('runs_per_variant')} runs per variant: " + "; ".join(out) if out else "(see file)"
+
+
+def perview(path):
+    j = _load(path) or {}
+    keys = [k for k in j if isinstance(j[k], (int, float)) and ("us" in k or "ms" in k)][:6]
+    return ", ".join(f"{k} {j[k]}" for k in keys) or "(see file)"
+
+
+def mapidle(path):
+    j = _load(path) or {}
+    return (f"{j.get('workload')}, densify every {j.get('densify_every')}: wall {j.get('wall_us_per_step')} us / step, GPU busy "
+            f"{j.get('gpu_busy_us_per_step_torch_profiler')} us (raster {j.get('raster_kernels_us_per_step')}, other {j.get('non_raster_kernels_us_per_step')}), "
+            f"idle {j.get('idle_us_per_step')} us, {j.get('kernels_per_step')} kernels")
+
+
+def rccl(path):
+    j = _load(path) or {}
+    return f"backend {j.get('backend')}, RCCL {j.get('rccl_version')}, HSA_ENABLE_IPC_MODE_LEGACY={((j.get('env') or {}).get('HSA_ENABLE_IPC_MODE_LEGACY'))}, ok = {j.get('ok')}"
+
+
+EXTRACT = {"scenelists": scenelists, "scene": scene, "ab": ab, "perview": perview, "mapidle": mapidle, "rccl": rccl, "kstats": kstats, "hbm": hbm, "sq": sq, "timeline": timeline, "bench": bench, "clocks": clocks, "gradbars": gradbars, "idle": idle}
 
 
 def describe(name, path):
@@ -140,7 +197,7 @@ def describe(name, path):
     return "(undescribed)"
 
 
-def main():
+def render() -> str:
     files = sorted((os.path.basename(p) for p in glob.glob(os.path.join(PROF, "*")) if not p.endswith("README.md")),
                    key=lambda n: (not n.startswith("r"), -(int(n[1:3]) if re.match(r"r\d\d_", n) else 0), n))
     lines = ["# profiles/ — rocprofv3 evidence, per round", "",
@@ -151,9 +208,14 @@ def main():
              "| file | what |", "|---|---|"]
     for n in files:
         lines.append(f"| `{n}` | {describe(n, os.path.join(PROF, n))} |")
+    return "\n".join(lines) + "\n"
+
+
+def main():
+    txt = render()
     with open(os.path.join(PROF, "README.md"), "w") as f:
-        f.write("\n".join(lines) + "\n")
-    print("wrote profiles/README.md:", len(files), "files")
+        f.write(txt)
+    print("wrote profiles/README.md:", txt.count("\n| `"), "files;", txt.count("(undescribed)"), "undescribed")
 
 
 if __name__ == "__main__":
