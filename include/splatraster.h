@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 11
+#define SPLATRASTER_ABI_VERSION 12
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
@@ -445,6 +445,26 @@ int splatraster_mapping_loss(int32_t pixels, const float* image, const float* de
                              float rgb_boundary_threshold, const float* exposure /* [2] = a, b or NULL */,
                              float* g_image, float* g_depth, float* g_marker, float* out /* [4] */,
                              void* workspace, void* stream);
+
+/* The same for the n_views <= SPLATRASTER_MAX_WINDOW_VIEWS views of a window (the loop train_gaussians.py:195-219 sums the
+ * per-view losses with weight 1) in ONE launch pair: `views` is a HOST array of per-view device pointers, out is [n_views][4]
+ * (device), workspace n_views x splatraster_mapping_loss_workspace_bytes(pixels).  Per-view results are bit-identical to
+ * n_views calls of splatraster_mapping_loss (same blocks, same summation order). */
+typedef struct splatraster_loss_view {
+    const float* image;    /* 3 planes */
+    const float* depth;
+    const float* marker;
+    const float* gt_image; /* 3 planes */
+    const float* gt_depth;
+    const float* kp;
+    const float* exposure; /* [2] = a, b or NULL */
+    float* g_image;        /* 3 planes */
+    float* g_depth;
+    float* g_marker;
+} splatraster_loss_view;
+int splatraster_mapping_loss_window(int32_t n_views, int32_t pixels, const splatraster_loss_view* views,
+                                    float rgb_boundary_threshold, float* out /* [n_views][4] */, void* workspace,
+                                    void* stream);
 
 /* Colour-refinement loss (train_gaussians.py:283-285):
  *   loss = (1 - lambda_dssim) l1_loss(image, gt) + lambda_dssim (1 - ssim(image, gt))

@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 11   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 12   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 WARN_LOOKBACK_STALL = 5   # splatraster_poll_errors() only; not an error of any frame
@@ -46,6 +46,12 @@ class WindowView(C.Structure):
                 ("radii", C.c_void_p), ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p),
                 ("dL_dout_color", C.c_void_p), ("dL_dout_depth", C.c_void_p), ("dL_dout_alpha", C.c_void_p),
                 ("dL_dmeans2D", C.c_void_p), ("dL_dout_last", C.c_void_p), ("color_grad_channels", C.c_int32)]
+
+
+class LossView(C.Structure):
+    """struct splatraster_loss_view"""
+    _fields_ = [(n, C.c_void_p) for n in ("image", "depth", "marker", "gt_image", "gt_depth", "kp", "exposure", "g_image", "g_depth",
+                                          "g_marker")]
 
 
 class GeometryLayout(C.Structure):
@@ -132,6 +138,7 @@ SYMBOLS = {
     "splatraster_isotropic_loss": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_mapping_loss_workspace_bytes": (_sz, [_i32]),
     "splatraster_mapping_loss": (C.c_int, [_i32] + [_vp] * 6 + [C.c_float] + [_vp] * 7),
+    "splatraster_mapping_loss_window": (C.c_int, [_i32, _i32, _vp, C.c_float, _vp, _vp, _vp]),
     "splatraster_refinement_loss_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "splatraster_refinement_loss": (C.c_int, [_i32, _i32, _i32, C.c_float] + [_vp] * 6),
     "splatraster_eval_metrics_workspace_bytes": (_sz, [_i32, _i32, _i32]),

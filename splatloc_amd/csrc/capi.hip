@@ -994,6 +994,20 @@ int splatraster_mapping_loss(int32_t pixels, const float* image, const float* de
                                g_image, g_depth, g_marker, out, workspace, reinterpret_cast<hipStream_t>(stream));
 }
 
+int splatraster_mapping_loss_window(int32_t n_views, int32_t pixels, const splatraster_loss_view* views,
+                                    float rgb_boundary_threshold, float* out, void* workspace, void* stream)
+{
+    if (pixels <= 0 || n_views < 1 || n_views > SPLATRASTER_MAX_WINDOW_VIEWS || !views || !out || !workspace)
+        return SPLATRASTER_ERR_BAD_ARG;
+    for (int v = 0; v < n_views; ++v) {
+        const splatraster_loss_view& w = views[v];
+        if (!w.image || !w.depth || !w.marker || !w.gt_image || !w.gt_depth || !w.kp || !w.g_image || !w.g_depth || !w.g_marker)
+            return SPLATRASTER_ERR_BAD_ARG;
+    }
+    return launch_mapping_loss_window(n_views, pixels, views, rgb_boundary_threshold, out, workspace,
+                                      reinterpret_cast<hipStream_t>(stream));
+}
+
 size_t splatraster_refinement_loss_workspace_bytes(int32_t channels, int32_t height, int32_t width)
 {
     if (channels <= 0 || height <= 0 || width <= 0) return 0;

@@ -294,6 +294,8 @@ struct StatsViews {
 int launch_densification_stats(int32_t P, int32_t V, const StatsViews& views, float* accum /*or null*/,
                                float* denom /*or null*/, float* max_radii, hipStream_t stream);
 size_t mapping_loss_workspace_bytes(int32_t HW);
+int launch_mapping_loss_window(int32_t V, int32_t HW, const splatraster_loss_view* views, float threshold, float* out,
+                               void* workspace, hipStream_t stream);
 int launch_mapping_loss(int32_t HW, const float* image, const float* depth, const float* marker,
                         const float* gt_image, const float* gt_depth, const float* kp, float threshold,
                         const float* exposure, float* g_image, float* g_depth, float* g_marker, float* out,

@@ -19,13 +19,30 @@ constexpr int LOSS_SUMS = 5;  // l1 rgb, l1 depth, bce, d/da, d/db
 
 __device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
+// the views of a window in ONE launch pair (blockIdx.y = view): every view's blocks, partial sums and their order are those
+// of the single-view launch, so the window's per-view results are bit-identical to V separate calls
+struct LossViews {
+    const float* image[MAX_VIEWS]; const float* depth[MAX_VIEWS]; const float* marker[MAX_VIEWS];
+    const float* gt_image[MAX_VIEWS]; const float* gt_depth[MAX_VIEWS]; const float* kp[MAX_VIEWS];
+    const float* exposure[MAX_VIEWS];   // [2] = a, b or NULL
+    float* g_image[MAX_VIEWS]; float* g_depth[MAX_VIEWS]; float* g_marker[MAX_VIEWS];
+};
+
 __global__ void __launch_bounds__(LOSS_BLOCK)
-mapping_loss_kernel(int HW, const float* __restrict__ image /*3 planes*/, const float* __restrict__ depth,
-                    const float* __restrict__ marker, const float* __restrict__ gt_image,
-                    const float* __restrict__ gt_depth, const float* __restrict__ kp, float threshold,
-                    const float* __restrict__ exposure /*[2] = a, b or NULL*/, float* __restrict__ g_image,
-                    float* __restrict__ g_depth, float* __restrict__ g_marker, double* __restrict__ partial)
+mapping_loss_kernel(int HW, LossViews lv, float threshold, double* __restrict__ partial_all /*[V][gridDim.x][LOSS_SUMS]*/)
 {
+    const int view = blockIdx.y;
+    const float* __restrict__ image = lv.image[view];
+    const float* __restrict__ depth = lv.depth[view];
+    const float* __restrict__ marker = lv.marker[view];
+    const float* __restrict__ gt_image = lv.gt_image[view];
+    const float* __restrict__ gt_depth = lv.gt_depth[view];
+    const float* __restrict__ kp = lv.kp[view];
+    const float* __restrict__ exposure = lv.exposure[view];
+    float* __restrict__ g_image = lv.g_image[view];
+    float* __restrict__ g_depth = lv.g_depth[view];
+    float* __restrict__ g_marker = lv.g_marker[view];
+    double* __restrict__ partial = partial_all + (size_t)view * gridDim.x * LOSS_SUMS;
     const float ea = exposure ? expf(exposure[0]) : 1.0f;
     const float eb = exposure ? exposure[1] : 0.0f;
     const float inv_rgb = 1.0f / (3.0f * (float)HW), inv_n = 1.0f / (float)HW;
@@ -74,9 +91,13 @@ mapping_loss_kernel(int HW, const float* __restrict__ image /*3 planes*/, const 
 }
 
 __global__ void __launch_bounds__(LOSS_BLOCK)
-mapping_loss_finish_kernel(int blocks, int HW, const double* __restrict__ partial,
-                           const float* __restrict__ exposure, float* __restrict__ out /*[4]*/)
+mapping_loss_finish_kernel(int blocks, int HW, const double* __restrict__ partial_all, LossViews lv,
+                           float* __restrict__ out_all /*[V][4]*/)
 {
+    const int view = blockIdx.x;
+    const double* __restrict__ partial = partial_all + (size_t)view * blocks * LOSS_SUMS;
+    const float* __restrict__ exposure = lv.exposure[view];
+    float* __restrict__ out = out_all + 4 * view;
     __shared__ double s_red[LOSS_BLOCK / WAVE][LOSS_SUMS];
     double acc[LOSS_SUMS] = {0, 0, 0, 0, 0};
     for (int b = threadIdx.x; b < blocks; b += blockDim.x)
@@ -103,12 +124,34 @@ mapping_loss_finish_kernel(int blocks, int HW, const double* __restrict__ partia
     }
 }
 
-size_t mapping_loss_workspace_bytes(int32_t HW)
+static int loss_blocks(int32_t HW)
 {
     int blocks = (HW + LOSS_BLOCK - 1) / LOSS_BLOCK;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    return (size_t)blocks * LOSS_SUMS * sizeof(double);
+    return blocks;
+}
+
+size_t mapping_loss_workspace_bytes(int32_t HW) { return (size_t)loss_blocks(HW) * LOSS_SUMS * sizeof(double); }
+
+// V views (host array of per-view pointers), out [V][4], workspace V x mapping_loss_workspace_bytes(HW)
+int launch_mapping_loss_window(int32_t V, int32_t HW, const splatraster_loss_view* views, float threshold, float* out,
+                               void* workspace, hipStream_t stream)
+{
+    LossViews lv{};
+    for (int v = 0; v < V; ++v) {
+        lv.image[v] = views[v].image; lv.depth[v] = views[v].depth; lv.marker[v] = views[v].marker;
+        lv.gt_image[v] = views[v].gt_image; lv.gt_depth[v] = views[v].gt_depth; lv.kp[v] = views[v].kp;
+        lv.exposure[v] = views[v].exposure;
+        lv.g_image[v] = views[v].g_image; lv.g_depth[v] = views[v].g_depth; lv.g_marker[v] = views[v].g_marker;
+    }
+    const int blocks = loss_blocks(HW);
+    double* partial = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(mapping_loss_kernel, dim3(blocks, V), dim3(LOSS_BLOCK), 0, stream, HW, lv, threshold, partial);
+    SR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mapping_loss_finish_kernel, dim3(V), dim3(LOSS_BLOCK), 0, stream, blocks, HW, partial, lv, out);
+    SR_LAUNCH_CHECK();
+    return SPLATRASTER_OK;
 }
 
 int launch_mapping_loss(int32_t HW, const float* image, const float* depth, const float* marker,
@@ -116,16 +159,8 @@ int launch_mapping_loss(int32_t HW, const float* image, const float* depth, cons
                         const float* exposure, float* g_image, float* g_depth, float* g_marker, float* out,
                         void* workspace, hipStream_t stream)
 {
-    int blocks = (HW + LOSS_BLOCK - 1) / LOSS_BLOCK;
-    if (blocks > 2048) blocks = 2048;
-    double* partial = reinterpret_cast<double*>(workspace);
-    hipLaunchKernelGGL(mapping_loss_kernel, dim3(blocks), dim3(LOSS_BLOCK), 0, stream, HW, image, depth, marker,
-                       gt_image, gt_depth, kp, threshold, exposure, g_image, g_depth, g_marker, partial);
-    SR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mapping_loss_finish_kernel, dim3(1), dim3(LOSS_BLOCK), 0, stream, blocks, HW, partial,
-                       exposure, out);
-    SR_LAUNCH_CHECK();
-    return SPLATRASTER_OK;
+    const splatraster_loss_view one{image, depth, marker, gt_image, gt_depth, kp, exposure, g_image, g_depth, g_marker};
+    return launch_mapping_loss_window(1, HW, &one, threshold, out, workspace, stream);
 }
 
 

@@ -113,7 +113,50 @@ def mapping_loss_window(config, pkgs, viewpoints, initialization: bool = False):
         ex_all = torch.cat([t.reshape(1) for vp in viewpoints for t in (vp.exposure_a, vp.exposure_b)]).to(torch.float32).detach()
     tensors, grads, pending = [], [], []
     with torch.no_grad():
-        for v, (pkg, vp) in enumerate(zip(pkgs, viewpoints)):
+        lib = _native.load()
+        H, W = int(pkgs[0]["render"].shape[-2]), int(pkgs[0]["render"].shape[-1])
+        HW = H * W
+        same = all(tuple(p["render"].shape) == (3, H, W) and p["depth"].numel() == HW and p["kp_prob"].numel() == HW for p in pkgs)
+        if same and V <= _native.MAX_WINDOW_VIEWS:
+            # the window's per-view launches as ONE launch pair (splatraster_mapping_loss_window; per-view results bit-identical):
+            # the gradients of all views are slices of one allocation [V, 5, H, W] = (g_image[3] | g_depth | g_marker) per view
+            gbuf = torch.empty((V, 5, H, W), dtype=torch.float32, device=dev)
+            ws_one = int(lib.splatraster_mapping_loss_workspace_bytes(HW))
+            ws = torch.empty((V * ws_one,), dtype=torch.uint8, device=dev)
+            lv = (_native.LossView * V)()
+            keep = []      # prepared inputs stay alive until the launch is enqueued
+            for v, (pkg, vp) in enumerate(zip(pkgs, viewpoints)):
+                gt_depth = vp.depth
+                if isinstance(gt_depth, np.ndarray):
+                    gt_depth = torch.from_numpy(gt_depth)
+                a = None if initialization else getattr(vp, "exposure_a", None)
+                ex = ex_all[2 * v:2 * v + 2] if ex_all is not None else (
+                    None if a is None else torch.cat((vp.exposure_a.reshape(1), vp.exposure_b.reshape(1))).to(torch.float32).detach())
+                ins = [_prep(t, dev) for t in (pkg["render"], pkg["depth"], pkg["kp_prob"], vp.original_image, gt_depth,
+                                                 vp.kp_score.to(torch.float32))]
+                if any(t is None for t in ins):
+                    raise RuntimeError("mapping_loss_window: empty input")
+                exp_t = None     # (two floats read with scalar loads: no alignment requirement, so a slice of the window's table is passed as it is)
+                if ex is not None:
+                    ok = ex.dtype is torch.float32 and ex.device == dev and ex.is_contiguous()
+                    exp_t = ex.detach() if ok else ex.detach().to(device=dev, dtype=torch.float32).contiguous()
+                keep.append((ins, exp_t))
+                g_image, g_depth, g_marker = gbuf[v, 0:3], gbuf[v, 3:4].view(pkg["depth"].shape), gbuf[v, 4].view(pkg["kp_prob"].shape)
+                e = lv[v]
+                e.image, e.depth, e.marker, e.gt_image, e.gt_depth, e.kp = (t.data_ptr() for t in ins)
+                e.exposure = exp_t.data_ptr() if exp_t is not None else None
+                e.g_image, e.g_depth, e.g_marker = g_image.data_ptr(), g_depth.data_ptr(), g_marker.data_ptr()
+                tensors += [pkg["render"], pkg["depth"], pkg["kp_prob"]]
+                grads += [g_image, g_depth, g_marker]
+                if ex is not None:
+                    pending += [(prm, v, col) for prm, col in ((vp.exposure_a, 2), (vp.exposure_b, 3))
+                                if isinstance(prm, torch.Tensor) and prm.requires_grad]
+            with _on_device(dev):
+                _native.check(lib.splatraster_mapping_loss_window(V, HW, lv, C.c_float(float(thr)), _ptr(table), _ptr(ws), _stream(dev)),
+                              "mapping_loss_window")
+            del keep
+        else:
+          for v, (pkg, vp) in enumerate(zip(pkgs, viewpoints)):
             gt_depth = vp.depth
             if isinstance(gt_depth, np.ndarray):
                 gt_depth = torch.from_numpy(gt_depth)

@@ -136,3 +136,47 @@ def test_refinement_loss_full_resolution_against_oracle_sample():
     for rows in (slice(0, 20), slice(536, 552), slice(1070, 1080)):
         ref = o["dL_dimage"][:, rows]
         assert np.abs(got[:, rows] - ref).max() <= 5e-4 * np.abs(o["dL_dimage"]).max()
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (480, 640), (201, 333)])
+def test_window_launch_equals_the_per_view_launches_bit_for_bit(shape):
+    """`mapping_loss_window` issues ONE launch pair for the views of a window (splatraster_mapping_loss_window): the per-view
+    gradients, loss values and exposure gradients must be bit-identical to one `mapping_loss` launch per view (the loop
+    train_gaussians.py:195-219), with and without the exposure affine, for views of a [4,H,W] render (what render() hands over)."""
+    from splatloc_amd.losses import _mapping_loss_launch, mapping_loss_window
+    H, W = shape
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    cfg = {"Training": {"rgb_boundary_threshold": 0.01}}
+    for init in (False, True):
+        pkgs, vps, single = [], [], []
+        for v in range(5):
+            render = torch.rand(4, H, W, generator=g).to(DEV)
+            depth = (3 * torch.rand(1, H, W, generator=g)).to(DEV)
+            gt = torch.rand(3, H, W, generator=g)
+            gt[:, : H // 8] = 0.0                                   # masked rows
+            gtd = 3 * torch.rand(H, W, generator=g)
+            gtd[H // 2:, : W // 4] = 0.0
+            vp = types.SimpleNamespace(original_image=gt.to(DEV), depth=gtd.numpy() if v % 2 else gtd.to(DEV),
+                                       kp_score=(torch.rand(H, W, generator=g) ** 4).to(DEV),
+                                       exposure_a=torch.tensor([0.05 * v - 0.1], device=DEV, requires_grad=True),
+                                       exposure_b=torch.tensor([0.01 * v], device=DEV, requires_grad=True))
+            pkgs.append({"render": render[:3], "depth": depth, "kp_prob": render[-1] * 4 - 2})
+            vps.append(vp)
+            ex = None if init else torch.cat((vp.exposure_a.detach(), vp.exposure_b.detach()))
+            single.append(_mapping_loss_launch(pkgs[-1]["render"], depth, pkgs[-1]["kp_prob"], vp.original_image, gtd.to(DEV), vp.kp_score,
+                                               0.01, ex))
+        tensors, grads, value = mapping_loss_window(cfg, pkgs, vps, initialization=init)
+        torch.cuda.synchronize()
+        assert len(tensors) == 15 and len(grads) == 15
+        total = 0.0
+        for v in range(5):
+            gi, gd, gm, out = single[v]
+            assert torch.equal(grads[3 * v].view(torch.int32), gi.view(torch.int32))
+            assert torch.equal(grads[3 * v + 1].view(torch.int32), gd.view(torch.int32)) and grads[3 * v + 1].shape == pkgs[v]["depth"].shape
+            assert torch.equal(grads[3 * v + 2].view(torch.int32), gm.view(torch.int32)) and grads[3 * v + 2].shape == (H, W)
+            total += float(out[0]) + float(out[1])
+            if init:
+                assert vps[v].exposure_a.grad is None
+            else:
+                assert float(vps[v].exposure_a.grad) == float(out[2]) and float(vps[v].exposure_b.grad) == float(out[3])
+        assert abs(float(value) - total) <= 1e-5 * abs(total)
