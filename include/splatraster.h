@@ -586,13 +586,19 @@ int splatraster_debug_set_payload_stream_min(int64_t instances);
  * (view, tile) + one LDS sort per tile) for windows of at most 6144 (view, tile) lists — SplatLoc's own
  * 640x480 frames, singly or five at a time — and the two global radix sorts otherwise; 0: the radix sorts always; 1: the
  * binned front end whenever the shape allows (at most 16 384 tiles per view).  Both produce bit-identical point lists,
- * ranges and payloads.  Must not change between the geometry and the render stage of a forward. */
+ * ranges and payloads.  The render stage follows the choice the GEOMETRY stage made for its geometry buffer: a change between the
+ * two stages of a forward takes effect at the next geometry stage. */
 int splatraster_debug_set_front_end(int mode);
 /* A/B / test hook of the binned front end: the per-tile sort launch exists for lists of up to 2048 keys (128 threads, every
  * tile of a 640x480 frame resident at once) and of up to 4096 (256 threads); by default the library follows a hint the kernel
  * raises when it meets a list beyond 2048 keys (longer lists than the chosen launch holds go to its work-list launch either
  * way).  2048 / 4096 force an instantiation, any other value restores the default.  Results never depend on it. */
 int splatraster_debug_set_tile_sort_cap(int keys);
+/* The binned front end's two sort launches (lists up to the tile launch's cap | longer lists, which that launch finds in the
+ * scanned table itself) are independent: -1 (default) runs the long-list launch on an internal side stream — forked behind the
+ * key scatter, joined before the compositing grid — when a list beyond 2048 keys was seen in the last 64 frames; 0 never (both
+ * on the caller's stream); 1 always.  Results never depend on it. */
+int splatraster_debug_set_sort_fork(int mode);
 int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
 /* test hook: fills the LDS of every compute unit with `pattern` (e.g. a NaN's bits): enough workgroups of 64 KB each to cover
  * the whole array.  The compositing kernels read rows of their LDS staging buffers that a round did not write (the absent second

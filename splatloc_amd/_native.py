@@ -108,6 +108,7 @@ SYMBOLS = {
     "splatraster_debug_set_fwd_team": (C.c_int, [C.c_int]),
     "splatraster_debug_set_front_end": (C.c_int, [C.c_int]),
     "splatraster_debug_set_tile_sort_cap": (C.c_int, [C.c_int]),
+    "splatraster_debug_set_sort_fork": (C.c_int, [C.c_int]),
     "splatraster_debug_set_payload_stream_min": (C.c_int, [C.c_int64]),
     "splatraster_mark_visible": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "splatraster_get_geometry_layout": (C.c_int, [_i32, C.POINTER(GeometryLayout)]),
@@ -198,6 +199,8 @@ def load(build_if_missing: bool = True):
         lib.splatraster_debug_set_front_end(int(os.environ["SPLATRASTER_FRONT_END"]))
     if os.environ.get("SPLATRASTER_TILE_SORT_CAP"):
         lib.splatraster_debug_set_tile_sort_cap(int(os.environ["SPLATRASTER_TILE_SORT_CAP"]))
+    if os.environ.get("SPLATRASTER_SORT_FORK"):
+        lib.splatraster_debug_set_sort_fork(int(os.environ["SPLATRASTER_SORT_FORK"]))
     if os.environ.get("SPLATRASTER_SMALL_PANEL_MAX_WAVES"):
         lib.splatraster_debug_set_small_panel_max_waves(int(os.environ["SPLATRASTER_SMALL_PANEL_MAX_WAVES"]))
     return lib

@@ -214,7 +214,7 @@ tile_order_kernel(int T, const uint32_t* __restrict__ ranges, uint32_t* __restri
 {
     __shared__ uint32_t s_cnt[ORDER_BUCKETS];
     __shared__ uint32_t s_wsum[ORDER_THREADS / WAVE];
-    tile_order_block(T, ranges, order, s_cnt, s_wsum);
+    tile_order_block(T, [&](int i) { return ranges[2 * i + 1] - ranges[2 * i]; }, order, s_cnt, s_wsum);
 }
 
 int launch_tile_order(const splatraster_settings& s, int32_t V, const BinView& b, hipStream_t stream)

@@ -84,7 +84,7 @@ template <int ROWS, bool SCATTER>
 __global__ void __launch_bounds__(BIN_THREADS)
 bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __restrict__ rec,
                 uint32_t* __restrict__ table /*[(v * tiles + t) * nchunk + chunk]: COUNT out / exclusive prefix in*/,
-                uint64_t* __restrict__ keys /*SCATTER: [R]*/, uint32_t* __restrict__ big_count /*zeroed here, by both walks*/)
+                uint64_t* __restrict__ keys /*SCATTER: [R]*/)
 {
     extern __shared__ uint32_t s_bin[];
     __shared__ uint64_t s_qkey[BIN_QUEUE];
@@ -92,9 +92,6 @@ bin_walk_kernel(int P, int tiles, int gx, int gy, int nchunk, const float4* __re
     __shared__ uint32_t s_qn;
     const int v = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
     uint32_t* col = table + (size_t)v * tiles * nchunk + chunk;
-    // the work list of the tile kernel (the launch behind the SCATTER walk) starts empty on EVERY render of this geometry: a
-    // second render stage on the same geometry buffer must not append behind the first one's entries
-    if (big_count && t == 0 && chunk == 0 && v == 0) *big_count = 0u;
     if (t == 0) s_qn = 0u;
     // A block's rows are 64-row groups INTERLEAVED over the whole view (group j of the block = group j nchunk + chunk of the view):
     // a map's rows are spatially coherent — one 2048-row run can be a near wall whose every Gaussian covers hundreds of tiles —
@@ -373,12 +370,13 @@ __device__ void sort_lds_f64(double* s, uint32_t M)
 __device__ uint32_t* g_bin_wide_sink = nullptr;
 
 // First sort launch: one block of CAP / 16 threads per global tile, of which ceil(n / 1024) waves work on the list (the
-// others leave at once): a list of up to 1024 keys is one wave's alone.  Lists longer than CAP are appended to the work list.
+// others leave at once): a list of up to 1024 keys is one wave's alone.  Lists longer than CAP are the second launch's
+// (bin_sort_big_kernel finds them itself from the scanned table: the two launches share no state and may run side by side).
 template <int CAP>
 __global__ void __launch_bounds__(CAP / 16)
 bin_sort_tile_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* __restrict__ table /*exclusive prefix*/,
                      const uint32_t* __restrict__ total /*[0]: R*/, const uint64_t* __restrict__ keys,
-                     const float4* __restrict__ rec, BinView b, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list)
+                     const float4* __restrict__ rec, BinView b)
 {
     __shared__ double s_keys[CAP + CAP / 16];
     const uint32_t gt = blockIdx.x, t = threadIdx.x;
@@ -394,7 +392,6 @@ bin_sort_tile_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* 
     if (t == 0) {   // empty tiles keep [0, 0), like the radix front end's zeroed table
         b.ranges[2 * gt] = n ? start : 0u;
         b.ranges[2 * gt + 1] = n ? start + n : 0u;
-        if (n > (uint32_t)CAP) big_list[atomicAdd(big_count, 1u)] = gt;
         if (n > (uint32_t)BIN_SORT_TILE_NARROW) {   // tell the host that the wide instantiation pays on this scene
             uint32_t* sink = g_bin_wide_sink;
             if (sink) __hip_atomic_store(sink, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -440,23 +437,46 @@ bin_sort_tile_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* 
 // four registers at a time: ~70 us per list, 87 us of a refinement iteration at Replica scale where 15 - 40 lists of a frame
 // exceed 4 096 keys; profiles/r05_ab_probes.txt #11.)
 __global__ void __launch_bounds__(1024)
-bin_sort_big_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* __restrict__ table,
-                    const uint32_t* __restrict__ total, uint64_t* __restrict__ keys, const float4* __restrict__ rec, BinView b,
-                    const uint32_t* __restrict__ big_count, const uint32_t* __restrict__ big_list,
-                    uint32_t* __restrict__ order /*launch order of the compositing grids (tile_order.h), or null*/)
+bin_sort_big_kernel(int gtiles, int tiles, int gx, int nchunk, int cap /*the tile launch's CAP: longer lists are this launch's*/,
+                    const uint32_t* __restrict__ table, const uint32_t* __restrict__ total, uint64_t* __restrict__ keys,
+                    const float4* __restrict__ rec, BinView b,
+                    uint32_t* __restrict__ order /*launch order of the compositing grids (tile_order.h), or null*/,
+                    int ranges_final /*the tile launch has finished (same stream): its range table may be read*/)
 {
     __shared__ double s_keys[BIN_SORT_BIG + BIN_SORT_BIG / 16];
+    __shared__ uint32_t s_mine[BIN_BIG_MINE];   // this block's share of the long lists
+    __shared__ uint32_t s_nmine;
     uint64_t* s_bits = reinterpret_cast<uint64_t*>(s_keys);
-    const uint32_t nwork = *big_count, t = threadIdx.x;
+    const uint32_t t = threadIdx.x;
     static_assert(ORDER_THREADS == 1024, "the last block of this launch computes the launch order");
-    if (order && blockIdx.x == gridDim.x - 1) {   // every range is final: the tile kernel wrote them all (also the long lists')
+    if (order && blockIdx.x == gridDim.x - 1) {
         __shared__ uint32_t s_cnt[ORDER_BUCKETS];
         __shared__ uint32_t s_wsum[ORDER_THREADS / WAVE];
-        tile_order_block(gtiles, b.ranges, order, s_cnt, s_wsum);
+        if (ranges_final)   // (contiguous 8-byte entries)
+            tile_order_block(gtiles, [&](int i) { return b.ranges[2 * i + 1] - b.ranges[2 * i]; }, order, s_cnt, s_wsum);
+        else                // beside the tile launch: from the scanned table, like the lists below — nothing that launch writes is read here
+            tile_order_block(gtiles, [&](int i) { uint32_t st_, n_; tile_span((uint32_t)i, gtiles, nchunk, table, total, st_, n_); return n_; },
+                             order, s_cnt, s_wsum);
         __syncthreads();
     }
-    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const uint32_t gt = big_list[wi];
+    // The long lists: list i is block i % gridDim.x's (neighbouring tiles — a near wall's — go to different blocks); every block
+    // looks at its own gtiles / gridDim.x lengths in the scanned table.  (Round 5: the tile launch appended the long lists to a
+    // list in global memory with an atomic counter — this launch then had to wait for that one, 40 us of a Replica-scale frame,
+    // and the counter had to be reset per render.)
+    if (t == 0) s_nmine = 0u;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x + t * gridDim.x; i < (uint32_t)gtiles; i += gridDim.x * 1024u) {
+        uint32_t st_, n_;
+        tile_span(i, gtiles, nchunk, table, total, st_, n_);
+        if (n_ > (uint32_t)cap) {
+            const uint32_t slot = atomicAdd(&s_nmine, 1u);
+            if (slot < (uint32_t)BIN_BIG_MINE) s_mine[slot] = i;
+        }
+    }
+    __syncthreads();
+    const uint32_t nwork = min(s_nmine, (uint32_t)BIN_BIG_MINE);
+    for (uint32_t wi = 0; wi < nwork; ++wi) {
+        const uint32_t gt = s_mine[wi];
         uint32_t start, n;
         tile_span(gt, gtiles, nchunk, table, total, start, n);
         if (n <= (uint32_t)BIN_SORT_BIG) {
@@ -524,9 +544,9 @@ int launch_bin_count(const splatraster_settings& s, int32_t P, int32_t V, const 
 #define SR_BIN_WALK(ROWS, SC, ...) hipLaunchKernelGGL((bin_walk_kernel<ROWS, SC>), dim3((unsigned)nchunk, (unsigned)V), dim3(BIN_THREADS), \
                                                       (size_t)tiles * sizeof(uint32_t), stream, P, tiles, gx, gy, nchunk, g.rec, __VA_ARGS__)
     switch (bin_rows_per_thread(P, V, tiles)) {
-        case 1: SR_BIN_WALK(1, false, table, (uint64_t*)nullptr, g.total + 2); break;
-        case 2: SR_BIN_WALK(2, false, table, (uint64_t*)nullptr, g.total + 2); break;
-        default: SR_BIN_WALK(8, false, table, (uint64_t*)nullptr, g.total + 2); break;
+        case 1: SR_BIN_WALK(1, false, table, (uint64_t*)nullptr); break;
+        case 2: SR_BIN_WALK(2, false, table, (uint64_t*)nullptr); break;
+        default: SR_BIN_WALK(8, false, table, (uint64_t*)nullptr); break;
     }
     SR_LAUNCH_CHECK();
     return exclusive_scan_u32((int64_t)bin_table_entries(P, V, tiles), table, g.total, scan_tmp, stream, true);
@@ -553,43 +573,92 @@ static int wide_hint_init(int dev)
     return SPLATRASTER_OK;
 }
 
+// -1: fork the long-list launch onto the side stream when the scene has long lists (default); 0: never; 1: always
+static int g_bin_fork = -1;
+void set_bin_fork(int mode) { g_bin_fork = mode < 0 ? -1 : (mode > 1 ? 1 : mode); }
+
+// one side stream + fork / join events per host thread (events are re-recorded per call: another thread's call must never sit
+// between this thread's record and wait)
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; int device = -1; };
+static thread_local SideStream t_side;
+static int side_stream(int dev, SideStream** out)
+{
+    SideStream& s = t_side;
+    if (!s.stream || s.device != dev) {
+        if (s.stream) { (void)hipStreamDestroy(s.stream); (void)hipEventDestroy(s.fork); (void)hipEventDestroy(s.join); }
+        s = SideStream{};
+        SR_HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        SR_HIP_CHECK(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        SR_HIP_CHECK(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+        s.device = dev;
+    }
+    *out = &s;
+    return SPLATRASTER_OK;
+}
+
 // render stage: scatter the keys, sort every tile's list, write the payload
 int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g,
-                            const uint32_t* table, const BinView& b, uint64_t* keys, uint32_t* big_list, hipStream_t stream)
+                            const uint32_t* table, const BinView& b, uint64_t* keys, hipStream_t stream)
 {
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
     const int tiles = gx * gy, nchunk = bin_chunks(P, V, tiles);
     const int gtiles = V * tiles;
     (void)R;
     switch (bin_rows_per_thread(P, V, tiles)) {
-        case 1: SR_BIN_WALK(1, true, const_cast<uint32_t*>(table), keys, g.total + 2); break;
-        case 2: SR_BIN_WALK(2, true, const_cast<uint32_t*>(table), keys, g.total + 2); break;
-        default: SR_BIN_WALK(8, true, const_cast<uint32_t*>(table), keys, g.total + 2); break;
+        case 1: SR_BIN_WALK(1, true, const_cast<uint32_t*>(table), keys); break;
+        case 2: SR_BIN_WALK(2, true, const_cast<uint32_t*>(table), keys); break;
+        default: SR_BIN_WALK(8, true, const_cast<uint32_t*>(table), keys); break;
     }
 #undef SR_BIN_WALK
     SR_LAUNCH_CHECK();
-    uint32_t* big_count = g.total + 2;
     int dev = 0;
     SR_HIP_CHECK(hipGetDevice(&dev));
     bool wide = g_tile_cap == BIN_SORT_TILE_WIDE;
+    bool long_lists = false;   // a list beyond the narrow instantiation was seen in the last BIN_WIDE_FRAMES frames
     if (dev >= 0 && dev < 64) {
         int st = wide_hint_init(dev);
         if (st) return st;
         volatile uint32_t* h = g_wide_host[dev];
         if (*h) { *h = 0u; g_wide_left[dev] = BIN_WIDE_FRAMES; }      // (benign race between host threads: a hint)
-        if (g_tile_cap == 0) wide = g_wide_left[dev] > 0;
+        long_lists = g_wide_left[dev] > 0;
+        if (g_tile_cap == 0) wide = long_lists;
         if (g_wide_left[dev] > 0) --g_wide_left[dev];
+    }
+    // The two sort launches are independent (the long-list launch finds its lists in the scanned table itself), so on a scene
+    // that HAS long lists they run side by side: the long-list launch on this thread's side stream, forked behind the scatter
+    // and joined before the compositing grids (round 5: 40 us of a Replica-scale frame were one 8 192-key sort AFTER the tile
+    // launch had finished).  Without long lists the second launch only computes the launch order: same stream, no events.
+    const bool fork = g_bin_fork == 1 || (g_bin_fork < 0 && long_lists);
+    hipStream_t side = stream;
+    SideStream* ss = nullptr;
+    if (fork) {
+        int st = side_stream(dev, &ss);
+        if (st) return st;
+        side = ss->stream;
+        SR_HIP_CHECK(hipEventRecord(ss->fork, stream));
+        SR_HIP_CHECK(hipStreamWaitEvent(side, ss->fork, 0));
+        // the long lists first: they are the launch sequence's longest blocks
+        hipLaunchKernelGGL(bin_sort_big_kernel, dim3(BIN_BIG_BLOCKS), dim3(1024), 0, side, gtiles, tiles, gx, nchunk,
+                           wide ? BIN_SORT_TILE_WIDE : BIN_SORT_TILE_NARROW, table, g.total, keys, g.rec, b,
+                           use_tile_order(V, tiles) ? b.tile_order : (uint32_t*)nullptr, 0);
+        SR_LAUNCH_CHECK();
+        SR_HIP_CHECK(hipEventRecord(ss->join, side));
     }
     if (wide)
         hipLaunchKernelGGL(bin_sort_tile_kernel<BIN_SORT_TILE_WIDE>, dim3((unsigned)gtiles), dim3(BIN_SORT_TILE_WIDE / 16), 0, stream,
-                           gtiles, tiles, gx, nchunk, table, g.total, keys, g.rec, b, big_count, big_list);
+                           gtiles, tiles, gx, nchunk, table, g.total, keys, g.rec, b);
     else
         hipLaunchKernelGGL(bin_sort_tile_kernel<BIN_SORT_TILE_NARROW>, dim3((unsigned)gtiles), dim3(BIN_SORT_TILE_NARROW / 16), 0,
-                           stream, gtiles, tiles, gx, nchunk, table, g.total, keys, g.rec, b, big_count, big_list);
+                           stream, gtiles, tiles, gx, nchunk, table, g.total, keys, g.rec, b);
     SR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bin_sort_big_kernel, dim3(BIN_BIG_BLOCKS), dim3(1024), 0, stream, gtiles, tiles, gx, nchunk, table,
-                       g.total, keys, g.rec, b, big_count, big_list, use_tile_order(V, tiles) ? b.tile_order : (uint32_t*)nullptr);
-    SR_LAUNCH_CHECK();
+    if (fork) {
+        SR_HIP_CHECK(hipStreamWaitEvent(stream, ss->join, 0));
+    } else {
+        hipLaunchKernelGGL(bin_sort_big_kernel, dim3(BIN_BIG_BLOCKS), dim3(1024), 0, stream, gtiles, tiles, gx, nchunk,
+                           wide ? BIN_SORT_TILE_WIDE : BIN_SORT_TILE_NARROW, table, g.total, keys, g.rec, b,
+                           use_tile_order(V, tiles) ? b.tile_order : (uint32_t*)nullptr, 1);
+        SR_LAUNCH_CHECK();
+    }
     return SPLATRASTER_OK;
 }
 

@@ -157,7 +157,7 @@ GeomView geom_view(void* base, int32_t P, int32_t V)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, ipack, featp, gacc, pose_acc, ckpt, tile_order, big_list, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, ipack, featp, gacc, pose_acc, ckpt, tile_order, bytes;
 };
 static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t H, int32_t C)
 {
@@ -186,7 +186,6 @@ static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t 
     const bool ck = C <= 4 && 4 * (size_t)tiles <= (size_t)SPLIT_MAX_WAVES;
     L.ckpt = take(ck ? nv * (size_t)SPLIT_PARTS * (size_t)(C + 2) * (size_t)W * (size_t)H * sizeof(float) : 16);
     L.tile_order = take(4 * (tiles > 0 ? tiles : 1));
-    L.big_list = take(4 * (tiles > 0 ? tiles : 1));
     L.bytes = o;
     return L;
 }
@@ -209,7 +208,6 @@ BinView bin_view(void* base, int32_t P, int32_t V, int64_t R, int32_t W, int32_t
     v.pose_acc = reinterpret_cast<float*>(b + L.pose_acc);
     v.ckpt = reinterpret_cast<float*>(b + L.ckpt);
     v.tile_order = reinterpret_cast<uint32_t*>(b + L.tile_order);
-    v.big_list = reinterpret_cast<uint32_t*>(b + L.big_list);
     return v;
 }
 
@@ -527,7 +525,7 @@ static int window_render(const splatraster_settings* s, int32_t V, const splatra
         // binned front end: scatter the 64-bit keys into their (tile, chunk) pieces, sort every tile's list in LDS and write
         // the payload + lists + ranges (binsort.hip); the keys live where the radix path keeps its unsorted pairs
         StageTimer t(SPLATRASTER_STAGE_TILE_SORT, stream);
-        st = launch_bin_scatter_sort(*s, P, V, R, g, bins.table, b, reinterpret_cast<uint64_t*>(b.keys_tmp), b.big_list, stream);
+        st = launch_bin_scatter_sort(*s, P, V, R, g, bins.table, b, reinterpret_cast<uint64_t*>(b.keys_tmp), stream);
         if (st) return st;
     }
     if (R > 0 && !bins.on) {
@@ -780,6 +778,12 @@ int splatraster_debug_set_payload_stream_min(int64_t instances)
 int splatraster_debug_set_front_end(int mode)
 {
     set_bin_mode(mode);
+    return SPLATRASTER_OK;
+}
+
+int splatraster_debug_set_sort_fork(int mode)
+{
+    set_bin_fork(mode);
     return SPLATRASTER_OK;
 }
 

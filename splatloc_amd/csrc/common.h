@@ -117,7 +117,6 @@ struct BinView {
     float* pose_acc;      // right behind gacc (one fill zeroes both): POSE_SETS replicated accumulator sets of the camera gradients + the ticket word
     float* ckpt;          // [V][SPLIT_PARTS][C + 2][H * W] segment records of the forward (T in front of the segment, its own colours, depth), split launches only
     uint32_t* tile_order; // [V * tiles] global tile ids, longest list first: the launch order of the compositing kernels
-    uint32_t* big_list;   // [V * tiles] binned front end: the (view, tile) lists too long for the first sort launch
 };
 struct ImgView {
     float* final_T;       // [V][H * W]
@@ -188,8 +187,11 @@ constexpr int BIN_MAX_TILES = 16384;        // tiles per view: the LDS histogram
 constexpr int BIN_AUTO_MAX_TILES = SR_BIN_AUTO_MAX_TILES;
 constexpr int BIN_SORT_TILE_NARROW = 2048, BIN_SORT_TILE_WIDE = 4096;   // longest list of the per-tile launch's two instantiations
 constexpr int BIN_WIDE_FRAMES = 64;         // frames the wide instantiation stays selected after a list beyond 2048 was seen
+void set_bin_fork(int mode);                // -1: the long-list sort launch runs on a side stream when the scene has long lists; 0 never; 1 always
 void set_bin_tile_cap(int cap);             // test / A-B hook: 2048 or 4096 forces an instantiation, anything else: follow the hint
-constexpr int BIN_SORT_BIG = 16384, BIN_BIG_BLOCKS = 128; // the work-list launch for longer lists (keys in 139 KB of LDS, 1024 threads; blocks)
+constexpr int BIN_SORT_BIG = 16384, BIN_BIG_BLOCKS = 128; // the launch for longer lists (keys in 139 KB of LDS, 1024 threads; blocks)
+constexpr int BIN_BIG_MINE = 1024;          // long lists one block of that launch can be handed (list k is block k % BIN_BIG_BLOCKS's)
+static_assert((size_t)BIN_MAX_TILES * MAX_VIEWS <= (size_t)BIN_BIG_MINE * BIN_BIG_BLOCKS, "every (view, tile) list could be a long one");
 void set_bin_mode(int mode);   // -1 auto, 0 radix front end always, 1 binned whenever the shape allows
 size_t bin_table_entries(int32_t P, int32_t V, int tiles);
 size_t bin_scratch_bytes(int32_t P, int32_t V, int tiles);
@@ -197,7 +199,7 @@ bool use_bins(int32_t P, int32_t V, int gx, int gy /*tiles per row / column of a
 int launch_bin_count(const splatraster_settings& s, int32_t P, int32_t V, const GeomView& g, uint32_t* table, void* scan_tmp,
                      hipStream_t stream);
 int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g,
-                            const uint32_t* table, const BinView& b, uint64_t* keys, uint32_t* big_list, hipStream_t stream);
+                            const uint32_t* table, const BinView& b, uint64_t* keys, hipStream_t stream);
 
 int launch_emit(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g, uint32_t* keys,
                 uint32_t* vals, uint32_t* ranges, uint32_t nranges, hipStream_t stream);

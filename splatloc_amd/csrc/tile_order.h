@@ -9,14 +9,16 @@ constexpr int ORDER_THREADS = 1024, ORDER_BUCKETS = 1024;
 
 // One block of ORDER_THREADS threads buckets the T (view, tile) lists by length (16 entries per bucket, longest first) and writes
 // the tile ids in that order.  s_cnt: ORDER_BUCKETS words, s_wsum: ORDER_THREADS / WAVE words of LDS.
-__device__ __forceinline__ void tile_order_block(int T, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
-                                                 uint32_t* s_cnt, uint32_t* s_wsum)
+// `len_at(i)`: length of list i (the range table of the radix front end; the scanned (tile, chunk) table of the binned one, whose
+// ranges may still be in flight when this runs beside the tile kernel).
+template <typename LenAt>
+__device__ __forceinline__ void tile_order_block(int T, LenAt len_at, uint32_t* __restrict__ order, uint32_t* s_cnt, uint32_t* s_wsum)
 {
     const int t = threadIdx.x;
     s_cnt[t] = 0u;
     __syncthreads();
     for (int i = t; i < T; i += ORDER_THREADS) {
-        const uint32_t len = ranges[2 * i + 1] - ranges[2 * i];
+        const uint32_t len = len_at(i);
         atomicAdd(&s_cnt[ORDER_BUCKETS - 1 - min((uint32_t)(ORDER_BUCKETS - 1), len >> 4)], 1u);
     }
     __syncthreads();
@@ -37,7 +39,7 @@ __device__ __forceinline__ void tile_order_block(int T, const uint32_t* __restri
     s_cnt[t] = before + incl - c;
     __syncthreads();
     for (int i = t; i < T; i += ORDER_THREADS) {
-        const uint32_t len = ranges[2 * i + 1] - ranges[2 * i];
+        const uint32_t len = len_at(i);
         const uint32_t pos = atomicAdd(&s_cnt[ORDER_BUCKETS - 1 - min((uint32_t)(ORDER_BUCKETS - 1), len >> 4)], 1u);
         order[pos] = (uint32_t)i;
     }

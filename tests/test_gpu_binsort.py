@@ -24,6 +24,7 @@ def _restore_front_end():
     yield
     _native.set_front_end(-1)
     _native.check(_native.load().splatraster_debug_set_tile_sort_cap(0), "tile_sort_cap")
+    _native.check(_native.load().splatraster_debug_set_sort_fork(-1), "sort_fork")
 
 
 def _state_equal(a: HipRun, b: HipRun):
@@ -210,3 +211,42 @@ def test_render_stage_follows_the_front_end_the_geometry_stage_chose(first, then
     color, depth, alpha = outs[0]
     assert np.abs(color.cpu().numpy() - f["color"]).max() <= 1e-4
     assert np.abs(alpha.cpu().numpy().reshape(f["alpha"].shape) - f["alpha"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("fork", [0, 1])
+@pytest.mark.parametrize("name", ["one_long_list", "beyond_lds", "S0"])
+def test_long_list_launch_on_the_side_stream_changes_nothing(name, fork):
+    """The long-list sort launch finds its lists in the scanned table itself and may run beside the tile launch on the library's
+    side stream (splatraster_debug_set_sort_fork: 0 never, 1 always; default: when the scene has long lists).  Same state either
+    way, three frames in a row (the side stream and its events are reused), forward and backward against the oracle."""
+    sc = CASES[name]()
+    f = oracle_forward(sc)
+    _native.set_front_end(1)
+    _native.check(_native.load().splatraster_debug_set_sort_fork(fork), "sort_fork")
+    runs = [HipRun(sc, backward=(k == 2)) for k in range(3)]
+    for run in runs:
+        _check_forward(run, f, sc)
+    _check_backward(runs[2], oracle_backward(f, sc))
+    _state_equal(runs[0], runs[1])
+
+
+def test_window_with_long_lists_forks_by_itself():
+    """Default mode: the first frame meets a list beyond 2 048 keys and raises the hint; the following frames run the long-list
+    launch on the side stream.  A window of 3 views of such a scene, five frames in a row: per-view state stays the oracle's."""
+    from splatloc_amd import introspect, rasterize_window
+    from tests.test_gpu_window import _views
+    sc = _concentrate(make_scene(20_000, 256, 256, 4, 54, scale_median=0.02), 5_000, (130.4, 60.7))
+    dev = torch.device("cuda:0")
+    settings = [rs for _, rs, _ in _views(sc, 3, dev)]
+    _native.set_front_end(1)
+    first = None
+    for _ in range(5):
+        m3 = sc.means3D.to(dev).requires_grad_(True)
+        m2 = [torch.zeros_like(m3, requires_grad=True) for _ in settings]
+        res = rasterize_window(settings, m3, m2, sc.features.to(dev), sc.opacities.to(dev), sc.scales.to(dev), sc.rotations.to(dev))
+        torch.cuda.synchronize()
+        imgs = [r[0].detach().clone() for r in res]
+        if first is None:
+            first = imgs
+        for a, b in zip(first, imgs):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
