@@ -210,18 +210,18 @@ int launch_payload(const splatraster_settings& s, int32_t V, int64_t R, const Ge
 // compositing kernels map block -> tile_order[block's tile slot].  Which tile a wave works on changes, never what it computes.
 // Only for launches of a few rounds (use_tile_order, common.h).
 __global__ void __launch_bounds__(ORDER_THREADS)
-tile_order_kernel(int T, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order)
+tile_order_kernel(int T, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, uint32_t* __restrict__ nparts)
 {
     __shared__ uint32_t s_cnt[ORDER_BUCKETS];
     __shared__ uint32_t s_wsum[ORDER_THREADS / WAVE];
-    tile_order_block(T, [&](int i) { return ranges[2 * i + 1] - ranges[2 * i]; }, order, s_cnt, s_wsum);
+    tile_order_block(T, [&](int i) { return ranges[2 * i + 1] - ranges[2 * i]; }, order, s_cnt, s_wsum, nparts);
 }
 
 int launch_tile_order(const splatraster_settings& s, int32_t V, const BinView& b, hipStream_t stream)
 {
     const int gx = (s.image_width + TILE - 1) / TILE, gy = (s.image_height + TILE - 1) / TILE;
     if (!use_tile_order(V, gx * gy)) return SPLATRASTER_OK;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, stream, V * gx * gy, b.ranges, b.tile_order);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, stream, V * gx * gy, b.ranges, b.tile_order, b.nparts);
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

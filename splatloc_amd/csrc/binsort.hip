@@ -453,10 +453,10 @@ bin_sort_big_kernel(int gtiles, int tiles, int gx, int nchunk, int cap /*the til
         __shared__ uint32_t s_cnt[ORDER_BUCKETS];
         __shared__ uint32_t s_wsum[ORDER_THREADS / WAVE];
         if (ranges_final)   // (contiguous 8-byte entries)
-            tile_order_block(gtiles, [&](int i) { return b.ranges[2 * i + 1] - b.ranges[2 * i]; }, order, s_cnt, s_wsum);
+            tile_order_block(gtiles, [&](int i) { return b.ranges[2 * i + 1] - b.ranges[2 * i]; }, order, s_cnt, s_wsum, b.nparts);
         else                // beside the tile launch: from the scanned table, like the lists below — nothing that launch writes is read here
             tile_order_block(gtiles, [&](int i) { uint32_t st_, n_; tile_span((uint32_t)i, gtiles, nchunk, table, total, st_, n_); return n_; },
-                             order, s_cnt, s_wsum);
+                             order, s_cnt, s_wsum, b.nparts);
         __syncthreads();
     }
     // The long lists: list i is block i % gridDim.x's (neighbouring tiles — a near wall's — go to different blocks); every block

@@ -157,7 +157,7 @@ GeomView geom_view(void* base, int32_t P, int32_t V)
 }
 
 struct BinLayout {
-    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, ipack, featp, gacc, pose_acc, ckpt, tile_order, bytes;
+    size_t keysA, valsA, keysB, valsB, ranges, sort_tmp, irec, ipack, featp, gacc, pose_acc, ckpt, tile_order, nparts, bytes;
 };
 static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t H, int32_t C)
 {
@@ -184,8 +184,9 @@ static BinLayout bin_layout(int32_t P, int32_t V, int64_t R, int32_t W, int32_t 
     // mid-list checkpoints of the forward for split launches (small frames, narrow layouts): the maximum is reserved
     // whenever the shape qualifies, whatever the run-time knob says
     const bool ck = C <= 4 && 4 * (size_t)tiles <= (size_t)SPLIT_MAX_WAVES;
-    L.ckpt = take(ck ? nv * (size_t)SPLIT_PARTS * (size_t)(C + 2) * (size_t)W * (size_t)H * sizeof(float) : 16);
+    L.ckpt = take(ck ? nv * (size_t)SPLIT_PARTS_MAX * (size_t)(C + 2) * (size_t)W * (size_t)H * sizeof(float) : 16);
     L.tile_order = take(4 * (tiles > 0 ? tiles : 1));
+    L.nparts = take(4 * (tiles > 0 ? tiles : 1));
     L.bytes = o;
     return L;
 }
@@ -208,6 +209,7 @@ BinView bin_view(void* base, int32_t P, int32_t V, int64_t R, int32_t W, int32_t
     v.pose_acc = reinterpret_cast<float*>(b + L.pose_acc);
     v.ckpt = reinterpret_cast<float*>(b + L.ckpt);
     v.tile_order = reinterpret_cast<uint32_t*>(b + L.tile_order);
+    v.nparts = reinterpret_cast<uint32_t*>(b + L.nparts);
     return v;
 }
 

@@ -115,7 +115,8 @@ struct BinView {
     float* featp;         // [P * CP] feature rows padded to CP = roundup4(C) floats (16-byte aligned rows); shared by the views
     float* gacc;          // [V * P * gacc_row_floats(C)] backward gradient accumulator rows (one per row)
     float* pose_acc;      // right behind gacc (one fill zeroes both): POSE_SETS replicated accumulator sets of the camera gradients + the ticket word
-    float* ckpt;          // [V][SPLIT_PARTS][C + 2][H * W] segment records of the forward (T in front of the segment, its own colours, depth), split launches only
+    uint32_t* nparts;     // [V * tiles] parts of every (view, tile) list in a split launch (written with the launch order; common.h)
+    float* ckpt;          // [V][SPLIT_PARTS_MAX][C + 2][H * W] segment records of the forward (T in front of the segment, its own colours, depth), split launches only
     uint32_t* tile_order; // [V * tiles] global tile ids, longest list first: the launch order of the compositing kernels
 };
 struct ImgView {
@@ -241,16 +242,39 @@ constexpr int SPLIT_MIN_LIST = 256;
 #ifndef SR_SPLIT_PARTS
 #define SR_SPLIT_PARTS 4
 #endif
-constexpr int SPLIT_PARTS = SR_SPLIT_PARTS;
+constexpr int SPLIT_PARTS = SR_SPLIT_PARTS;     // parts of every split list = gridDim.y of the split backward
+// Round 6: the LONGEST lists of such a frame get more parts.  On a reconstructed room the lists are not the uniform cloud's: at
+// Replica scale (413k rows, 640x480) the mean list has 1 400 entries and 15 - 40 lists per frame exceed 4 096 (up to 7 400) — a
+// quarter of one is still 1 900 entries for one wave, and the backward (241 us) waited for those waves: 8 parts for EVERY list
+// 241 -> 217 us there but 102 -> 109 us on the uniform cloud, 16 parts 227 / 164 (profiles/r06_ab_probes.txt #5).  So: the first
+// SPLIT_EXTRA_TILES lists of the launch order (longest first) are split in 8 parts from SPLIT_LONG entries and in 16 from twice that;
+// their parts beyond the fourth are walked by EXTRA workgroups at the head of the backward's grid.  How many parts a list has is
+// decided once, by the block that computes the launch order (tile_order.h: `nparts[global tile]`), and read by the forward (which
+// writes that many segment records) and the backward alike.
+constexpr int SPLIT_PARTS_MAX = 4 * SPLIT_PARTS;       // segment records per pixel the checkpoint buffer holds
+#ifndef SR_SPLIT_LONG
+#define SR_SPLIT_LONG 2048
+#endif
+#ifndef SR_SPLIT_EXTRA_TILES
+#define SR_SPLIT_EXTRA_TILES 128
+#endif
+constexpr int SPLIT_LONG = SR_SPLIT_LONG, SPLIT_EXTRA_TILES = SR_SPLIT_EXTRA_TILES;
+static_assert(SPLIT_EXTRA_TILES % 8 == 0, "the extra workgroups use the quadrant id scheme (8 tiles per 32 ids)");
 void set_split_max_waves(int waves);   // A/B hook (< 0: default)
 void set_fwd_team(int mode);           // A/B hook: teams of four waves for the longest lists of a narrow launch (-1 automatic, 0 never, 1 whenever possible)
 void set_payload_stream_min(int64_t instances);   // test hook (< 0: default)
 int split_max_waves();
 static inline bool split_lists(int C, int V, int tiles) { return C <= 4 && 4 * V * tiles <= split_max_waves(); }
-// entries per part of a list of `len` entries (a multiple of the 64-entry chunk; len when the list is not split)
-__host__ __device__ static inline uint32_t split_part(uint32_t len)
+// parts of a list of `len` entries at position `rank` of the launch order
+__host__ __device__ static inline uint32_t split_count(uint32_t len, uint32_t rank)
 {
-    return len < (uint32_t)SPLIT_MIN_LIST ? len : ((len / (uint32_t)SPLIT_PARTS + 63u) & ~63u);
+    if (rank >= (uint32_t)SPLIT_EXTRA_TILES || len < (uint32_t)SPLIT_LONG) return (uint32_t)SPLIT_PARTS;
+    return len < 2u * (uint32_t)SPLIT_LONG ? 2u * (uint32_t)SPLIT_PARTS : (uint32_t)SPLIT_PARTS_MAX;
+}
+// entries per part of a list of `len` entries split in `np` parts (a multiple of the 64-entry chunk; len when the list is not split)
+__host__ __device__ static inline uint32_t split_part(uint32_t len, uint32_t np = (uint32_t)SPLIT_PARTS)
+{
+    return len < (uint32_t)SPLIT_MIN_LIST ? len : ((len / np + 63u) & ~63u);
 }
 
 int launch_composite_fwd(const splatraster_settings& s, int32_t P, int32_t V, int64_t R, const GeomView& g, const BinView& b,

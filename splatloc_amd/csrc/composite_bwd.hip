@@ -161,8 +161,10 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
                      const float* __restrict__ final_T_all, const uint32_t* __restrict__ n_contrib_all,
                      float* __restrict__ gacc /*[V * P, GROW]*/, int GROW,
                      int MO, long long* __restrict__ gacc64 /*[V * P, GROW] fixed point, DET only*/,
-                     const float* __restrict__ ckpt_all /*split launches (common.h; gridDim.y == SPLIT_PARTS): the forward's list
-                                                          checkpoints [V][SPLIT_PARTS - 1][NC + 2][H * W], else null*/,
+                     const float* __restrict__ ckpt_all /*split launches (common.h; gridDim.y == SPLIT_PARTS): the forward's segment
+                                                          records [V][SPLIT_PARTS_MAX][NC + 2][H * W], else null*/,
+                     const uint32_t* __restrict__ nparts /*split launches: parts of every (view, tile) list, or null: SPLIT_PARTS*/,
+                     int extra_blocks /*split launches: workgroups at the head of the grid that walk parts 4 .. of the longest lists*/,
                      const uint32_t* __restrict__ tile_order /*launch order (binning.hip), or null*/,
                      int det_pass /*DET only: 0 = per-element max of |partial|, 1 = fixed-point sums (acc_add)*/)
 {
@@ -193,8 +195,22 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
 
     int gtile, quad;   // global tile = view * tiles + tile: the grid covers the V views of the window
     const int gx = (W + TILE - 1) / TILE;
-    quadrant_of_block(blockIdx.x, V * tiles, gx, gtile, quad, tile_order);
-    if (gtile >= V * tiles) return;
+    int seg_y = (int)blockIdx.y;      // split launches: the part of the list this wave walks
+    if (NC <= 4 && (int)blockIdx.x < extra_blocks) {
+        // EXTRA workgroups (first in the grid: their lists are the launch's longest): group e / (ids of SPLIT_EXTRA_TILES tiles) walks
+        // parts 4 (group + 1) + blockIdx.y of the list at position r of the launch order — if that list has so many parts
+        const unsigned per = quadrant_blocks(SPLIT_EXTRA_TILES, gx);
+        const unsigned group = blockIdx.x / per;
+        int r;
+        quadrant_of_block(blockIdx.x - group * per, SPLIT_EXTRA_TILES, gx, r, quad);
+        if (r >= SPLIT_EXTRA_TILES || r >= V * tiles) return;
+        gtile = (int)tile_order[r];
+        seg_y += SPLIT_PARTS * (int)(group + 1u);
+        if (seg_y >= (int)nparts[gtile]) return;
+    } else {
+        quadrant_of_block(blockIdx.x - (NC <= 4 ? (unsigned)extra_blocks : 0u), V * tiles, gx, gtile, quad, tile_order);
+        if (gtile >= V * tiles) return;
+    }
     const int view = (V == 1) ? 0 : gtile / tiles;      // wave-uniform (scalar)
     const int tile = gtile - view * tiles;
     const uint32_t row0 = (uint32_t)view * (uint32_t)P;  // accumulator rows are per (view, Gaussian), feature rows shared
@@ -216,11 +232,12 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
     // split launches: wave blockIdx.y of the quadrant takes part blockIdx.y of the tile's list
     const uint32_t list0 = beg;                                // list positions (n_contrib) count from the tile's first entry
     const bool split = !DET && NC <= 4 && ckpt_all != nullptr;   // (the accurate mode starts every list at its head)
-    const int seg = split ? (int)blockIdx.y : 0;
+    const int seg = split ? seg_y : 0;
+    const int np = (split && nparts != nullptr) ? (int)nparts[gtile] : SPLIT_PARTS;   // parts of this list (wave-uniform)
     if (split) {
-        const uint32_t part = split_part(end0 - beg);
+        const uint32_t part = split_part(end0 - beg, (uint32_t)np);
         beg += (uint32_t)seg * part;
-        if (seg < SPLIT_PARTS - 1) end0 = min(end0, beg + part);
+        if (seg < np - 1) end0 = min(end0, beg + part);
         if (beg >= end0) return;
     }
     // (the forward wrote C_total + 2 planes per checkpoint k, taken in front of list entry beg + (k + 1) part: T, its C_total
@@ -237,7 +254,7 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
         last = n_contrib[pix];
         // a split launch's segment that ends in FRONT of this pixel's last contributor starts from the boundary state rebuilt
         // from the forward's segment records (common.h): T_b, and A_b = (what the later segments contribute) / T_b
-        const bool from_ckpt = split && seg < SPLIT_PARTS - 1 && list0 + last > end0;
+        const bool from_ckpt = split && seg < np - 1 && list0 + last > end0;
         float s_end = 0.0f;
         // planes [0, gc) behind dL_dcolor, the LAST channel's plane behind dL_dlast, nothing in between.  Branch-free on purpose:
         // every channel loads from a valid address chosen by selects (plane 0 when the channel has no gradient) and the value
@@ -281,8 +298,8 @@ composite_bwd_kernel(int W, int H, int C_total, int CP4, int c0, int first_pass,
             if (from_ckpt) {
                 // later segments first (the smallest contributions), this boundary's neighbour last
                 float sfx = final_T[pix] * s_end;
-                const float* rec0 = ckpt_all + (size_t)view * SPLIT_PARTS * (C_total + 2) * plane + pix;
-                for (int k = SPLIT_PARTS - 1; k > seg; --k) {
+                const float* rec0 = ckpt_all + (size_t)view * SPLIT_PARTS_MAX * (C_total + 2) * plane + pix;
+                for (int k = np - 1; k > seg; --k) {
                     const float* ck = rec0 + (size_t)k * (C_total + 2) * plane;
 #pragma unroll
                     for (int ch = 0; ch < NC; ++ch) sfx = fmaf(ck[(size_t)(1 + c0 + ch) * plane], g[ch], sfx);
@@ -680,13 +697,17 @@ static int launch_one_bwd(const splatraster_settings& s, int c0, int first, cons
     const int tiles = gx * gy;
     const unsigned blocks = quadrant_blocks(L.V * tiles, gx);  // 4 quadrants per (view, tile) (+ padding of the id space)
     const float* ckpt = (NC <= 4 && c0 == 0 && first) ? L.ckpt : nullptr;
-    const dim3 grid(blocks, ckpt ? (unsigned)SPLIT_PARTS : 1u);
+    // split launches with a launch order: three groups of extra workgroups (parts 4 .. 15 of the SPLIT_EXTRA_TILES longest lists) lead the grid
+    const bool extras = ckpt != nullptr && use_tile_order(L.V, tiles);
+    const unsigned extra_blocks = extras ? (unsigned)(SPLIT_PARTS_MAX / SPLIT_PARTS - 1) * quadrant_blocks(SPLIT_EXTRA_TILES, gx) : 0u;
+    const dim3 grid(blocks + extra_blocks, ckpt ? (unsigned)SPLIT_PARTS : 1u);
 #define SR_BWD_LAUNCH(SPV)                                                                                          \
     hipLaunchKernelGGL((composite_bwd_kernel<NC, DET, SPV, AUX>), grid, dim3(WAVE), 0, stream, s.image_width,           \
                        s.image_height, feat_stride, padded_channels(feat_stride) / 4, c0, first, tiles, L.V, L.P,      \
                        b.ranges, b.ipack, b.irec, reinterpret_cast<const float4*>(feat), *L.grads,       \
                        im.final_T, im.n_contrib, gacc, gacc_row_floats(s.channels),                                    \
-                       gacc_moment_offset(s.channels), gacc64, ckpt, use_tile_order(L.V, tiles) ? b.tile_order : nullptr, L.det_pass)
+                       gacc_moment_offset(s.channels), gacc64, ckpt, extras ? b.nparts : nullptr, (int)extra_blocks,               \
+                       use_tile_order(L.V, tiles) ? b.tile_order : nullptr, L.det_pass)
     if constexpr (NC >= 4 && NC <= 15 && AUX) {   // C = 3 and below: the flush costs what the 8 saved butterfly values gain (A/B: S0 0.036 vs 0.041 ms)
         // per VIEW: small frames (SplatLoc's 640x480) take the panel variant — also as a window of V views (A/B at the
         // reference layout, 5 views: 0.816 vs 0.869 ms); large frames the butterfly variant at full occupancy

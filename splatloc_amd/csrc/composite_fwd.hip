@@ -342,8 +342,9 @@ composite_fwd_kernel(int W, int H, int CP4, int c0, int bg_channels, int write_a
         const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ ipack /*id | reach bits << 24*/,                  \
         const float4 *__restrict__ irec, const float4 *__restrict__ featp4, const float *__restrict__ bg, WinOut outs,      \
         float *__restrict__ final_T_all, uint32_t *__restrict__ n_contrib_all,                                              \
-        float *__restrict__ ckpt_all /*split launches (common.h): [V][SPLIT_PARTS][NC + 2][H * W] segment records, else null*/
-#define SR_FWD_ARGS W, H, CP4, c0, bg_channels, write_aux, tiles, V, P, ranges, ipack, irec, featp4, bg, outs, final_T_all, n_contrib_all, ckpt_all
+        float *__restrict__ ckpt_all /*split launches (common.h): [V][SPLIT_PARTS_MAX][NC + 2][H * W] segment records, else null*/, \
+        const uint32_t *__restrict__ nparts /*split launches: parts of every (view, tile) list (written with the launch order), or null: SPLIT_PARTS*/
+#define SR_FWD_ARGS W, H, CP4, c0, bg_channels, write_aux, tiles, V, P, ranges, ipack, irec, featp4, bg, outs, final_T_all, n_contrib_all, ckpt_all, nparts
 
 // one quadrant of global tile `gtile` (= view * tiles + tile) by ONE wave; s_rec0 / s_rec1 / s_fq: WAVE + 1 float4 each, the wave's own
 template <int NC>
@@ -408,7 +409,8 @@ __device__ __forceinline__ void narrow_quadrant(SR_FWD_PARAMS, int gtile, int qu
     // are accumulated from zero, so they are accurate relative to their own (transmittance-scaled) magnitude; the backward
     // rebuilds "what lies behind a boundary" from the sums of the later segments (a prefix C_k subtracted from the image
     // would carry the image's rounding, 1e-7 |C|, into a remainder of size T_k |C|).
-    const uint32_t part = ckpt_all != nullptr ? split_part(end - beg) : 0u;
+    const int np = (ckpt_all != nullptr && nparts != nullptr) ? (int)nparts[gtile] : SPLIT_PARTS;   // (wave-uniform)
+    const uint32_t part = ckpt_all != nullptr ? split_part(end - beg, (uint32_t)np) : 0u;
     uint32_t ck_at = part ? beg + part : 0xFFFFFFFFu;
     int ck_k = 0;
     float sacc[NC], sD = 0.0f;     // the current segment's own sums (split launches only)
@@ -417,7 +419,7 @@ __device__ __forceinline__ void narrow_quadrant(SR_FWD_PARAMS, int gtile, int qu
     auto store_segment = [&](int k, bool with_next_T) {
         if (inside) {
             const size_t pl = (size_t)H * W;
-            float* ck = ckpt_all + ((size_t)view * SPLIT_PARTS + k) * (NC + 2) * pl + (size_t)py * W + px;
+            float* ck = ckpt_all + ((size_t)view * SPLIT_PARTS_MAX + k) * (NC + 2) * pl + (size_t)py * W + px;
 #pragma unroll
             for (int ch = 0; ch < NC; ++ch) ck[(size_t)(1 + ch) * pl] = sacc[ch];
             ck[(size_t)(1 + NC) * pl] = sD;
@@ -432,7 +434,7 @@ __device__ __forceinline__ void narrow_quadrant(SR_FWD_PARAMS, int gtile, int qu
             for (int ch = 0; ch < NC; ++ch) sacc[ch] = 0.0f;
             sD = 0.0f;
             ++ck_k;
-            ck_at = ck_k < SPLIT_PARTS - 1 ? ck_at + part : 0xFFFFFFFFu;
+            ck_at = ck_k < np - 1 ? ck_at + part : 0xFFFFFFFFu;
         }
         uint64_t cand = __builtin_amdgcn_ballot_w64((pw >> (24 + quad)) & 1u);
         if (cand != 0) {
@@ -495,7 +497,7 @@ __device__ __forceinline__ void narrow_quadrant(SR_FWD_PARAMS, int gtile, int qu
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) sacc[ch] = 0.0f;
         sD = 0.0f;
-        for (int k = ck_k + 1; k < SPLIT_PARTS; ++k) store_segment(k, false);   // segments the wave never reached contribute nothing
+        for (int k = ck_k + 1; k < np; ++k) store_segment(k, false);   // segments the wave never reached contribute nothing
     }
     if (inside) {
         const size_t plane = (size_t)H * W;
@@ -586,7 +588,8 @@ __device__ __forceinline__ void team_quadrant(SR_FWD_PARAMS, int gtile, int quad
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (WAVE - lane));
     const size_t plane = (size_t)H * W;
     const size_t pix = (size_t)py * W + px;
-    const uint32_t part = ckpt_all != nullptr ? split_part(end - beg) : 0u;
+    const int np = (ckpt_all != nullptr && nparts != nullptr) ? (int)nparts[gtile] : SPLIT_PARTS;   // (workgroup-uniform)
+    const uint32_t part = ckpt_all != nullptr ? split_part(end - beg, (uint32_t)np) : 0u;
 
     if (threadIdx.x == 0) s_fin = -1;
     __syncthreads();
@@ -698,9 +701,9 @@ __device__ __forceinline__ void team_quadrant(SR_FWD_PARAMS, int gtile, int quad
         int ck_k = 0;
         auto boundary = [&] {
             if (base == ck_at) {   // a segment ends in front of this entry: plane 0 of record k + 1 = T in front of it
-                if (inside) ckpt_all[((size_t)view * SPLIT_PARTS + ck_k) * (NC + 2) * plane + pix + (size_t)(NC + 2) * plane] = T;
+                if (inside) ckpt_all[((size_t)view * SPLIT_PARTS_MAX + ck_k) * (NC + 2) * plane + pix + (size_t)(NC + 2) * plane] = T;
                 ++ck_k;
-                ck_at = ck_k < SPLIT_PARTS - 1 ? ck_at + part : 0xFFFFFFFFu;
+                ck_at = ck_k < np - 1 ? ck_at + part : 0xFFFFFFFFu;
             }
         };
         bool finished = false;
@@ -772,7 +775,7 @@ __device__ __forceinline__ void team_quadrant(SR_FWD_PARAMS, int gtile, int quad
     for (int ch = 0; ch < NC; ++ch) sacc[ch] = 0.0f;
     auto store_sums = [&](int k) {
         if (inside) {
-            float* ck = ckpt_all + ((size_t)view * SPLIT_PARTS + k) * (NC + 2) * plane + pix;
+            float* ck = ckpt_all + ((size_t)view * SPLIT_PARTS_MAX + k) * (NC + 2) * plane + pix;
 #pragma unroll
             for (int ch = 0; ch < NC; ++ch) ck[(size_t)(1 + ch) * plane] = sacc[ch];
             ck[(size_t)(1 + NC) * plane] = sD;
@@ -785,7 +788,7 @@ __device__ __forceinline__ void team_quadrant(SR_FWD_PARAMS, int gtile, int quad
             for (int ch = 0; ch < NC; ++ch) sacc[ch] = 0.0f;
             sD = 0.0f;
             ++ck_k;
-            ck_at = ck_k < SPLIT_PARTS - 1 ? ck_at + part : 0xFFFFFFFFu;
+            ck_at = ck_k < np - 1 ? ck_at + part : 0xFFFFFFFFu;
         }
     };
 #pragma unroll 1
@@ -833,7 +836,7 @@ __device__ __forceinline__ void team_quadrant(SR_FWD_PARAMS, int gtile, int quad
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) sacc[ch] = 0.0f;
         sD = 0.0f;
-        for (int k = ck_k + 1; k < SPLIT_PARTS; ++k) store_sums(k);   // segments the walk never reached contribute nothing
+        for (int k = ck_k + 1; k < np; ++k) store_sums(k);   // segments the walk never reached contribute nothing
     }
     if (inside) {
         const float T = s_T[lane];
@@ -951,12 +954,13 @@ static int launch_one(const splatraster_settings& s, int c0, int write_aux, cons
             hipLaunchKernelGGL(composite_fwd_mixed_kernel<NC>, dim3((unsigned)(L.V * tiles + 4 * TEAM_MAX)), dim3(4 * WAVE), 0, stream,
                                s.image_width, s.image_height, padded_channels(feat_stride) / 4, c0, s.bg_channels, write_aux, tiles, L.V, L.P,
                                b.ranges, b.ipack, b.irec, reinterpret_cast<const float4*>(featp), bg, *L.outs, im.final_T, im.n_contrib,
-                               (c0 == 0 && write_aux) ? L.ckpt : nullptr, b.tile_order, g_fwd_team == 2 ? 1 : 0);
+                               (c0 == 0 && write_aux) ? L.ckpt : nullptr, b.nparts, b.tile_order, g_fwd_team == 2 ? 1 : 0);
         } else {
             hipLaunchKernelGGL(composite_fwd_narrow_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,
                                s.image_height, padded_channels(feat_stride) / 4, c0, s.bg_channels, write_aux, tiles, L.V, L.P, b.ranges,
                                b.ipack, b.irec, reinterpret_cast<const float4*>(featp), bg, *L.outs, im.final_T,
-                               im.n_contrib, (c0 == 0 && write_aux) ? L.ckpt : nullptr, use_tile_order(L.V, tiles) ? b.tile_order : nullptr);
+                               im.n_contrib, (c0 == 0 && write_aux) ? L.ckpt : nullptr, use_tile_order(L.V, tiles) ? b.nparts : nullptr,
+                               use_tile_order(L.V, tiles) ? b.tile_order : nullptr);
         }
     } else {
         hipLaunchKernelGGL(composite_fwd_kernel<NC>, dim3(blocks), dim3(WAVE), 0, stream, s.image_width,

@@ -12,7 +12,8 @@ constexpr int ORDER_THREADS = 1024, ORDER_BUCKETS = 1024;
 // `len_at(i)`: length of list i (the range table of the radix front end; the scanned (tile, chunk) table of the binned one, whose
 // ranges may still be in flight when this runs beside the tile kernel).
 template <typename LenAt>
-__device__ __forceinline__ void tile_order_block(int T, LenAt len_at, uint32_t* __restrict__ order, uint32_t* s_cnt, uint32_t* s_wsum)
+__device__ __forceinline__ void tile_order_block(int T, LenAt len_at, uint32_t* __restrict__ order, uint32_t* s_cnt, uint32_t* s_wsum,
+                                                 uint32_t* __restrict__ nparts = nullptr /*[T]: parts of list i in a split launch (common.h)*/)
 {
     const int t = threadIdx.x;
     s_cnt[t] = 0u;
@@ -42,6 +43,7 @@ __device__ __forceinline__ void tile_order_block(int T, LenAt len_at, uint32_t* 
         const uint32_t len = len_at(i);
         const uint32_t pos = atomicAdd(&s_cnt[ORDER_BUCKETS - 1 - min((uint32_t)(ORDER_BUCKETS - 1), len >> 4)], 1u);
         order[pos] = (uint32_t)i;
+        if (nparts) nparts[i] = split_count(len, pos);
     }
 }
 
