@@ -247,16 +247,18 @@ constexpr int SPLIT_PARTS = SR_SPLIT_PARTS;     // parts of every split list = g
 // Replica scale (413k rows, 640x480) the mean list has 1 400 entries and 15 - 40 lists per frame exceed 4 096 (up to 7 400) — a
 // quarter of one is still 1 900 entries for one wave, and the backward (241 us) waited for those waves: 8 parts for EVERY list
 // 241 -> 217 us there but 102 -> 109 us on the uniform cloud, 16 parts 227 / 164 (profiles/r06_ab_probes.txt #5).  So: the first
-// SPLIT_EXTRA_TILES lists of the launch order (longest first) are split in 8 parts from SPLIT_LONG entries and in 16 from twice that;
+// SPLIT_EXTRA_TILES lists of the launch order (longest first) are split in 8 parts from SPLIT_LONG entries and in 16 from twice that
+// (128 lists from 2 048 entries: 214 us at Replica scale / 134 on the 60-key-frame room / 102 on the uniform cloud; 256 from 1 536:
+// 201 / 133 / 103; 512 from 1 024: 195 / 128 / 105 — SplatLoc's maps are rooms: the last one);
 // their parts beyond the fourth are walked by EXTRA workgroups at the head of the backward's grid.  How many parts a list has is
 // decided once, by the block that computes the launch order (tile_order.h: `nparts[global tile]`), and read by the forward (which
 // writes that many segment records) and the backward alike.
 constexpr int SPLIT_PARTS_MAX = 4 * SPLIT_PARTS;       // segment records per pixel the checkpoint buffer holds
 #ifndef SR_SPLIT_LONG
-#define SR_SPLIT_LONG 2048
+#define SR_SPLIT_LONG 1024
 #endif
 #ifndef SR_SPLIT_EXTRA_TILES
-#define SR_SPLIT_EXTRA_TILES 128
+#define SR_SPLIT_EXTRA_TILES 512
 #endif
 constexpr int SPLIT_LONG = SR_SPLIT_LONG, SPLIT_EXTRA_TILES = SR_SPLIT_EXTRA_TILES;
 static_assert(SPLIT_EXTRA_TILES % 8 == 0, "the extra workgroups use the quadrant id scheme (8 tiles per 32 ids)");

@@ -23,7 +23,10 @@ names = {"bench_S2.json": "bench.json", "bench_S0.json": "bench_S0.json", "bench
          "scene_radix_front_end.json": "scene_radix_front_end.json", "refine_idle.json": "refine_idle.json", "refine_idle_S0.json": "refine_idle_S0.json",
          "refine_idle_radix_front_end.json": "refine_idle_radix_front_end.json", "scene_lists.json": "scene_lists.json",
          "scene_lists_radix_front_end.json": "scene_lists_radix_front_end.json",
-         "scene_lists_one_wave_forward.json": "scene_lists_one_wave_forward.json", "lone_wave.json": "lone_wave.json"}
+         "scene_lists_one_wave_forward.json": "scene_lists_one_wave_forward.json", "lone_wave.json": "lone_wave.json",
+         "rccl_contact.json": "rccl_contact.json", "bench_force_process_group.json": "bench_force_process_group.json",
+         "bench_force_process_group_rs_ag.json": "bench_force_process_group_rs_ag.json", "map_idle_S2-ref-layout.json": "map_idle_S2-ref-layout.json",
+         "map_idle_S2.json": "map_idle_S2.json", "scene_lists_replica_scale.json": "scene_lists_replica_scale.json"}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p):

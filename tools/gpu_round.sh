@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's evidence in one run on the GPU box (replaces the per-round scratch scripts):
-#   tools/gpu_round.sh TAG [all|profile|bench|stages|scene|idle]      e.g.  tools/gpu_round.sh r05 all
+#   tools/gpu_round.sh TAG [all|profile|bench|stages|scene|dist|idle]      e.g.  tools/gpu_round.sh r06 all
 # Everything is written under gpurun_out/TAG/; tools/collect_round.py TAG rNN copies the summaries into profiles/.
 TAG=${1:-r05}; WHAT=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,7 +10,8 @@ want() { [ "$WHAT" = all ] || [ "$WHAT" = "$1" ]; }
 if want profile; then
   bash tools/gpu_profile.sh $TAG > $O/profile.log 2>&1; tail -6 $O/profile.log
   python tools/clock_trace.py $O/clocks.json > $O/clock_summary.txt 2>&1; cut -c1-300 $O/clock_summary.txt
-  bash tools/ms_timeline.sh S2-ref-layout refine_step > /dev/null 2>&1; cp gpurun_out/map_step_timeline.txt $O/refine_step_timeline.txt
+  # (no rocprofv3 timeline of the refinement iteration any more: the profiler's own overhead made it 524 us of a 398-us iteration;
+  #  the LIVE figures are tools/refine_idle.py's, below)
 fi
 if want bench; then
   python bench.py > $O/bench_S2.json 2> $O/bench_S2.err; cut -c1-200 $O/bench_S2.json; echo
@@ -30,7 +31,15 @@ if want scene; then
   python bench.py --stage scene --keyframes 180 --truth 600000 > $O/scene_replica_scale.json 2>/dev/null; cut -c1-200 $O/scene_replica_scale.json; echo
   SPLATRASTER_FRONT_END=0 python bench.py --stage scene > $O/scene_radix_front_end.json 2>/dev/null; cut -c1-200 $O/scene_radix_front_end.json; echo
 fi
+if want dist; then
+  python tools/rccl_contact.py > $O/rccl_contact.json 2>$O/rccl_contact.err; cut -c1-200 $O/rccl_contact.json; echo
+  python bench.py --gpus 1 --force-process-group --no-cpu-baseline --no-multi-stream > $O/bench_force_process_group.json 2>/dev/null; cut -c1-160 $O/bench_force_process_group.json; echo
+  python bench.py --gpus 1 --force-process-group --reduce rs_ag --no-cpu-baseline --no-multi-stream > $O/bench_force_process_group_rs_ag.json 2>/dev/null; cut -c1-160 $O/bench_force_process_group_rs_ag.json; echo
+fi
 if want idle; then
+  python tools/map_idle.py S2-ref-layout 100 0 > $O/map_idle_S2-ref-layout.json 2>/dev/null; cut -c1-300 $O/map_idle_S2-ref-layout.json; echo
+  python tools/map_idle.py S2 40 0 > $O/map_idle_S2.json 2>/dev/null; cut -c1-300 $O/map_idle_S2.json; echo
+  python tools/scene_lists.py 180 600000 300 > $O/scene_lists_replica_scale.json 2>/dev/null; cut -c1-200 $O/scene_lists_replica_scale.json; echo
   python tools/refine_idle.py S2-ref-layout 300 > $O/refine_idle.json 2>/dev/null; cut -c1-200 $O/refine_idle.json; echo
   python tools/refine_idle.py S0 300 > $O/refine_idle_S0.json 2>/dev/null
   SPLATRASTER_FRONT_END=0 python tools/refine_idle.py S2-ref-layout 300 > $O/refine_idle_radix_front_end.json 2>/dev/null
