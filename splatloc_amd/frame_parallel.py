@@ -153,16 +153,46 @@ def sync_densification_stats(grad_accum_inc: torch.Tensor, denom_inc: torch.Tens
     denom_inc.copy_(packed[n:].view_as(denom_inc))
 
 
+_HEADER_GROUPS: dict = {}
+
+
+def _header_group(group):
+    """The group the 32-byte length check runs on: a GLOO twin of `group` (same ranks), created once — collectively, by the first
+    reduce_step / broadcast_model every rank reaches — when `group` itself is not a CPU backend.  The check's result is read on the
+    HOST; on the payload's own (RCCL) group that read drained the stream in front of every step's payload: 0.3 ms of a 6.8-ms S2
+    step on a group of one (bench.py --force-process-group: 700 instead of 733 frames/s), and the host could no longer run ahead of
+    the GPU across the reduction (round-5 advisor).  Over gloo the host blocks for the exchange only, the GPU keeps working."""
+    import weakref
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+    hit = _HEADER_GROUPS.get(id(pg))
+    if hit is not None and hit[0]() is pg:       # (the same group OBJECT: a re-initialised default group is a new one)
+        return hit[1]
+    if _backend_of(group) == "gloo":
+        g = (group, True)
+    else:
+        try:
+            g = (dist.new_group(ranks=dist.get_process_group_ranks(pg), backend="gloo"), True)
+        except Exception:  # noqa: BLE001  (no gloo in this build: the check stays on the payload's group, with its device read)
+            g = (group, False)
+    try:
+        _HEADER_GROUPS[id(pg)] = (weakref.ref(pg), g)
+    except TypeError:    # (a group object that cannot be weakly referenced: kept alive by the cache instead)
+        _HEADER_GROUPS[id(pg)] = ((lambda _pg=pg: _pg), g)
+    return g
+
+
 def _check_same_layout(numel, device, group) -> None:
     """A SUM over buffers of different lengths is undefined behaviour in RCCL (and silently wrong sums when the
     lengths agree but the piece order does not).  EVERY call verifies, with one fixed-size 32-byte MAX collective
     issued before the payload, that all ranks are about to reduce the same length.  (Rounds 3-4 cached the lengths a
     rank had already checked: a rank that had cached a length skipped the collective while a diverging peer issued
     it, pairing the peer's int64 MAX with this rank's float SUM — a hang instead of the intended error.  The check is
-    only a check if every rank always takes part in it.)"""
+    only a check if every rank always takes part in it.)  Round 6: the exchange runs on a CPU (gloo) twin of the group
+    (`_header_group`): no device synchronisation in front of the payload."""
     lens = [int(numel), 0] if not isinstance(numel, (tuple, list)) else [int(v) for v in numel][:2] + [0] * (2 - len(numel))
-    t = torch.tensor([lens[0], -lens[0], lens[1], -lens[1]], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hgroup, on_cpu = _header_group(group)
+    t = torch.tensor([lens[0], -lens[0], lens[1], -lens[1]], dtype=torch.int64, device="cpu" if on_cpu else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=hgroup)
     v = t.tolist()
     if v[0] != -v[1] or v[2] != -v[3]:
         raise RuntimeError(f"frame_parallel.reduce_step: ranks disagree on the reduce buffers (SUM {-v[1]} .. {v[0]}, "

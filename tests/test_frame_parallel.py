@@ -240,3 +240,44 @@ def test_bench_gpus_flag_launches_ranks_or_refuses(monkeypatch):
     monkeypatch.undo()
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_group_of_one_exchanges_nothing_unless_forced():
+    """A process group of ONE rank: every function returns early (no collective) — unless `force=True` (or
+    SPLATLOC_FORCE_COLLECTIVES=1), which issues every collective anyway: the first-contact path tests/test_gpu_rccl.py drives on
+    RCCL, here on gloo.  SUM / MAX / broadcast over one rank leave the values unchanged."""
+    from splatloc_amd import frame_parallel as fp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert not fp.collectives_active() and fp.collectives_active(force=True)
+        flat = torch.arange(100, dtype=torch.float32)
+        a, b, c = flat[0:30].view(10, 3), flat[32:42].view(10, 1), flat[44:84].view(10, 4)
+        tail = flat[84:100].view(2, 8)
+        mx = torch.rand(7)
+        ref = flat.clone(), mx.clone()
+        g, e, info = fp.reduce_step([a, b, c], sum_extras=[tail[0], tail[1]], max_extras=[mx])
+        assert info["collectives"] == 0 and g[0] is a
+        for mode in ("ring", "rs_ag"):
+            g, e, info = fp.reduce_step([a, b, c], sum_extras=[tail[0], tail[1]], max_extras=[mx], mode=mode, force=True)
+            assert info["sum_path"] == "in-place span" and info["collectives"] == 2 and info["header_collectives"] == 1
+            assert info["header_ms"] >= 0.0
+            assert g[0].data_ptr() == a.data_ptr() and torch.equal(flat, ref[0]) and torch.equal(mx, ref[1])
+        # packed path (pieces of different allocations)
+        x, y = torch.randn(13), torch.randn(5, 1)
+        rx, ry = x.clone(), y.clone()
+        g, e, info = fp.reduce_step([x], sum_extras=[y], mode="rs_ag", force=True)
+        assert info["sum_path"] == "packed" and torch.equal(g[0], rx) and torch.equal(e[0], ry)
+        assert fp.allreduce_grads([a, b, c]) is None
+        path = fp.allreduce_grads([a, None, b, c, torch.randn(4, 3)[:, :2]], force=True)
+        assert path["spans"] == 1 and path["buckets"] == 1 and torch.equal(flat, ref[0])
+        fp.FORCE_COLLECTIVES = True
+        try:
+            assert fp.collectives_active()
+            g, e, info = fp.reduce_step([a, b, c], sum_extras=[tail[0], tail[1]], max_extras=[mx])
+            assert info["collectives"] == 2
+        finally:
+            fp.FORCE_COLLECTIVES = False
+    finally:
+        dist.destroy_process_group()
