@@ -990,7 +990,8 @@ def launch_ranks(n: int, argv) -> int:
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env, cwd=ROOT, stdout=sys.stdout).returncode      # (the ranks' fd 1 = the REAL stdout: main() moved ours)
 
 
 def main():
@@ -1034,6 +1035,13 @@ def main():
                     choices=["raster", "activations", "loss", "map_step", "refine_step", "scene", "eval_rendering", "pose_refine"],
                     help="raster = the BASELINE metric (default); activations = the fused front-end stage alone")
     args = ap.parse_args()
+
+    # stdout carries ONE JSON line.  Native libraries write banners to file descriptor 1 (RCCL under NCCL_DEBUG=VERSION: five lines per
+    # process group; gloo: "[Gloo] Rank 0 is connected to ..."): Python's own stdout moves to a duplicate of the real one and fd 1 is
+    # pointed at stderr, so that whatever C code prints lands beside the warnings, not in front of the line the driver parses.
+    sys.stdout.flush()
+    sys.stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher around us: become one (a fresh child process per rank; nothing here has touched the GPU yet)

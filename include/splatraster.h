@@ -594,10 +594,10 @@ int splatraster_debug_set_front_end(int mode);
  * raises when it meets a list beyond 2048 keys (longer lists than the chosen launch holds go to its work-list launch either
  * way).  2048 / 4096 force an instantiation, any other value restores the default.  Results never depend on it. */
 int splatraster_debug_set_tile_sort_cap(int keys);
-/* The binned front end's two sort launches (lists up to the tile launch's cap | longer lists, which that launch finds in the
- * scanned table itself) are independent: -1 (default) runs the long-list launch on an internal side stream — forked behind the
- * key scatter, joined before the compositing grid — when a list beyond 2048 keys was seen in the last 64 frames; 0 never (both
- * on the caller's stream); 1 always.  Results never depend on it. */
+/* Measurement hook.  The binned front end's two sort launches (lists up to the tile launch's cap | longer lists, which that launch
+ * finds in the scanned table itself) are independent: 0 (default) = both on the caller's stream; -1 = the long-list launch on an
+ * internal side stream — forked behind the key scatter, joined before the compositing grid — when a list beyond 2048 keys was seen
+ * in the last 64 frames; 1 = always.  Measured a wash at Replica scale (profiles/r06_ab_probes.txt #6).  Results never depend on it. */
 int splatraster_debug_set_sort_fork(int mode);
 int splatraster_debug_exp2(int64_t n, const float* x, float* y, void* stream);
 /* test hook: fills the LDS of every compute unit with `pattern` (e.g. a NaN's bits): enough workgroups of 64 KB each to cover

@@ -573,8 +573,10 @@ static int wide_hint_init(int dev)
     return SPLATRASTER_OK;
 }
 
-// -1: fork the long-list launch onto the side stream when the scene has long lists (default); 0: never; 1: always
-static int g_bin_fork = -1;
+// 0 (default): both sort launches on the caller's stream; -1: the long-list launch on the side stream when the scene has long lists; 1: always.
+// Measured a wash (profiles/r06_ab_probes.txt #6: 4 x 9 interleaved regions at Replica scale: 599.5 us forked, 596.5 serial): the fork / join
+// costs what the overlap of 40 us of one-block sorts with a 58-us launch of 1 200 blocks gains.  The hook stays for measurements.
+static int g_bin_fork = 0;
 void set_bin_fork(int mode) { g_bin_fork = mode < 0 ? -1 : (mode > 1 ? 1 : mode); }
 
 // one side stream + fork / join events per host thread (events are re-recorded per call: another thread's call must never sit
@@ -628,6 +630,7 @@ int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V,
     // that HAS long lists they run side by side: the long-list launch on this thread's side stream, forked behind the scatter
     // and joined before the compositing grids (round 5: 40 us of a Replica-scale frame were one 8 192-key sort AFTER the tile
     // launch had finished).  Without long lists the second launch only computes the launch order: same stream, no events.
+    const int tile_cap = wide ? BIN_SORT_TILE_WIDE : BIN_SORT_TILE_NARROW;
     const bool fork = g_bin_fork == 1 || (g_bin_fork < 0 && long_lists);
     hipStream_t side = stream;
     SideStream* ss = nullptr;
@@ -639,7 +642,7 @@ int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V,
         SR_HIP_CHECK(hipStreamWaitEvent(side, ss->fork, 0));
         // the long lists first: they are the launch sequence's longest blocks
         hipLaunchKernelGGL(bin_sort_big_kernel, dim3(BIN_BIG_BLOCKS), dim3(1024), 0, side, gtiles, tiles, gx, nchunk,
-                           wide ? BIN_SORT_TILE_WIDE : BIN_SORT_TILE_NARROW, table, g.total, keys, g.rec, b,
+                           tile_cap, table, g.total, keys, g.rec, b,
                            use_tile_order(V, tiles) ? b.tile_order : (uint32_t*)nullptr, 0);
         SR_LAUNCH_CHECK();
         SR_HIP_CHECK(hipEventRecord(ss->join, side));
@@ -655,7 +658,7 @@ int launch_bin_scatter_sort(const splatraster_settings& s, int32_t P, int32_t V,
         SR_HIP_CHECK(hipStreamWaitEvent(stream, ss->join, 0));
     } else {
         hipLaunchKernelGGL(bin_sort_big_kernel, dim3(BIN_BIG_BLOCKS), dim3(1024), 0, stream, gtiles, tiles, gx, nchunk,
-                           wide ? BIN_SORT_TILE_WIDE : BIN_SORT_TILE_NARROW, table, g.total, keys, g.rec, b,
+                           tile_cap, table, g.total, keys, g.rec, b,
                            use_tile_order(V, tiles) ? b.tile_order : (uint32_t*)nullptr, 1);
         SR_LAUNCH_CHECK();
     }

@@ -187,6 +187,8 @@ constexpr int BIN_MAX_TILES = 16384;        // tiles per view: the LDS histogram
 #endif
 constexpr int BIN_AUTO_MAX_TILES = SR_BIN_AUTO_MAX_TILES;
 constexpr int BIN_SORT_TILE_NARROW = 2048, BIN_SORT_TILE_WIDE = 4096;   // longest list of the per-tile launch's two instantiations
+// (a 1024-key instantiation — one wave, 8.7 KB of LDS — was measured at 1080p, where every list fits: tile-sort stage 0.797 -> 0.785 ms per window
+//  of five views; the stage is the payload's gathers and stores there, not residency; profiles/r06_ab_probes.txt #9)
 constexpr int BIN_WIDE_FRAMES = 64;         // frames the wide instantiation stays selected after a list beyond 2048 was seen
 void set_bin_fork(int mode);                // -1: the long-list sort launch runs on a side stream when the scene has long lists; 0 never; 1 always
 void set_bin_tile_cap(int cap);             // test / A-B hook: 2048 or 4096 forces an instantiation, anything else: follow the hint
