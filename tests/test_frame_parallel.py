@@ -219,8 +219,8 @@ def test_bench_gpus_flag_launches_ranks_or_refuses(monkeypatch):
     spec.loader.exec_module(bench)
     seen = {}
 
-    def fake_run(cmd, env=None, cwd=None):
-        seen["cmd"], seen["env"] = cmd, env
+    def fake_run(cmd, env=None, cwd=None, stdout=None):
+        seen["cmd"], seen["env"], seen["stdout"] = cmd, env, stdout
         return types.SimpleNamespace(returncode=0)
 
     import types
@@ -231,6 +231,7 @@ def test_bench_gpus_flag_launches_ranks_or_refuses(monkeypatch):
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["stdout"] is sys.stdout      # the ranks write their JSON line to the launcher's REAL stdout (main() points fd 1 at stderr)
     monkeypatch.setenv("SPLATLOC_DIST_BACKEND", "nccl")
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     seen.clear()
