@@ -265,6 +265,62 @@ def test_split_backward_matches_unsplit(C, aux):
     assert_grad_close("dL_dcolors vs oracle", b.np(b.colors.grad), bo["dL_dcolors"])
 
 
+def _clustered(P, W, H, C, seed, clusters):
+    """a scene whose first Gaussians are moved onto a few pixels (distinct depths): tile lists of chosen lengths"""
+    sc = make_scene(P, W, H, C, seed=seed, scale_median=0.02)
+    g = torch.Generator().manual_seed(seed + 1)
+    cam = sc.camera
+    fx, fy = cam.image_width / (2.0 * cam.tanfovx), cam.image_height / (2.0 * cam.tanfovy)
+    at = 0
+    for n, (px, py) in clusters:
+        z = 1.0 + 4.0 * torch.rand(n, generator=g)
+        sc.means3D[at:at + n, 0] = (px - (W - 1) / 2.0) / fx * z
+        sc.means3D[at:at + n, 1] = (py - (H - 1) / 2.0) / fy * z
+        sc.means3D[at:at + n, 2] = z
+        sc.scales[at:at + n] = 0.004
+        sc.opacities[at:at + n] = 0.02 + 0.05 * torch.rand(n, 1, generator=g)      # translucent: the whole list contributes
+        at += n
+    return sc
+
+
+@pytest.mark.parametrize("front_end", [0, 1])
+@pytest.mark.parametrize("C,aux", [(4, True), (3, False)])
+def test_split_backward_with_8_and_16_parts_matches_unsplit(C, aux, front_end):
+    """Round 6: the longest lists of a split launch get 8 parts (from 1 024 entries) or 16 (from 2 048), walked by extra workgroups
+    at the head of the backward's grid; the part count is written with the launch order and read by the forward (segment records)
+    and the backward.  Lists of ~700, ~1 500, ~2 600 and ~5 000 entries in one frame (4 / 8 / 16 / 16 parts), both front ends:
+    bit-identical images, gradients per row equal to the one-wave-per-quadrant backward's, and the oracle's."""
+    from splatloc_amd import _native
+    lib = _native.load()
+    sc = _clustered(30_000, 256, 192, C, seed=300 + C, clusters=[(5_000, (40.3, 30.2)), (2_500, (120.7, 100.1)), (1_400, (200.2, 50.6)),
+                                                                   (600, (90.5, 150.4))])
+    names = ["means3D", "means2D", "opacities", "colors", "scales", "rotations"]
+    _native.set_front_end(front_end)
+    try:
+        lib.splatraster_debug_set_split_max_waves(0)
+        a = HipRun(sc, use_depth=aux, use_alpha=aux)
+        lib.splatraster_debug_set_split_max_waves(-1)
+        b = HipRun(sc, use_depth=aux, use_alpha=aux)
+    finally:
+        lib.splatraster_debug_set_split_max_waves(-1)
+        _native.set_front_end(-1)
+    lens = (a.state["ranges"][:, 1] - a.state["ranges"][:, 0]).long()
+    assert int((lens >= 2048).sum()) >= 2 and int(((lens >= 1024) & (lens < 2048)).sum()) >= 1 and int(lens.max()) >= 4096
+    assert torch.equal(a.color, b.color) and torch.equal(a.depth, b.depth) and torch.equal(a.alpha, b.alpha)
+    assert torch.equal(a.state["n_contrib"], b.state["n_contrib"])
+    # the clusters' pixels really are deep: some pixel has more than 2 048 contributors
+    assert int(a.state["n_contrib"].max()) > 2048
+    for n in names:
+        ga, gb = getattr(a, n).grad.cpu().numpy(), getattr(b, n).grad.cpu().numpy()
+        assert_grad_close(n, gb, ga, rtol=1e-4, atol_scale=2e-5)
+        assert_grad_rows_close("rows " + n, gb, ga, rtol=1e-4, row_atol=1e-3, allow_frac=1e-3, outlier_factor=100.0)
+    f = oracle_forward(sc)
+    bo = oracle_backward(f, sc, use_depth=aux, use_alpha=aux)
+    assert_grad_close("dL_dmeans3D vs oracle", b.np(b.means3D.grad), bo["dL_dmeans3D"])
+    assert_grad_close("dL_dcolors vs oracle", b.np(b.colors.grad), bo["dL_dcolors"])
+    assert_grad_close("dL_dopacities vs oracle", b.np(b.opacities.grad), bo["dL_dopacities"])
+
+
 @pytest.mark.parametrize("C,W,H,P,scale", [(4, 256, 256, 40_000, 0.05), (3, 250, 130, 6_000, 0.12), (1, 64, 48, 3_000, 0.3), (2, 16, 16, 700, 0.25)])
 def test_team_forward_changes_nothing(C, W, H, P, scale):
     """Narrow layouts on a frame that does not fill the machine run the forward with a TEAM of four waves per quadrant (two
