@@ -33,3 +33,15 @@ def test_random_sizes_keep_the_ordering_contract():
         assert bool(((d1 > d0) | ((d1 == d0) & (pl[1:] > pl[:-1])))[same].all()), it
         rng = st["ranges"].long()
         assert bool((torch.bincount(tiles, minlength=rng.shape[0]) == rng[:, 1] - rng[:, 0]).all()), it
+
+
+def test_split_backward_part_logic_on_random_clustered_frames():
+    """Short form of tools/soak_split.py: random small frames of narrow layouts with random clusters (lists of a few hundred to several
+    thousand entries: 4 / 8 / 16 parts, lengths around the thresholds), all three front-end modes: the split backward against the
+    one-wave-per-quadrant backward — images bit-identical, gradients within the per-row bars."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_split.py"), "15", "3"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "soak_split ok" in r.stdout, (r.stdout[-800:], r.stderr[-2000:])
