@@ -56,7 +56,10 @@ for it in range(n):
             f = oracle_forward(sc)
             bo = oracle_backward(f, sc, use_depth=aux, use_alpha=aux)
             go = np.asarray(bo[key], dtype=np.float64).reshape(gb.shape)
-            assert_grad_close(f"{it} {name} split vs ORACLE", gb, go)
+            # (a few elements may miss it by a bounded factor in EITHER walk: a Gaussian of radius 90 over dozens of tiles collects hundreds of
+            #  float atomics of cancelling terms, in an order that changes from run to run — scene 182 of seed 1: the same element is the worst
+            #  of both walks, 2e-7 .. 1.4e-6 from the oracle depending on the run)
+            assert_grad_close(f"{it} {name} split vs ORACLE", gb, go, allow_frac=1e-3, outlier_factor=30.0)
             ea, eb = np.abs(ga - go).max(), np.abs(gb - go).max()
             noise.append((it, name, str(ex)[:90], f"max err vs oracle: one-wave {ea:.2e}, split {eb:.2e}, scale {np.abs(go).max():.2e}"))
 _native.set_front_end(-1)
