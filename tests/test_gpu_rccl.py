@@ -24,9 +24,11 @@ def _child_env():
     return env
 
 
-def _one_json_line(r):
+def _one_json_line(r, only_line=False):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    if only_line:   # bench.py: stdout carries the JSON line and NOTHING else (RCCL / gloo banners go to stderr)
+        assert r.stdout.strip().splitlines() == lines, r.stdout[:600]
     return json.loads(lines[0])
 
 
@@ -52,7 +54,8 @@ def test_bench_force_process_group_runs_the_step_through_rccl(reduce):
     device_id=)`, the span SUM in place in the backward's allocation, the MAX, the barrier + MAX-over-ranks timing."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-process-group", "--steps", "3", "--warmup", "1",
            "--workload", "S0", "--no-cpu-baseline", "--no-multi-stream", "--repeats", "2", "--reduce", reduce]
-    out = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=_child_env(), capture_output=True, text=True, timeout=600))
+    env = dict(_child_env(), NCCL_DEBUG="VERSION")      # RCCL then prints a five-line banner per process group: it must not reach stdout
+    out = _one_json_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600), only_line=True)
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["dist_backend"] == "nccl"
     assert out["reduce_path"] == "in-place span" and out["collectives_per_step"] == (3 if reduce == "rs_ag" else 2)
     assert out["dist_env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and out["dist_env"]["rccl_version"]
