@@ -591,7 +591,7 @@ int splatraster_debug_set_payload_stream_min(int64_t instances);
 int splatraster_debug_set_front_end(int mode);
 /* A/B / test hook of the binned front end: the per-tile sort launch exists for lists of up to 2048 keys (128 threads, every
  * tile of a 640x480 frame resident at once) and of up to 4096 (256 threads); by default the library follows a hint the kernel
- * raises when it meets a list beyond 2048 keys (longer lists than the chosen launch holds go to its work-list launch either
+ * raises when it meets a list beyond 2048 keys (longer lists than the chosen launch holds go to the long-list launch either
  * way).  2048 / 4096 force an instantiation, any other value restores the default.  Results never depend on it. */
 int splatraster_debug_set_tile_sort_cap(int keys);
 /* Measurement hook.  The binned front end's two sort launches (lists up to the tile launch's cap | longer lists, which that launch

@@ -26,8 +26,8 @@
 //                          32 keys per lane 73 us; this form 39 us, of which ~20 us are the 92 MB of payload traffic.)
 // (depth bits, row) is unique inside a tile, so the sorted list is THE (tile, depth, index) order of the lineage's stable
 // 64-bit sort — bit-identical point lists and ranges to the radix front end (tests/test_gpu_binsort.py runs both).
-// Lists beyond the first launch's capacity go to a work list served by a second launch (1024 threads, the same LDS network on
-// up to 16 384 keys in 139 KB of LDS; beyond 16 384 keys a normalised network runs on the global buffer: slow, correct).
+// Lists beyond the first launch's capacity are sorted by a second launch that finds them in the scanned table itself (1024 threads, the
+// same LDS network on up to 16 384 keys in 139 KB of LDS; beyond 16 384 keys a normalised network runs on the global buffer: slow, correct).
 //
 // Compiled with -ffp-contract=off like preprocess.hip / binning.hip: the rect arithmetic must round like preprocess's.
 #include <mutex>
@@ -187,7 +187,7 @@ __device__ __forceinline__ void write_tile(RowAt row_at, uint32_t n, uint32_t st
 }
 
 // loads the list (blocked), sorts it in registers and leaves the rows in LDS at pad32(list position)
-// Normalised bitonic network on n keys in GLOBAL memory (lists beyond the 16 384 keys the work-list launch holds in
+// Normalised bitonic network on n keys in GLOBAL memory (lists beyond the 16 384 keys the long-list launch holds in
 // registers): merge size k = 2, 4, ...; the first step of a merge pairs i with its MIRROR inside the k-block, the following
 // steps pair i with i + j, j = k/4 ... 1.  Every compare-exchange is ascending (minimum to the lower index), so elements
 // beyond n behave as +infinity without being stored: a pair whose upper index is >= n is skipped.  One block, a workgroup
@@ -431,7 +431,7 @@ bin_sort_tile_kernel(int gtiles, int tiles, int gx, int nchunk, const uint32_t* 
     SR_STAMP(5);
 }
 
-// Second sort launch: 1024-thread blocks stride over the work list; up to BIN_SORT_BIG keys with the SAME LDS network as the tile
+// Second sort launch: list i is block i % gridDim.x's if it is longer than the tile launch's cap; up to BIN_SORT_BIG keys with the SAME LDS network as the tile
 // kernel (139 KB of the CU's 160 KB: one block per CU), the global network beyond.  (Round 5 first held these lists in the
 // registers of the block — 8 or 16 keys per thread, 64-bit integer compares, every distance beyond a wave exchanged through LDS
 // four registers at a time: ~70 us per list, 87 us of a refinement iteration at Replica scale where 15 - 40 lists of a frame

@@ -98,7 +98,7 @@ struct GeomView {
     uint8_t* clamped;        // [3P]
     uint32_t* sort_keys;     // [n] scratch (depth bits)
     uint32_t* sort_tmp;      // scratch for the n-sized sort + scan partials
-    uint32_t* total;         // [4] device-side R (uint64 as two words), written by the scan; [2]: entries of the binned front end's work list
+    uint32_t* total;         // [4] device-side R (uint64 as two words), written by the scan
     uint32_t* block_tiles;   // [V * preprocess_blocks(P)] per-(view, block) sums of tiles_touched, written by preprocess
     uint32_t* span_owner;    // [SPAN_OWNER_CAP] depth rank owning instance k * EMIT_SPAN, written by the one-pass scan
 };
