@@ -1085,6 +1085,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        from splatloc_amd import frame_parallel as _fp2
+        _fp2.prepare()          # the length check's gloo twin group: created here, not inside the first step
 
     from splatloc_amd import training as _training
     _training.REDUCE_MODE = args.reduce

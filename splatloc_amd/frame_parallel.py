@@ -181,6 +181,13 @@ def _header_group(group):
     return g
 
 
+def prepare(group=None) -> None:
+    """Create the length check's gloo twin of `group` now (a collective: every rank of `group` must call it) instead of inside the
+    first reduce_step / broadcast_model — e.g. right after init_process_group, outside any timed region."""
+    if dist.is_available() and dist.is_initialized():
+        _header_group(group)
+
+
 def _check_same_layout(numel, device, group) -> None:
     """A SUM over buffers of different lengths is undefined behaviour in RCCL (and silently wrong sums when the
     lengths agree but the piece order does not).  EVERY call verifies, with one fixed-size 32-byte MAX collective
