@@ -36,7 +36,7 @@ extern "C" {
 /* bumped on every change of a signature or buffer layout; the Python binding refuses a library
  * whose splatraster_abi_version() differs (a stale in-tree .so would otherwise be called through
  * ctypes with mismatched arguments) */
-#define SPLATRASTER_ABI_VERSION 12
+#define SPLATRASTER_ABI_VERSION 13
 
 #define SPLATRASTER_TILE 16 /* tile edge in pixels (16x16 = 256 pixels = 4 wave64) */
 
@@ -236,6 +236,32 @@ int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, 
                                 float* dL_drotations, /* [P,4] or NULL */
                                 float* dL_dcov3D,     /* [P,6] or NULL */
                                 void* stream);
+
+/* The same backward, writing the gradients of SplatLoc's RAW parameters directly (SH degree 0, scales + rotations; what
+ * gaussian_model.py:78-105 and gaussian_renderer/__init__.py:84-102 put between the optimiser tensors and the rasterizer call):
+ *   scales = exp(scaling), rotations = normalize(rotation), opacities = sigmoid(opacity),
+ *   colors_precomp = [clamp_min(C0 f_dc + 0.5, 0) | extra]                                       (C = 3 + extra_channels)
+ * The chain through these activations and the sum of the accumulator rows' colour columns run inside the per-Gaussian
+ * backward kernel: no dL/dcolors / dL/dopacities / dL/dscales / dL/drotations tensors, no second pass over them.  `scales`,
+ * `rotations`, `colors_precomp` are the ACTIVATED tensors the forward was given; results are bit-identical to
+ * splatraster_backward_window followed by splatraster_activate_backward. */
+typedef struct splatraster_raw_params {
+    const float* scaling;  /* [P,3] */
+    const float* rotation; /* [P,4] */
+    const float* opacity;  /* [P]   logits */
+    const float* f_dc;     /* [P,3] */
+    int32_t extra_channels;
+    float* dL_dscaling;    /* [P,3] */
+    float* dL_drotation;   /* [P,4] */
+    float* dL_dopacity;    /* [P]   */
+    float* dL_df_dc;       /* [P,3] */
+    float* dL_dextra;      /* [P,extra_channels] or NULL */
+} splatraster_raw_params;
+int splatraster_backward_window_raw(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
+                                    int32_t P, const int64_t* num_rendered, const float* bg, const float* means3D,
+                                    const float* colors_precomp, const float* scales, const float* rotations, void* geometry,
+                                    const void* binning, const void* image, const splatraster_raw_params* raw,
+                                    float* dL_dmeans3D /* [P,3] */, void* stream);
 
 /* ---- auxiliary entry points ---------------------------------------------------------- */
 

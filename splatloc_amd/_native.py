@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 12   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
+ABI_VERSION = 13   # == SPLATRASTER_ABI_VERSION of include/splatraster.h
 
 OK = 0
 WARN_LOOKBACK_STALL = 5   # splatraster_poll_errors() only; not an error of any frame
@@ -52,6 +52,13 @@ class LossView(C.Structure):
     """struct splatraster_loss_view"""
     _fields_ = [(n, C.c_void_p) for n in ("image", "depth", "marker", "gt_image", "gt_depth", "kp", "exposure", "g_image", "g_depth",
                                           "g_marker")]
+
+
+class RawParams(C.Structure):
+    """struct splatraster_raw_params"""
+    _fields_ = [("scaling", C.c_void_p), ("rotation", C.c_void_p), ("opacity", C.c_void_p), ("f_dc", C.c_void_p),
+                ("extra_channels", C.c_int32), ("dL_dscaling", C.c_void_p), ("dL_drotation", C.c_void_p), ("dL_dopacity", C.c_void_p),
+                ("dL_df_dc", C.c_void_p), ("dL_dextra", C.c_void_p)]
 
 
 class GeometryLayout(C.Structure):
@@ -100,6 +107,8 @@ SYMBOLS = {
                                           + [_vp] * 6),
     "splatraster_backward_window": (C.c_int, [C.POINTER(Settings), _i32, C.POINTER(WindowView), _i32, C.POINTER(_i64)]
                                     + [_vp] * 16),
+    "splatraster_backward_window_raw": (C.c_int, [C.POINTER(Settings), _i32, C.POINTER(WindowView), _i32, C.POINTER(_i64)]
+                                        + [_vp] * 8 + [C.POINTER(RawParams)] + [_vp] * 2),
     "splatraster_get_window_geometry_layout": (C.c_int, [_i32, _i32, C.POINTER(GeometryLayout)]),
     "splatraster_get_window_binning_layout": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _i32, C.POINTER(BinningLayout)]),
     "splatraster_get_window_image_layout": (C.c_int, [_i32, _i32, _i32, C.POINTER(ImageLayout)]),

@@ -9,7 +9,7 @@
 // HBM-bound: every array is streamed once (reads 44 + 12 K + 4 E bytes per Gaussian, writes
 // 44 + 4 E forward; about twice that backward).  Accurate expf / sqrtf / division (no fast-math
 // intrinsics): the outputs track torch's to the last ulp or two.
-#include "common.h"
+#include "activation_math.h"
 
 namespace sr {
 
@@ -96,7 +96,7 @@ __device__ __forceinline__ float sh_channel(int i, int c, int K, int deg, const 
 {
     if (deg == 0) {
         B[0] = A_C0;
-        return A_C0 * f_dc[3 * (size_t)i + c] + 0.5f;
+        return act_rgb_raw_deg0(f_dc[3 * (size_t)i + c]);
     }
     const float vx = xyz[3 * (size_t)i] - campos[0], vy = xyz[3 * (size_t)i + 1] - campos[1],
                 vz = xyz[3 * (size_t)i + 2] - campos[2];
@@ -153,10 +153,10 @@ activate_fwd_kernel(int P, int K, int deg, int SC, int E, const float* __restric
     // rotations = q / max(||q||, 1e-12)
     {
         const float4 q = reinterpret_cast<const float4*>(rotation)[i];
-        const float n = fmaxf(sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w), 1e-12f);
+        const float n = act_quat_norm(q);
         reinterpret_cast<float4*>(rotations)[i] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
     }
-    opacities[i] = 1.0f / (1.0f + expf(-opacity[i]));
+    opacities[i] = act_sigmoid(opacity[i]);
 }
 
 __global__ void __launch_bounds__(256)
@@ -218,16 +218,11 @@ activate_bwd_kernel(int P, int K, int deg, int SC, int E, const float* __restric
     {
         const float4 q = reinterpret_cast<const float4*>(rotation)[i];
         const float4 g = reinterpret_cast<const float4*>(g_rotations)[i];
-        const float n = fmaxf(sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w), 1e-12f);
-        const float ux = q.x / n, uy = q.y / n, uz = q.z / n, uw = q.w / n;
-        const float ug = ((ux * g.x + uy * g.y) + uz * g.z) + uw * g.w;
-        reinterpret_cast<float4*>(d_rotation)[i] =
-            make_float4((g.x - ux * ug) / n, (g.y - uy * ug) / n, (g.z - uz * ug) / n, (g.w - uw * ug) / n);
+        reinterpret_cast<float4*>(d_rotation)[i] = act_normalize_bwd(q, g);
     }
     // d sigmoid
     {
-        const float s = 1.0f / (1.0f + expf(-opacity[i]));
-        d_opacity[i] = g_opacities[i] * s * (1.0f - s);
+        d_opacity[i] = act_sigmoid_bwd(g_opacities[i], opacity[i]);
     }
     // view-direction term of the SH colour (degree > 0 only)
     if (d_xyz) {

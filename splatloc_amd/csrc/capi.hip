@@ -583,26 +583,30 @@ static int window_backward(const splatraster_settings* s, int32_t V, const splat
                            const void* binning, const void* image, float* dL_dmeans3D, float* dL_dcolors,
                            float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                            float* dL_dshs, float* dL_dviewmatrix, float* dL_dprojmatrix, float* dL_dcampos,
-                           hipStream_t stream)
+                           hipStream_t stream, const RawBwd* raw = nullptr)
 {
     int st = check_window(s, V, views);
     if (st) return st;
     if (P < 0 || R < 0) return SPLATRASTER_ERR_BAD_ARG;
     if (V > 1 && (shs || dL_dviewmatrix || dL_dprojmatrix || dL_dcampos)) return SPLATRASTER_ERR_UNSUPPORTED;
+    if (raw && (shs || cov3D_precomp || dL_dviewmatrix || dL_dprojmatrix || dL_dcampos)) return SPLATRASTER_ERR_UNSUPPORTED;
     if (P == 0) {   // nothing to differentiate: the camera gradients are still defined (zero)
         if (dL_dviewmatrix) SR_HIP_CHECK(hipMemsetAsync(dL_dviewmatrix, 0, 16 * sizeof(float), stream));
         if (dL_dprojmatrix) SR_HIP_CHECK(hipMemsetAsync(dL_dprojmatrix, 0, 16 * sizeof(float), stream));
         if (dL_dcampos) SR_HIP_CHECK(hipMemsetAsync(dL_dcampos, 0, 3 * sizeof(float), stream));
         return SPLATRASTER_OK;
     }
-    if (!means3D || !geometry || !binning || !image || !dL_dmeans3D || !dL_dopacities) return SPLATRASTER_ERR_BAD_ARG;
+    if (!means3D || !geometry || !binning || !image || !dL_dmeans3D || (!dL_dopacities && !raw)) return SPLATRASTER_ERR_BAD_ARG;
+    if (raw && (P > 0) && (!raw->scaling || !raw->rotation || !raw->opacity || !raw->f_dc || !raw->d_scaling || !raw->d_rotation ||
+                           !raw->d_opacity || !raw->d_f_dc || raw->E != s->channels - 3 || (raw->E > 0 && !raw->d_extra)))
+        return SPLATRASTER_ERR_BAD_ARG;
     for (int v = 0; v < V; ++v)
         if (!views[v].viewmatrix || !views[v].projmatrix || !views[v].radii || !views[v].out_color || !views[v].out_depth ||
             !views[v].dL_dout_color || !views[v].dL_dmeans2D)
             return SPLATRASTER_ERR_BAD_ARG;
     if (shs && (!dL_dshs || !views[0].campos)) return SPLATRASTER_ERR_BAD_ARG;
-    if (!shs && (!colors_precomp || !dL_dcolors)) return SPLATRASTER_ERR_BAD_ARG;
-    if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || !dL_dscales || !dL_drotations))
+    if (!shs && (!colors_precomp || (!dL_dcolors && !raw))) return SPLATRASTER_ERR_BAD_ARG;
+    if (cov3D_precomp ? !dL_dcov3D : (!scales || !rotations || ((!dL_dscales || !dL_drotations) && !raw)))
         return SPLATRASTER_ERR_BAD_ARG;
     st = check_row_index_range(P, V, s->channels);
     if (st) return st;
@@ -666,7 +670,7 @@ static int window_backward(const splatraster_settings* s, int32_t V, const splat
                                  b.gacc, C, shs ? nullptr : dL_dcolors, dL_dmeans3D, dL_dopacities,
                                  cov3D_precomp ? nullptr : dL_dscales, cov3D_precomp ? nullptr : dL_drotations,
                                  cov3D_precomp ? dL_dcov3D : nullptr, dL_dshs, dL_dviewmatrix, dL_dprojmatrix, dL_dcampos,
-                                 b.pose_acc, stream);
+                                 b.pose_acc, stream, raw);
 }
 
 }  // namespace sr
@@ -763,6 +767,25 @@ int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, 
     return window_backward(s, n_views, views, P, R, bg, means3D, nullptr, colors_precomp, scales, rotations, cov3D_precomp,
                            geometry, binning, image, dL_dmeans3D, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations,
                            dL_dcov3D, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int splatraster_backward_window_raw(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
+                                    int32_t P, const int64_t* num_rendered, const float* bg, const float* means3D,
+                                    const float* colors_precomp, const float* scales, const float* rotations, void* geometry,
+                                    const void* binning, const void* image, const splatraster_raw_params* rp, float* dL_dmeans3D,
+                                    void* stream)
+{
+    if (!num_rendered || n_views < 1 || n_views > MAX_VIEWS || !rp) return SPLATRASTER_ERR_BAD_ARG;
+    int64_t R = 0;
+    for (int v = 0; v < n_views; ++v) {
+        if (num_rendered[v] < 0) return SPLATRASTER_ERR_BAD_ARG;
+        R += num_rendered[v];
+    }
+    const RawBwd raw{rp->scaling, rp->rotation, rp->opacity, rp->f_dc, rp->extra_channels, rp->dL_dscaling, rp->dL_drotation,
+                     rp->dL_dopacity, rp->dL_df_dc, rp->dL_dextra};
+    return window_backward(s, n_views, views, P, R, bg, means3D, nullptr, colors_precomp, scales, rotations, nullptr,
+                           geometry, binning, image, dL_dmeans3D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, reinterpret_cast<hipStream_t>(stream), &raw);
 }
 
 int splatraster_debug_set_small_panel_max_waves(int waves)

@@ -135,6 +135,21 @@ int launch_preprocess(const splatraster_settings& s, int32_t P, int32_t V, const
                       hipStream_t stream, bool depth_keys = true /*false: no depth-sort input (binned front end)*/);
 // sums the gradient contributions of the V views of a window into ONE set of parameter gradients (written once,
 // in view order: deterministic given the accumulator rows); dL/dmeans2D is per view
+// RAW-parameter mode of the preprocess backward (SplatLoc's own configuration: SH degree 0, scales + rotations): the chain through the
+// parameter activations and the sum of the accumulator rows' colour columns happen in the same kernel — no gather_dcolors launch, no
+// activation-backward launch, no activated-gradient tensors (splatraster_backward_window_raw)
+struct RawBwd {
+    const float* scaling;    // [P,3] log-scales
+    const float* rotation;   // [P,4] raw quaternions
+    const float* opacity;    // [P]   logits
+    const float* f_dc;       // [P,3] SH dc coefficients
+    int E;                   // feature columns behind the three colours (C = 3 + E)
+    float* d_scaling;        // [P,3]
+    float* d_rotation;       // [P,4]
+    float* d_opacity;        // [P]
+    float* d_f_dc;           // [P,3]
+    float* d_extra;          // [P,E] (null when E == 0)
+};
 int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const WinGrad& grads,
                           const float* means3D, const float* shs /*V == 1 only*/,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
@@ -143,7 +158,8 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, c
                           float* dL_dmeans3D, float* dL_dopacities, float* dL_dscales,
                           float* dL_drotations, float* dL_dcov3D, float* dL_dshs,
                           float* dL_dview /*[16] or null; V == 1 only*/, float* dL_dproj, float* dL_dcampos,
-                          float* pose_acc /*BinView::pose_acc, zeroed by the caller; needed with dL_dview*/, hipStream_t stream);
+                          float* pose_acc /*BinView::pose_acc, zeroed by the caller; needed with dL_dview*/, hipStream_t stream,
+                          const RawBwd* raw = nullptr);
 int launch_mark_visible(int32_t P, const float* means3D, const float* view, uint8_t* present,
                         hipStream_t stream);
 

@@ -10,6 +10,7 @@
 // inputs; writes every gradient tensor once.
 // HBM-bound: ~100 B read, ~70 B written per Gaussian.
 #include "composite_common.h"
+#include "activation_math.h"
 
 namespace sr {
 
@@ -86,7 +87,7 @@ __device__ void sh_backward(int deg, int M, const float* sh, float* dsh, const u
 // row g = v * P + i, forward record rec[g], the view's camera) are summed in view order into ONE set of parameter
 // gradients, written once — no per-view gradient tensors, no accumulation kernels, a deterministic sum.
 // dL/dmeans2D stays per view (GaussianModel.add_densification_stats reads it per view).
-template <bool POSE>
+template <bool POSE, bool RAW = false>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int M, WinCams cams, WinGrad grads,
                       const float* __restrict__ means3D, const float* __restrict__ shs,
@@ -98,7 +99,8 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
                       float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
                       float* __restrict__ dL_drotations, float* __restrict__ dL_dcov3D,
                       float* __restrict__ dL_dshs, float* __restrict__ dL_dview, float* __restrict__ dL_dproj,
-                      float* __restrict__ dL_dcampos, float* __restrict__ pose_acc /*POSE: zeroed sets + ticket (common.h)*/)
+                      float* __restrict__ dL_dcampos, float* __restrict__ pose_acc /*POSE: zeroed sets + ticket (common.h)*/,
+                      RawBwd raw /*RAW: the raw parameters and their gradient outputs (common.h)*/)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // pose partials of this Gaussian: dV[4c + r] (r < 3), dPM[4c + k] (k = 0, 1, 3), dcampos   (V == 1 only)
@@ -375,6 +377,28 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
     if (i < P) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = dmean[k];
+    if constexpr (RAW) {
+        // the chain through the activations, with activations.hip's own arithmetic (activation_math.h): bit-identical to
+        // gather_dcolors_kernel + activate_bwd_kernel behind the plain kernel
+#pragma unroll
+        for (int k = 0; k < 3; ++k) raw.d_scaling[3 * i + k] = dscale[k] * expf(raw.scaling[3 * (size_t)i + k]);
+        reinterpret_cast<float4*>(raw.d_rotation)[i] =
+            act_normalize_bwd(reinterpret_cast<const float4*>(raw.rotation)[i], make_float4(drot[0], drot[1], drot[2], drot[3]));
+        raw.d_opacity[i] = act_sigmoid_bwd(dop, raw.opacity[i]);
+        // dL/dcolours = the rows' colour columns summed in view order (gather_dcolors_kernel), then d cat / d clamp_min / d eval_sh (degree 0)
+        const int CW = 3 + raw.E;
+        for (int c = 0; c < CW; ++c) {
+            float sum = gacc[(size_t)i * GROW + c];
+            for (int v = 1; v < V; ++v) sum += gacc[((size_t)v * P + i) * GROW + c];
+            if (c < 3) {
+                const float g = act_rgb_raw_deg0(raw.f_dc[3 * (size_t)i + c]) >= 0.0f ? sum : 0.0f;
+                raw.d_f_dc[3 * (size_t)i + c] = ACT_SH_C0 * g;
+            } else {
+                raw.d_extra[(size_t)i * raw.E + (c - 3)] = sum;
+            }
+        }
+        return;
+    }
     dL_dopacities[i] = dop;
     if (dL_dscales) {
 #pragma unroll
@@ -435,10 +459,10 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, c
                           const float* cov3D_precomp, const uint8_t* clamped, const float4* rec, const float* gacc, int C,
                           float* dL_dcolors, float* dL_dmeans3D, float* dL_dopacities, float* dL_dscales,
                           float* dL_drotations, float* dL_dcov3D, float* dL_dshs, float* dL_dview,
-                          float* dL_dproj, float* dL_dcampos, float* pose_acc, hipStream_t stream)
+                          float* dL_dproj, float* dL_dcampos, float* pose_acc, hipStream_t stream, const RawBwd* raw)
 {
     if (P == 0) return SPLATRASTER_OK;
-    if (dL_dcolors) {
+    if (dL_dcolors && !raw) {
         const int64_t n = (int64_t)P * C;
         hipLaunchKernelGGL(gather_dcolors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, C,
                            gacc_row_floats(C), V, (int64_t)P, gacc, dL_dcolors);
@@ -450,8 +474,11 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, c
     P, V, s.image_width, s.image_height, s.scale_modifier, s.sh_degree, s.sh_coeffs, cams, grads, means3D,         \
         shs, scales, rotations, cov3D_precomp, clamped, rec, gacc, C, gacc_row_floats(C),                          \
         gacc_moment_offset(C), dL_dmeans3D, dL_dopacities, dL_dscales, dL_drotations,                              \
-        dL_dcov3D, dL_dshs, dL_dview, dL_dproj, dL_dcampos, pose_acc
-    if (pose)
+        dL_dcov3D, dL_dshs, dL_dview, dL_dproj, dL_dcampos, pose_acc, (raw ? *raw : RawBwd{})
+    if (raw) {
+        if (pose || shs || cov3D_precomp || !scales || !rotations) return SPLATRASTER_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((preprocess_bwd_kernel<false, true>), dim3((P + 255) / 256), dim3(256), 0, stream, SR_PBWD_ARGS);
+    } else if (pose)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, SR_PBWD_ARGS);
     else
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, stream, SR_PBWD_ARGS);

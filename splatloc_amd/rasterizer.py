@@ -462,6 +462,29 @@ class _RasterizeWindow(torch.autograd.Function):
             w.dL_dout_last = None if g_last is None else g_last.data_ptr()
             w.color_grad_channels = ctx.head if split else 0
         R = (C.c_int64 * V)(*ctx.R)
+        raw = getattr(ctx, "raw", None)
+        if raw is not None:
+            # RAW-parameter mode (training's graph-free paths: SplatLoc's own configuration): the chain through the activations and
+            # the colour gather run inside the per-Gaussian backward kernel (splatraster_backward_window_raw) — no dL/dcolors /
+            # dL/dopacities / dL/dscales / dL/drotations tensors, no activation-backward launch.  ctx.raw = (scaling [P,3],
+            # rotation [P,4], opacity [P,1], f_dc [P,1,3], extra [P,E] or None); the gradients are left in ctx.raw_out.
+            sc_r, ro_r, op_r, fd_r, ex_r = raw
+            E = 0 if ex_r is None else int(ex_r.shape[1])
+            d_sc, d_ro, d_opr = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
+            d_fd = torch.empty(tuple(fd_r.shape), **f32)
+            d_ex = torch.empty((P, E), **f32) if E else None
+            rp = _native.RawParams()
+            rp.scaling, rp.rotation, rp.opacity, rp.f_dc = sc_r.data_ptr(), ro_r.data_ptr(), op_r.data_ptr(), fd_r.data_ptr()
+            rp.extra_channels = E
+            rp.dL_dscaling, rp.dL_drotation, rp.dL_dopacity, rp.dL_df_dc = d_sc.data_ptr(), d_ro.data_ptr(), d_opr.data_ptr(), d_fd.data_ptr()
+            rp.dL_dextra = d_ex.data_ptr() if d_ex is not None else None
+            with _on_device(dev):
+                _native.check(lib.splatraster_backward_window_raw(
+                    C.byref(st), V, views, P, R, _ptr(bg), _ptr(m3), _ptr(col), _ptr(sca), _ptr(rot), _ptr(geom), _ptr(binning),
+                    _ptr(img), C.byref(rp), _ptr(d_m3), _stream(dev)), "backward_window_raw")
+            del keep
+            ctx.raw_out = (d_sc, d_ro, d_opr, d_fd, d_ex)
+            return (d_m3, None, None, None, None, None, None, None, None) + tuple(d_m2[v] for v in range(V))
         with _on_device(dev):
             _native.check(lib.splatraster_backward_window(
                 C.byref(st), V, views, P, R, _ptr(bg), _ptr(m3), _ptr(col), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(geom),

@@ -52,6 +52,21 @@ def _direct_refine_ok(gaussians, pipe) -> bool:
                                                              "_scaling", "_rotation"))
 
 
+RAW_BACKWARD = os.environ.get("SPLATLOC_RAW_BACKWARD", "1") != "0"     # (A/B and tests: 0 = the two-kernel chain)
+
+
+def _raw_backward_ok(gaussians) -> bool:
+    """The raw-parameter backward covers SplatLoc's own layout: contiguous fp32 [P,3] log-scales, [P,4] quaternions, [P,1] logits,
+    [P,1,3] SH dc, no higher SH coefficients, a [P,E] key-point column."""
+    if not RAW_BACKWARD:
+        return False
+    g = gaussians
+    ok = lambda t, shp: (t.dtype is torch.float32 and t.is_contiguous() and tuple(t.shape[1:]) == shp and not (t.data_ptr() & 15))  # noqa: E731
+    return (ok(g._scaling, (3,)) and ok(g._rotation, (4,)) and ok(g._opacity, (1,)) and ok(g._features_dc, (1, 3))
+            and int(g._features_rest.shape[1]) == 0 and g._kp_score.dim() == 2 and ok(g._kp_score, (int(g._kp_score.shape[1]),))
+            and int(g._kp_score.shape[1]) >= 1)
+
+
 def _color_refinement_step_direct(viewpoint_cam, gaussians, background, lambda_dssim, iteration, primitive_reg):
     """The iteration of `color_refinement_step` with the SAME forward / backward code (`_ActivatePack`, `_RasterizeWindow`:
     their static forward / backward called directly with a plain context) but without building an autograd graph: the
@@ -75,9 +90,19 @@ def _color_refinement_step_direct(viewpoint_cam, gaussians, background, lambda_d
         if gt_image.device != rgb.device:
             gt_image = gt_image.to(rgb.device)
         loss, g_image = refinement_loss_and_grad(rgb, gt_image, lambda_dssim)
-        d = _RasterizeWindow.backward(c_ras, g_image, None, None, None, None)
-        d_m3, d_col, d_op, d_sca, d_rot = d[0], d[1], d[2], d[3], d[4]
-        _dx, d_fd, d_fr, d_sc, d_ro, d_opa, d_ex, _, _ = _ActivatePack.backward(c_act, d_sca, d_rot, d_op, d_col)
+        if _raw_backward_ok(gaussians):
+            # the rasterizer's backward writes the RAW parameters' gradients itself (rasterizer.py: ctx.raw): two launches and the
+            # activated-gradient tensors less per iteration, bit-identical values (tests/test_gpu_refine.py)
+            c_ras.raw = (gaussians._scaling.detach(), gaussians._rotation.detach(), gaussians._opacity.detach(),
+                         gaussians._features_dc.detach(), gaussians._kp_score.detach())
+            d = _RasterizeWindow.backward(c_ras, g_image, None, None, None, None)
+            d_m3 = d[0]
+            d_sc, d_ro, d_opa, d_fd, d_ex = c_ras.raw_out
+            d_fr = torch.empty_like(gaussians._features_rest)
+        else:
+            d = _RasterizeWindow.backward(c_ras, g_image, None, None, None, None)
+            d_m3, d_col, d_op, d_sca, d_rot = d[0], d[1], d[2], d[3], d[4]
+            _dx, d_fd, d_fr, d_sc, d_ro, d_opa, d_ex, _, _ = _ActivatePack.backward(c_act, d_sca, d_rot, d_op, d_col)
         for p, g in ((gaussians._xyz, d_m3), (gaussians._features_dc, d_fd), (gaussians._features_rest, d_fr),
                      (gaussians._scaling, d_sc), (gaussians._rotation, d_ro), (gaussians._opacity, d_opa), (gaussians._kp_score, d_ex)):
             if g is not None:

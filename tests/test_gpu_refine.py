@@ -168,3 +168,53 @@ def test_map_step_function_matches_reference_iterations(golden_dir, adam):
         assert np.array_equal(gm.max_radii2D.cpu().numpy(), d[post + "max_radii"])
         assert np.array_equal(gm.denom.cpu().numpy(), d[post + "denom"])
         assert_grad_close(f"it{it} xyz_gradient_accum", gm.xyz_gradient_accum.cpu().numpy(), d[post + "accum"], rtol=3e-3, atol_scale=2e-4)
+
+
+@pytest.mark.parametrize("workload", ["S0", "S2-ref-layout"])
+def test_raw_parameter_backward_is_the_two_kernel_chain_bit_for_bit(workload):
+    """`color_refinement_step`'s graph-free path lets the rasterizer's backward write the RAW parameters' gradients itself
+    (splatraster_backward_window_raw: the chain through exp / normalize / sigmoid / SH degree 0 + clamp and the sum of the accumulator
+    rows' colour columns inside the per-Gaussian kernel) instead of gather_dcolors + preprocess_bwd + activate_backward.  Same
+    arithmetic from one shared header (csrc/activation_math.h): with the deterministic-sum compositing the gradients of every
+    parameter group must be IDENTICAL bit for bit, at 10k and at 500k Gaussians (full reference layout)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import map_idle
+    from splatloc_amd import _native, training
+    dev = torch.device(DEV)
+    pc, views = map_idle.build(workload, dev)
+    bg = torch.zeros(3, device=dev)
+    grads = {}
+    _native.set_deterministic(True)
+    try:
+        for raw in (False, True):
+            training.RAW_BACKWARD = raw
+            for p in (pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._kp_score, pc._scaling, pc._rotation):
+                p.grad = None
+            captured = {}
+            real_step = pc.optimizer.step
+
+            def capture():      # the gradients as they reach the optimizer
+                for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_kp_score", "_scaling", "_rotation"):
+                    g = getattr(pc, k).grad
+                    captured[k] = None if g is None else g.detach().clone()
+            pc.optimizer.step = capture
+            try:
+                training._color_refinement_step_direct(views[1], pc, bg, 0.2, 7, True)
+            finally:
+                pc.optimizer.step = real_step
+            torch.cuda.synchronize()
+            grads[raw] = captured
+            assert training._raw_backward_ok(pc) == raw
+    finally:
+        training.RAW_BACKWARD = True
+        _native.set_deterministic(False)
+    for k, a in grads[False].items():
+        b = grads[True][k]
+        assert (a is None) == (b is None), k
+        if a is None:
+            continue
+        assert a.shape == b.shape and torch.isfinite(b).all(), k
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (k, float((a - b).abs().max()))
+    assert float(grads[True]["_scaling"].abs().max()) > 0 and float(grads[True]["_features_dc"].abs().max()) > 0
+    assert float(grads[True]["_kp_score"].abs().max()) == 0.0       # the refinement loss reaches the RGB channels only
