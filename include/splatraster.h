@@ -245,6 +245,26 @@ int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, 
  * backward kernel: no dL/dcolors / dL/dopacities / dL/dscales / dL/drotations tensors, no second pass over them.  `scales`,
  * `rotations`, `colors_precomp` are the ACTIVATED tensors the forward was given; results are bit-identical to
  * splatraster_backward_window followed by splatraster_activate_backward. */
+/* Stage 1 of the window forward from the RAW parameters: the activations run inside the projection kernel, which uses the activated
+ * values and writes them — `scales`, `rotations`, `opacities`, `colors` are OUTPUTS of this call (the render stage takes `colors` as
+ * its colors_precomp, the backward `scales` / `rotations`) — bit-identical to splatraster_activate_forward followed by
+ * splatraster_forward_window_geometry. */
+typedef struct splatraster_raw_forward {
+    const float* scaling;  /* [P,3] */
+    const float* rotation; /* [P,4] */
+    const float* opacity;  /* [P]   logits */
+    const float* f_dc;     /* [P,3] */
+    const float* extra;    /* [P,extra_channels] or NULL */
+    int32_t extra_channels;
+    float* scales;         /* [P,3]   out */
+    float* rotations;      /* [P,4]   out */
+    float* opacities;      /* [P]     out */
+    float* colors;         /* [P,3 + extra_channels] out */
+} splatraster_raw_forward;
+int splatraster_forward_window_geometry_raw(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
+                                            int32_t P, const float* means3D, const splatraster_raw_forward* raw, void* geometry,
+                                            int64_t* num_rendered /* [n_views] */, void* stream);
+
 typedef struct splatraster_raw_params {
     const float* scaling;  /* [P,3] */
     const float* rotation; /* [P,4] */

@@ -61,6 +61,13 @@ class RawParams(C.Structure):
                 ("dL_df_dc", C.c_void_p), ("dL_dextra", C.c_void_p)]
 
 
+class RawForward(C.Structure):
+    """struct splatraster_raw_forward"""
+    _fields_ = [("scaling", C.c_void_p), ("rotation", C.c_void_p), ("opacity", C.c_void_p), ("f_dc", C.c_void_p), ("extra", C.c_void_p),
+                ("extra_channels", C.c_int32), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("opacities", C.c_void_p),
+                ("colors", C.c_void_p)]
+
+
 class GeometryLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
                 ("rec0", "rec1", "tiles_touched", "depth_order", "offsets", "rgb", "clamped", "total")]
@@ -107,6 +114,8 @@ SYMBOLS = {
                                           + [_vp] * 6),
     "splatraster_backward_window": (C.c_int, [C.POINTER(Settings), _i32, C.POINTER(WindowView), _i32, C.POINTER(_i64)]
                                     + [_vp] * 16),
+    "splatraster_forward_window_geometry_raw": (C.c_int, [C.POINTER(Settings), _i32, C.POINTER(WindowView), _i32, _vp, C.POINTER(RawForward),
+                                                          _vp, C.POINTER(_i64), _vp]),
     "splatraster_backward_window_raw": (C.c_int, [C.POINTER(Settings), _i32, C.POINTER(WindowView), _i32, C.POINTER(_i64)]
                                         + [_vp] * 8 + [C.POINTER(RawParams)] + [_vp] * 2),
     "splatraster_get_window_geometry_layout": (C.c_int, [_i32, _i32, C.POINTER(GeometryLayout)]),

@@ -152,9 +152,7 @@ activate_fwd_kernel(int P, int K, int deg, int SC, int E, const float* __restric
     for (int c = 0; c < 3; ++c) scales[3 * (size_t)i + c] = expf(scaling[(size_t)i * SC + (SC == 3 ? c : 0)]);
     // rotations = q / max(||q||, 1e-12)
     {
-        const float4 q = reinterpret_cast<const float4*>(rotation)[i];
-        const float n = act_quat_norm(q);
-        reinterpret_cast<float4*>(rotations)[i] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+        reinterpret_cast<float4*>(rotations)[i] = act_normalize(reinterpret_cast<const float4*>(rotation)[i]);
     }
     opacities[i] = act_sigmoid(opacity[i]);
 }

@@ -397,13 +397,19 @@ static BinScratch bin_scratch(const splatraster_settings& s, int32_t P, int32_t 
 static int window_geometry(const splatraster_settings* s, int32_t V, const splatraster_window_view* views, int32_t P,
                            const float* means3D, const float* shs, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, void* geometry, int64_t* num_rendered,
-                           hipStream_t stream)
+                           hipStream_t stream, const RawFwd* raw = nullptr)
 {
     int st = check_window(s, V, views);
     if (st) return st;
     if (P < 0 || !num_rendered) return SPLATRASTER_ERR_BAD_ARG;
     for (int v = 0; v < V; ++v) num_rendered[v] = 0;
     if (P == 0) return SPLATRASTER_OK;
+    if (raw) {      // the raw tensors stand in for opacities / scales / rotations (which are this call's OUTPUTS: raw->scales ...)
+        if (shs || cov3D_precomp || !raw->scaling || !raw->rotation || !raw->opacity || !raw->f_dc || !raw->scales || !raw->rotations ||
+            !raw->opacities || !raw->colors || raw->E != s->channels - 3 || (raw->E > 0 && !raw->extra))
+            return SPLATRASTER_ERR_BAD_ARG;
+        opacities = raw->opacities; scales = raw->scales; rotations = raw->rotations;
+    }
     if (!means3D || !opacities || !geometry) return SPLATRASTER_ERR_BAD_ARG;
     for (int v = 0; v < V; ++v)
         if (!views[v].viewmatrix || !views[v].projmatrix || !views[v].radii) return SPLATRASTER_ERR_BAD_ARG;
@@ -445,11 +451,11 @@ static int window_geometry(const splatraster_settings* s, int32_t V, const splat
         if (bins.on)
             st = launch_preprocess(*s, P, V, cams, means3D, shs, opacities, scales, rotations, cov3D_precomp, g, nullptr, 0u,
                                    reinterpret_cast<uint32_t*>(bins.scan_tmp), (uint32_t)(scan_state_bytes(bins.entries) / 4),
-                                   stream, false);
+                                   stream, false, raw);
         else
             st = launch_preprocess(*s, P, V, cams, means3D, shs, opacities, scales, rotations, cov3D_precomp, g,
                                    g.sort_tmp, (uint32_t)(sort_zero_bytes(n, 32) / 4),
-                                   reinterpret_cast<uint32_t*>(base + L.scan_tmp), (uint32_t)(scan_state_bytes(n) / 4), stream);
+                                   reinterpret_cast<uint32_t*>(base + L.scan_tmp), (uint32_t)(scan_state_bytes(n) / 4), stream, true, raw);
     }
     if (st) return st;
     SR_HIP_CHECK(hipEventRecord(slot->ev, stream));
@@ -767,6 +773,17 @@ int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, 
     return window_backward(s, n_views, views, P, R, bg, means3D, nullptr, colors_precomp, scales, rotations, cov3D_precomp,
                            geometry, binning, image, dL_dmeans3D, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations,
                            dL_dcov3D, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int splatraster_forward_window_geometry_raw(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
+                                            int32_t P, const float* means3D, const splatraster_raw_forward* rf, void* geometry,
+                                            int64_t* num_rendered, void* stream)
+{
+    if (!rf) return SPLATRASTER_ERR_BAD_ARG;
+    const RawFwd raw{rf->scaling, rf->rotation, rf->opacity, rf->f_dc, rf->extra, rf->extra_channels, rf->scales, rf->rotations,
+                     rf->opacities, rf->colors};
+    return window_geometry(s, n_views, views, P, means3D, nullptr, nullptr, nullptr, nullptr, nullptr, geometry, num_rendered,
+                           reinterpret_cast<hipStream_t>(stream), &raw);
 }
 
 int splatraster_backward_window_raw(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,

@@ -129,10 +129,26 @@ BinView bin_view(void* base, int32_t P, int32_t V, int64_t R, int32_t W, int32_t
 ImgView img_view(void* base, int32_t W, int32_t H, int32_t V);
 
 // ---- stage launchers (each returns a SPLATRASTER_* status) -----------------------------
+// RAW-parameter mode of the forward projection (splatraster_forward_window_geometry_raw): the parameter activations of SplatLoc's own
+// configuration run inside preprocess_kernel (activation_math.h: the arithmetic of activations.hip) — the kernel reads the raw tensors,
+// uses the activated values in registers and writes them (and the packed colour rows) once for the later stages and the backward
+struct RawFwd {
+    const float* scaling;    // [P,3] log-scales
+    const float* rotation;   // [P,4] raw quaternions
+    const float* opacity;    // [P]   logits
+    const float* f_dc;       // [P,3] SH dc coefficients
+    const float* extra;      // [P,E] feature columns (null when E == 0)
+    int E;
+    float* scales;           // [P,3]   out: exp
+    float* rotations;        // [P,4]   out: normalised
+    float* opacities;        // [P]     out: sigmoid
+    float* colors;           // [P,3+E] out: [clamp_min(C0 f_dc + 0.5, 0) | extra]
+};
 int launch_preprocess(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const float* means3D,
                       const float* shs /*V == 1 only*/, const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, GeomView g, uint32_t* zero0, uint32_t nzero0, uint32_t* zero1, uint32_t nzero1,
-                      hipStream_t stream, bool depth_keys = true /*false: no depth-sort input (binned front end)*/);
+                      hipStream_t stream, bool depth_keys = true /*false: no depth-sort input (binned front end)*/,
+                      const RawFwd* raw = nullptr);
 // sums the gradient contributions of the V views of a window into ONE set of parameter gradients (written once,
 // in view order: deterministic given the accumulator rows); dL/dmeans2D is per view
 // RAW-parameter mode of the preprocess backward (SplatLoc's own configuration: SH degree 0, scales + rotations): the chain through the

@@ -8,7 +8,7 @@
 //
 // THIS FILE IS COMPILED WITH -ffp-contract=off: the forward below must round exactly
 // like the CPU oracle so that radii / tile counts / depth keys are bit-identical.
-#include "common.h"
+#include "activation_math.h"
 
 namespace sr {
 
@@ -98,7 +98,8 @@ preprocess_kernel(int P, int V, int W, int H, float scale_modifier, int sh_degre
                   float* __restrict__ rgb, uint8_t* __restrict__ clamped,
                   uint32_t* __restrict__ block_tiles /*[V][gridDim.x] per-(view, block) sums of tiles_touched*/,
                   uint32_t* __restrict__ sort_keys, uint32_t* __restrict__ sort_vals /*depth-sort input*/,
-                  uint32_t* __restrict__ zero0, uint32_t nzero0, uint32_t* __restrict__ zero1, uint32_t nzero1)
+                  uint32_t* __restrict__ zero0, uint32_t nzero0, uint32_t* __restrict__ zero1, uint32_t nzero1,
+                  RawFwd raw /*raw.scaling != null: the parameter activations run here (common.h)*/)
 {
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
     // state words of the depth sort's look-back and of the one-pass scan must be zero when those
@@ -108,8 +109,30 @@ preprocess_kernel(int P, int V, int W, int H, float scale_modifier, int sh_degre
     const bool live = gi < P;
     const int i = live ? gi : P - 1;  // padding lanes recompute the last Gaussian and store nothing
     const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
-    const float opacity = opacities[i];
+    float opacity;
     float c6[6];
+    if (raw.scaling) {
+        // raw parameters: exp / normalize / sigmoid / SH degree 0 + clamp + [rgb | extra] packing with activations.hip's own arithmetic
+        // (activation_math.h: bit-identical to activate_fwd_kernel in front of the plain kernel); the activated values are used here
+        // and written once for the later stages (the compositing kernels gather the colour rows, the backward reads scales / rotations)
+        const float s3[3] = {expf(raw.scaling[3 * (size_t)i]), expf(raw.scaling[3 * (size_t)i + 1]), expf(raw.scaling[3 * (size_t)i + 2])};
+        const float4 qv = act_normalize(reinterpret_cast<const float4*>(raw.rotation)[i]);
+        opacity = act_sigmoid(raw.opacity[i]);
+        const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        cov3d_from_scale_rot(s3, scale_modifier, q, c6);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) raw.scales[3 * (size_t)i + k] = s3[k];
+            reinterpret_cast<float4*>(raw.rotations)[i] = qv;
+            raw.opacities[i] = opacity;
+            const int CW = 3 + raw.E;
+            float* crow = raw.colors + (size_t)i * CW;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) crow[c] = fmaxf(act_rgb_raw_deg0(raw.f_dc[3 * (size_t)i + c]), 0.0f);
+            for (int e = 0; e < raw.E; ++e) crow[3 + e] = raw.extra[(size_t)i * raw.E + e];
+        }
+    } else {
+    opacity = opacities[i];
     if (cov3D_precomp) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
@@ -118,6 +141,7 @@ preprocess_kernel(int P, int V, int W, int H, float scale_modifier, int sh_degre
         const float4 qv = reinterpret_cast<const float4*>(rotations)[i];
         const float q[4] = {qv.x, qv.y, qv.z, qv.w};
         cov3d_from_scale_rot(s3, scale_modifier, q, c6);
+    }
     }
     const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
     __shared__ uint32_t s_part[MAX_VIEWS][PREPROCESS_BLOCK / WAVE];
@@ -232,7 +256,7 @@ preprocess_kernel(int P, int V, int W, int H, float scale_modifier, int sh_degre
 int launch_preprocess(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const float* means3D,
                       const float* shs, const float* opacities, const float* scales, const float* rotations,
                       const float* cov3D_precomp, GeomView g, uint32_t* zero0, uint32_t nzero0,
-                      uint32_t* zero1, uint32_t nzero1, hipStream_t stream, bool depth_keys)
+                      uint32_t* zero1, uint32_t nzero1, hipStream_t stream, bool depth_keys, const RawFwd* raw)
 {
     if (P == 0) return SPLATRASTER_OK;
     const int blocks = preprocess_blocks(P);
@@ -240,7 +264,7 @@ int launch_preprocess(const splatraster_settings& s, int32_t P, int32_t V, const
                        s.image_height, s.scale_modifier, s.sh_degree, s.sh_coeffs, cams,
                        means3D, shs, opacities, scales, rotations, cov3D_precomp, g.rec,
                        g.tiles_touched, g.rgb, g.clamped, g.block_tiles, depth_keys ? g.sort_keys : nullptr,
-                       depth_keys ? g.depth_order : nullptr, zero0, nzero0, zero1, nzero1);
+                       depth_keys ? g.depth_order : nullptr, zero0, nzero0, zero1, nzero1, (raw ? *raw : RawFwd{}));
     SR_LAUNCH_CHECK();
     return SPLATRASTER_OK;
 }

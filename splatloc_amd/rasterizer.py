@@ -364,10 +364,23 @@ class _RasterizeWindow(torch.autograd.Function):
         img = torch.empty((lib.splatraster_window_image_bytes(W, H, V),), dtype=torch.uint8, device=dev)
         stream = _stream(dev)
         R = (C.c_int64 * V)()
+        raw_fwd = getattr(ctx, "raw_fwd", None)
         with _on_device(dev):
-            _native.check(lib.splatraster_forward_window_geometry(
-                C.byref(st), V, views, P, _ptr(m3), _ptr(opa), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(geom), R, stream),
-                "forward_window_geometry")
+            if raw_fwd is not None:
+                # RAW-parameter mode (training's graph-free paths): colors_precomp / opacities / scales / rotations are EMPTY tensors that
+                # the projection kernel fills from the raw parameters (ctx.raw_fwd = (scaling, rotation, opacity, f_dc, extra or None))
+                sc_r, ro_r, op_r, fd_r, ex_r = raw_fwd
+                rf = _native.RawForward()
+                rf.scaling, rf.rotation, rf.opacity, rf.f_dc = sc_r.data_ptr(), ro_r.data_ptr(), op_r.data_ptr(), fd_r.data_ptr()
+                rf.extra = None if ex_r is None else ex_r.data_ptr()
+                rf.extra_channels = 0 if ex_r is None else int(ex_r.shape[1])
+                rf.scales, rf.rotations, rf.opacities, rf.colors = sca.data_ptr(), rot.data_ptr(), opa.data_ptr(), col.data_ptr()
+                _native.check(lib.splatraster_forward_window_geometry_raw(
+                    C.byref(st), V, views, P, _ptr(m3), C.byref(rf), _ptr(geom), R, stream), "forward_window_geometry_raw")
+            else:
+                _native.check(lib.splatraster_forward_window_geometry(
+                    C.byref(st), V, views, P, _ptr(m3), _ptr(opa), _ptr(sca), _ptr(rot), _ptr(cov), _ptr(geom), R, stream),
+                    "forward_window_geometry")
             Rt = sum(int(r) for r in R)
             binning = torch.empty((lib.splatraster_window_binning_bytes(P, V, Rt, W, H, Cn),), dtype=torch.uint8,
                                   device=dev)

@@ -78,19 +78,30 @@ def _color_refinement_step_direct(viewpoint_cam, gaussians, background, lambda_d
     from .rasterizer import PlainCtx, _RasterizeWindow
     with torch.no_grad():
         xyz = gaussians._xyz
-        c_act = PlainCtx()
-        scales, rotations, opacity, colors = _ActivatePack.forward(
-            c_act, xyz, gaussians._features_dc, gaussians._features_rest, gaussians._scaling, gaussians._rotation,
-            gaussians._opacity, gaussians._kp_score, None, 0)
         settings = _view_settings(viewpoint_cam, gaussians, background, 1.0)
         c_ras = PlainCtx()
+        raw_ok = _raw_backward_ok(gaussians) and int(xyz.shape[0]) > 0
+        if raw_ok:
+            # the activations run inside the projection kernel (rasterizer.py: ctx.raw_fwd): it fills these four tensors
+            P = int(xyz.shape[0])
+            f32 = dict(dtype=torch.float32, device=xyz.device)
+            scales, rotations, opacity = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
+            colors = torch.empty((P, 3 + int(gaussians._kp_score.shape[1])), **f32)
+            c_ras.raw_fwd = (gaussians._scaling.detach(), gaussians._rotation.detach(), gaussians._opacity.detach(),
+                             gaussians._features_dc.detach(), gaussians._kp_score.detach())
+            c_act = None
+        else:
+            c_act = PlainCtx()
+            scales, rotations, opacity, colors = _ActivatePack.forward(
+                c_act, xyz, gaussians._features_dc, gaussians._features_rest, gaussians._scaling, gaussians._rotation,
+                gaussians._opacity, gaussians._kp_score, None, 0)
         rgb, _kp, _depth, _alpha, radii = _RasterizeWindow.forward(c_ras, xyz, colors, opacity, scales, rotations, None, (settings,),
                                                                  3, None, xyz)     # (means2D is a gradient carrier only)
         gt_image = viewpoint_cam.original_image
         if gt_image.device != rgb.device:
             gt_image = gt_image.to(rgb.device)
         loss, g_image = refinement_loss_and_grad(rgb, gt_image, lambda_dssim)
-        if _raw_backward_ok(gaussians):
+        if raw_ok:
             # the rasterizer's backward writes the RAW parameters' gradients itself (rasterizer.py: ctx.raw): two launches and the
             # activated-gradient tensors less per iteration, bit-identical values (tests/test_gpu_refine.py)
             c_ras.raw = (gaussians._scaling.detach(), gaussians._rotation.detach(), gaussians._opacity.detach(),

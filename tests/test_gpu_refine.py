@@ -172,9 +172,10 @@ def test_map_step_function_matches_reference_iterations(golden_dir, adam):
 
 @pytest.mark.parametrize("workload", ["S0", "S2-ref-layout"])
 def test_raw_parameter_backward_is_the_two_kernel_chain_bit_for_bit(workload):
-    """`color_refinement_step`'s graph-free path lets the rasterizer's backward write the RAW parameters' gradients itself
-    (splatraster_backward_window_raw: the chain through exp / normalize / sigmoid / SH degree 0 + clamp and the sum of the accumulator
-    rows' colour columns inside the per-Gaussian kernel) instead of gather_dcolors + preprocess_bwd + activate_backward.  Same
+    """`color_refinement_step`'s graph-free path runs the parameter activations INSIDE the rasterizer's per-Gaussian kernels: the
+    projection kernel reads the raw tensors (splatraster_forward_window_geometry_raw) and the backward writes the RAW parameters'
+    gradients itself (splatraster_backward_window_raw: the chain through exp / normalize / sigmoid / SH degree 0 + clamp and the sum
+    of the accumulator rows' colour columns) instead of activate_forward + ... + gather_dcolors + preprocess_bwd + activate_backward.  Same
     arithmetic from one shared header (csrc/activation_math.h): with the deterministic-sum compositing the gradients of every
     parameter group must be IDENTICAL bit for bit, at 10k and at 500k Gaussians (full reference layout)."""
     import sys
@@ -200,10 +201,11 @@ def test_raw_parameter_backward_is_the_two_kernel_chain_bit_for_bit(workload):
                     captured[k] = None if g is None else g.detach().clone()
             pc.optimizer.step = capture
             try:
-                training._color_refinement_step_direct(views[1], pc, bg, 0.2, 7, True)
+                loss = training._color_refinement_step_direct(views[1], pc, bg, 0.2, 7, True)
             finally:
                 pc.optimizer.step = real_step
             torch.cuda.synchronize()
+            captured["loss"] = loss.detach().reshape(1).clone()      # (the forward: activations inside the projection kernel vs in front of it)
             grads[raw] = captured
             assert training._raw_backward_ok(pc) == raw
     finally:
