@@ -44,11 +44,9 @@ __device__ __forceinline__ float act_sigmoid_bwd(const float g, const float logi
 }
 
 // SH degree 0: rgb before the clamp = C0 f_dc + 0.5
-__device__ __forceinline__ float act_rgb_raw_deg0(const float f_dc)
-{
-#pragma clang fp contract(fast)
-    return ACT_SH_C0 * f_dc + 0.5f;
-}
+// (two roundings, stated explicitly: what torch's `C0 * sh + 0.5` computes — and the one expression of this header whose contraction
+//  differed between the translation units: the product feeds only the addition, and `-ffp-contract=off` won over the pragma there)
+__device__ __forceinline__ float act_rgb_raw_deg0(const float f_dc) { return __fadd_rn(__fmul_rn(ACT_SH_C0, f_dc), 0.5f); }
 
 // q / max(||q||, 1e-12)
 __device__ __forceinline__ float4 act_normalize(const float4 q)
