@@ -276,6 +276,11 @@ typedef struct splatraster_raw_params {
     float* dL_dopacity;    /* [P]   */
     float* dL_df_dc;       /* [P,3] */
     float* dL_dextra;      /* [P,extra_channels] or NULL */
+    /* optional (NULL: none): SplatLoc.map's isotropic regulariser (train_gaussians.py:221-228; splatraster_isotropic_loss's row_grad and
+     * out) adds reg_weight * reg_out[1] * reg_row_grad[i] to dL/dscales[i, :] before the chain through exp */
+    const float* reg_row_grad; /* [P] */
+    const float* reg_out;      /* [2] (device) */
+    float reg_weight;
 } splatraster_raw_params;
 int splatraster_backward_window_raw(const splatraster_settings* s, int32_t n_views, const splatraster_window_view* views,
                                     int32_t P, const int64_t* num_rendered, const float* bg, const float* means3D,

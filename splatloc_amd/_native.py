@@ -58,7 +58,8 @@ class RawParams(C.Structure):
     """struct splatraster_raw_params"""
     _fields_ = [("scaling", C.c_void_p), ("rotation", C.c_void_p), ("opacity", C.c_void_p), ("f_dc", C.c_void_p),
                 ("extra_channels", C.c_int32), ("dL_dscaling", C.c_void_p), ("dL_drotation", C.c_void_p), ("dL_dopacity", C.c_void_p),
-                ("dL_df_dc", C.c_void_p), ("dL_dextra", C.c_void_p)]
+                ("dL_df_dc", C.c_void_p), ("dL_dextra", C.c_void_p), ("reg_row_grad", C.c_void_p), ("reg_out", C.c_void_p),
+                ("reg_weight", C.c_float)]
 
 
 class RawForward(C.Structure):

@@ -798,8 +798,9 @@ int splatraster_backward_window_raw(const splatraster_settings* s, int32_t n_vie
         if (num_rendered[v] < 0) return SPLATRASTER_ERR_BAD_ARG;
         R += num_rendered[v];
     }
+    if (rp->reg_row_grad && !rp->reg_out) return SPLATRASTER_ERR_BAD_ARG;
     const RawBwd raw{rp->scaling, rp->rotation, rp->opacity, rp->f_dc, rp->extra_channels, rp->dL_dscaling, rp->dL_drotation,
-                     rp->dL_dopacity, rp->dL_df_dc, rp->dL_dextra};
+                     rp->dL_dopacity, rp->dL_df_dc, rp->dL_dextra, rp->reg_row_grad, rp->reg_out, rp->reg_weight};
     return window_backward(s, n_views, views, P, R, bg, means3D, nullptr, colors_precomp, scales, rotations, nullptr,
                            geometry, binning, image, dL_dmeans3D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            nullptr, nullptr, reinterpret_cast<hipStream_t>(stream), &raw);

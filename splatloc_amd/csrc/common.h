@@ -165,6 +165,11 @@ struct RawBwd {
     float* d_opacity;        // [P]
     float* d_f_dc;           // [P,3]
     float* d_extra;          // [P,E] (null when E == 0)
+    // optional: the isotropic regulariser of SplatLoc.map (train_gaussians.py:221-228) adds reg_weight * reg_out[1] * reg_row_grad[i] to
+    // dL/dscales[i, :] BEFORE the chain through exp (losses.hip: row_grad, out = {loss, 1 / |mask|})
+    const float* reg_row_grad;   // [P] or null
+    const float* reg_out;        // [2] device
+    float reg_weight;
 };
 int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, const WinCams& cams, const WinGrad& grads,
                           const float* means3D, const float* shs /*V == 1 only*/,

@@ -380,6 +380,11 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
     if constexpr (RAW) {
         // the chain through the activations, with activations.hip's own arithmetic (activation_math.h): bit-identical to
         // gather_dcolors_kernel + activate_bwd_kernel behind the plain kernel
+        if (raw.reg_row_grad) {     // torch's `d_sca + ((w * out[1]) * row_grad)`: three separately rounded operations
+            const float t = __fmul_rn(__fmul_rn(raw.reg_weight, raw.reg_out[1]), raw.reg_row_grad[i]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dscale[k] = __fadd_rn(dscale[k], t);
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) raw.d_scaling[3 * i + k] = dscale[k] * expf(raw.scaling[3 * (size_t)i + k]);
         reinterpret_cast<float4*>(raw.d_rotation)[i] =

@@ -481,7 +481,8 @@ class _RasterizeWindow(torch.autograd.Function):
             # the colour gather run inside the per-Gaussian backward kernel (splatraster_backward_window_raw) — no dL/dcolors /
             # dL/dopacities / dL/dscales / dL/drotations tensors, no activation-backward launch.  ctx.raw = (scaling [P,3],
             # rotation [P,4], opacity [P,1], f_dc [P,1,3], extra [P,E] or None); the gradients are left in ctx.raw_out.
-            sc_r, ro_r, op_r, fd_r, ex_r = raw
+            sc_r, ro_r, op_r, fd_r, ex_r = raw[:5]
+            reg = raw[5] if len(raw) > 5 else None       # (row_grad [P], out [2], weight): the isotropic regulariser's term (map step)
             E = 0 if ex_r is None else int(ex_r.shape[1])
             d_sc, d_ro, d_opr = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
             d_fd = torch.empty(tuple(fd_r.shape), **f32)
@@ -491,6 +492,8 @@ class _RasterizeWindow(torch.autograd.Function):
             rp.extra_channels = E
             rp.dL_dscaling, rp.dL_drotation, rp.dL_dopacity, rp.dL_df_dc = d_sc.data_ptr(), d_ro.data_ptr(), d_opr.data_ptr(), d_fd.data_ptr()
             rp.dL_dextra = d_ex.data_ptr() if d_ex is not None else None
+            if reg is not None:
+                rp.reg_row_grad, rp.reg_out, rp.reg_weight = reg[0].data_ptr(), reg[1].data_ptr(), float(reg[2])
             with _on_device(dev):
                 _native.check(lib.splatraster_backward_window_raw(
                     C.byref(st), V, views, P, R, _ptr(bg), _ptr(m3), _ptr(col), _ptr(sca), _ptr(rot), _ptr(geom), _ptr(binning),

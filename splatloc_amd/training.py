@@ -205,12 +205,23 @@ def _map_grads_direct(mine, gaussians, pipe, background, config, with_reg: bool)
         return None
     with torch.no_grad():
         xyz = gaussians._xyz
-        c_act = PlainCtx()
-        scales, rotations, opacity, colors = _ActivatePack.forward(
-            c_act, xyz, gaussians._features_dc, gaussians._features_rest, gaussians._scaling, gaussians._rotation,
-            gaussians._opacity, gaussians._kp_score, None, 0)
         c_ras = PlainCtx()
         V = len(mine)
+        raw_ok = _raw_backward_ok(gaussians) and P > 0
+        raw_in = (gaussians._scaling.detach(), gaussians._rotation.detach(), gaussians._opacity.detach(),
+                  gaussians._features_dc.detach(), gaussians._kp_score.detach()) if raw_ok else None
+        if raw_ok:
+            # the activations run inside the projection kernel (rasterizer.py: ctx.raw_fwd), which fills these four tensors
+            f32 = dict(dtype=torch.float32, device=xyz.device)
+            scales, rotations, opacity = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
+            colors = torch.empty((P, 3 + int(gaussians._kp_score.shape[1])), **f32)
+            c_ras.raw_fwd = raw_in
+            c_act = None
+        else:
+            c_act = PlainCtx()
+            scales, rotations, opacity, colors = _ActivatePack.forward(
+                c_act, xyz, gaussians._features_dc, gaussians._features_rest, gaussians._scaling, gaussians._rotation,
+                gaussians._opacity, gaussians._kp_score, None, 0)
         outs = _RasterizeWindow.forward(c_ras, xyz, colors, opacity, scales, rotations, None, tuple(settings), 3, None,
                                         *([xyz] * V))
         pkgs = []
@@ -221,18 +232,30 @@ def _map_grads_direct(mine, gaussians, pipe, background, config, with_reg: bool)
         gouts = []
         for v in range(V):
             gouts += [g[3 * v], g[3 * v + 2], g[3 * v + 1], None, None]      # (rgb, last, depth, alpha, radii)
-        d = _RasterizeWindow.backward(c_ras, *gouts)
-        d_m3, d_col, d_op, d_sca, d_rot = d[0], d[1], d[2], d[3], d[4]
-        grads2d = list(d[9:9 + V])
+        reg = None
         if with_reg:
             # 0.01 * isotropic regulariser on exp(_scaling) (train_gaussians.py:221-228): its gradient w.r.t. the ACTIVATED scales
             # joins the rasterizer's before the activation backward multiplies by exp(s)
             c_reg = PlainCtx()
             value = _IsotropicLoss.forward(c_reg, scales, gaussians._marker.detach())
             row_grad, out = c_reg.saved_tensors
-            d_sca = d_sca + ((0.01 * out[1]) * row_grad).view(-1, 1)
+            reg = (row_grad, out, 0.01)
             loss = 0.01 * value if loss is None else loss + 0.01 * value
-        _dx, d_fd, d_fr, d_sc, d_ro, d_opa, d_ex, _, _ = _ActivatePack.backward(c_act, d_sca, d_rot, d_op, d_col)
+        if raw_ok:
+            # the rasterizer's backward writes the RAW parameters' gradients itself, the regulariser's term included (ctx.raw)
+            c_ras.raw = raw_in + ((reg,) if reg is not None else ())
+            d = _RasterizeWindow.backward(c_ras, *gouts)
+            d_m3 = d[0]
+            grads2d = list(d[9:9 + V])
+            d_sc, d_ro, d_opa, d_fd, d_ex = c_ras.raw_out
+            d_fr = torch.empty_like(gaussians._features_rest)
+        else:
+            d = _RasterizeWindow.backward(c_ras, *gouts)
+            d_m3, d_col, d_op, d_sca, d_rot = d[0], d[1], d[2], d[3], d[4]
+            grads2d = list(d[9:9 + V])
+            if reg is not None:
+                d_sca = d_sca + ((reg[2] * reg[1][1]) * reg[0]).view(-1, 1)
+            _dx, d_fd, d_fr, d_sc, d_ro, d_opa, d_ex, _, _ = _ActivatePack.backward(c_act, d_sca, d_rot, d_op, d_col)
         for p, gr in ((gaussians._xyz, d_m3), (gaussians._features_dc, d_fd), (gaussians._features_rest, d_fr),
                       (gaussians._scaling, d_sc), (gaussians._rotation, d_ro), (gaussians._opacity, d_opa), (gaussians._kp_score, d_ex)):
             if gr is not None:

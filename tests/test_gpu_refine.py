@@ -220,3 +220,51 @@ def test_raw_parameter_backward_is_the_two_kernel_chain_bit_for_bit(workload):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (k, float((a - b).abs().max()))
     assert float(grads[True]["_scaling"].abs().max()) > 0 and float(grads[True]["_features_dc"].abs().max()) > 0
     assert float(grads[True]["_kp_score"].abs().max()) == 0.0       # the refinement loss reaches the RGB channels only
+
+
+@pytest.mark.parametrize("workload", ["S0", "S2-ref-layout"])
+def test_map_step_raw_parameter_path_is_the_two_kernel_chain_bit_for_bit(workload):
+    """The same for the graph-free MAP step (five views, the isotropic regulariser's term joining dL/dscales inside the per-Gaussian
+    backward before the chain through exp): gradients of every parameter group, the per-view dL/dmeans2D and the loss identical bit for
+    bit to activate_forward + window + regulariser + activate_backward, with the deterministic-sum compositing."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import map_idle
+    import types as _types
+    from splatloc_amd import _native, training
+    dev = torch.device(DEV)
+    pc, views = map_idle.build(workload, dev)
+    bg = torch.zeros(3, device=dev)
+    pipe = _types.SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False)
+    cfg = {"Training": {"rgb_boundary_threshold": 0.01, "primitive_reg": True}}
+    keys = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_kp_score", "_scaling", "_rotation")
+    res = {}
+    _native.set_deterministic(True)
+    try:
+        for raw in (False, True):
+            training.RAW_BACKWARD = raw
+            for k in keys:
+                getattr(pc, k).grad = None
+            for cam in views:
+                cam.exposure_a.grad = cam.exposure_b.grad = None
+            out = training._map_grads_direct(views, pc, pipe, bg, cfg, True)
+            assert out is not None
+            pkgs, loss, grads2d = out
+            torch.cuda.synchronize()
+            res[raw] = ({k: (None if getattr(pc, k).grad is None else getattr(pc, k).grad.detach().clone()) for k in keys},
+                        [g.detach().clone() for g in grads2d], loss.detach().reshape(1).clone(), [p["render"].detach().clone() for p in pkgs])
+    finally:
+        training.RAW_BACKWARD = True
+        _native.set_deterministic(False)
+    (ga, m2a, la, ima), (gb, m2b, lb, imb) = res[False], res[True]
+    assert torch.equal(la.view(torch.int32), lb.view(torch.int32))
+    for a, b in zip(ima, imb):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    for a, b in zip(m2a, m2b):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    for k in keys:
+        a, b = ga[k], gb[k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (k, float((a - b).abs().max()))
+    assert float(gb["_scaling"].abs().max()) > 0 and float(gb["_kp_score"].abs().max()) > 0
