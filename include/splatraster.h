@@ -244,7 +244,8 @@ int splatraster_backward_window(const splatraster_settings* s, int32_t n_views, 
  * The chain through these activations and the sum of the accumulator rows' colour columns run inside the per-Gaussian
  * backward kernel: no dL/dcolors / dL/dopacities / dL/dscales / dL/drotations tensors, no second pass over them.  `scales`,
  * `rotations`, `colors_precomp` are the ACTIVATED tensors the forward was given; results are bit-identical to
- * splatraster_backward_window followed by splatraster_activate_backward. */
+ * splatraster_backward_window followed by splatraster_activate_backward.  extra_channels <= 1 (C <= 4: the accumulator rows' colour
+ * columns share the 64-byte line of the moments the kernel reads anyway); wider layouts: SPLATRASTER_ERR_UNSUPPORTED — use the plain call. */
 /* Stage 1 of the window forward from the RAW parameters: the activations run inside the projection kernel, which uses the activated
  * values and writes them — `scales`, `rotations`, `opacities`, `colors` are OUTPUTS of this call (the render stage takes `colors` as
  * its colors_precomp, the backward `scales` / `rotations`) — bit-identical to splatraster_activate_forward followed by

@@ -44,9 +44,24 @@ __device__ __forceinline__ float act_sigmoid_bwd(const float g, const float logi
 }
 
 // SH degree 0: rgb before the clamp = C0 f_dc + 0.5
-// (two roundings, stated explicitly: what torch's `C0 * sh + 0.5` computes — and the one expression of this header whose contraction
-//  differed between the translation units: the product feeds only the addition, and `-ffp-contract=off` won over the pragma there)
-__device__ __forceinline__ float act_rgb_raw_deg0(const float f_dc) { return __fadd_rn(__fmul_rn(ACT_SH_C0, f_dc), 0.5f); }
+// (two roundings — what torch's `C0 * sh + 0.5` computes — under `contract(off)`: HIP's __fmul_rn / __fadd_rn are plain `*` / `+` and
+//  contract like them; the first version of this header left the expression to the translation unit's flag and 13 % of the colour
+//  elements came out 1 ulp apart between activations.hip and preprocess.hip)
+__device__ __forceinline__ float act_rgb_raw_deg0(const float f_dc)
+{
+#pragma clang fp contract(off)
+    const float p = ACT_SH_C0 * f_dc;
+    return p + 0.5f;
+}
+
+// a + (w s) r with every operation rounded separately (torch's `a + ((w * s) * r)` on float32 tensors)
+__device__ __forceinline__ float act_add_scaled(const float a, const float w, const float s, const float r)
+{
+#pragma clang fp contract(off)
+    const float ws = w * s;
+    const float t = ws * r;
+    return a + t;
+}
 
 // q / max(||q||, 1e-12)
 __device__ __forceinline__ float4 act_normalize(const float4 q)

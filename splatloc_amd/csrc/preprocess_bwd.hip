@@ -112,6 +112,7 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dop = 0.f;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};   // RAW: dL/dcolours of this Gaussian (a view that does not see it left its row at +0: skipping it is exact)
     if (i < P) {
     bool any_visible = false;
     const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
@@ -159,6 +160,10 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
     if (visible) {
         any_visible = true;
         const float* mrow = gacc + gr * GROW + MO;  // moment record of this row
+        if constexpr (RAW) {    // the row's colour columns (C <= 4: the moments' own 64-byte line), summed in view order like gather_dcolors_kernel
+            const float4 cr = *reinterpret_cast<const float4*>(gacc + gr * GROW);
+            csum[0] += cr.x; csum[1] += cr.y; csum[2] += cr.z; csum[3] += cr.w;
+        }
         const float4 g0 = make_float4(mrow[0], mrow[1], mrow[2], mrow[3]);
         const float4 g1 = make_float4(mrow[4], mrow[5], mrow[6], 0.f);
         const float4 con = rec[2 * gr + 1];  // conic a, b, c, opacity of the forward
@@ -380,28 +385,23 @@ preprocess_bwd_kernel(int P, int V, int W, int H, float mod, int sh_degree, int 
     if constexpr (RAW) {
         // the chain through the activations, with activations.hip's own arithmetic (activation_math.h): bit-identical to
         // gather_dcolors_kernel + activate_bwd_kernel behind the plain kernel
-        if (raw.reg_row_grad) {     // torch's `d_sca + ((w * out[1]) * row_grad)`: three separately rounded operations
-            const float t = __fmul_rn(__fmul_rn(raw.reg_weight, raw.reg_out[1]), raw.reg_row_grad[i]);
+        if (raw.reg_row_grad) {     // torch's `d_sca + ((w * out[1]) * row_grad)`: three separately rounded operations (activation_math.h)
+            const float o1 = raw.reg_out[1], rg = raw.reg_row_grad[i];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) dscale[k] = __fadd_rn(dscale[k], t);
+            for (int k = 0; k < 3; ++k) dscale[k] = act_add_scaled(dscale[k], raw.reg_weight, o1, rg);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) raw.d_scaling[3 * i + k] = dscale[k] * expf(raw.scaling[3 * (size_t)i + k]);
         reinterpret_cast<float4*>(raw.d_rotation)[i] =
             act_normalize_bwd(reinterpret_cast<const float4*>(raw.rotation)[i], make_float4(drot[0], drot[1], drot[2], drot[3]));
         raw.d_opacity[i] = act_sigmoid_bwd(dop, raw.opacity[i]);
-        // dL/dcolours = the rows' colour columns summed in view order (gather_dcolors_kernel), then d cat / d clamp_min / d eval_sh (degree 0)
-        const int CW = 3 + raw.E;
-        for (int c = 0; c < CW; ++c) {
-            float sum = gacc[(size_t)i * GROW + c];
-            for (int v = 1; v < V; ++v) sum += gacc[((size_t)v * P + i) * GROW + c];
-            if (c < 3) {
-                const float g = act_rgb_raw_deg0(raw.f_dc[3 * (size_t)i + c]) >= 0.0f ? sum : 0.0f;
-                raw.d_f_dc[3 * (size_t)i + c] = ACT_SH_C0 * g;
-            } else {
-                raw.d_extra[(size_t)i * raw.E + (c - 3)] = sum;
-            }
+        // dL/dcolours (csum: summed in the view loop), then d cat / d clamp_min / d eval_sh (degree 0)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = act_rgb_raw_deg0(raw.f_dc[3 * (size_t)i + c]) >= 0.0f ? csum[c] : 0.0f;
+            raw.d_f_dc[3 * (size_t)i + c] = ACT_SH_C0 * g;
         }
+        if (raw.E) raw.d_extra[i] = csum[3];
         return;
     }
     dL_dopacities[i] = dop;
@@ -481,7 +481,7 @@ int launch_preprocess_bwd(const splatraster_settings& s, int32_t P, int32_t V, c
         gacc_moment_offset(C), dL_dmeans3D, dL_dopacities, dL_dscales, dL_drotations,                              \
         dL_dcov3D, dL_dshs, dL_dview, dL_dproj, dL_dcampos, pose_acc, (raw ? *raw : RawBwd{})
     if (raw) {
-        if (pose || shs || cov3D_precomp || !scales || !rotations) return SPLATRASTER_ERR_UNSUPPORTED;
+        if (pose || shs || cov3D_precomp || !scales || !rotations || raw->E > 1) return SPLATRASTER_ERR_UNSUPPORTED;   // (C <= 4: the colour columns share the moments' line)
         hipLaunchKernelGGL((preprocess_bwd_kernel<false, true>), dim3((P + 255) / 256), dim3(256), 0, stream, SR_PBWD_ARGS);
     } else if (pose)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, SR_PBWD_ARGS);

@@ -56,15 +56,15 @@ RAW_BACKWARD = os.environ.get("SPLATLOC_RAW_BACKWARD", "1") != "0"     # (A/B an
 
 
 def _raw_backward_ok(gaussians) -> bool:
-    """The raw-parameter backward covers SplatLoc's own layout: contiguous fp32 [P,3] log-scales, [P,4] quaternions, [P,1] logits,
-    [P,1,3] SH dc, no higher SH coefficients, a [P,E] key-point column."""
+    """The raw-parameter kernels cover SplatLoc's own layout: contiguous fp32 [P,3] log-scales, [P,4] quaternions, [P,1] logits,
+    [P,1,3] SH dc, no higher SH coefficients, ONE key-point column (C = 4)."""
     if not RAW_BACKWARD:
         return False
     g = gaussians
     ok = lambda t, shp: (t.dtype is torch.float32 and t.is_contiguous() and tuple(t.shape[1:]) == shp and not (t.data_ptr() & 15))  # noqa: E731
     return (ok(g._scaling, (3,)) and ok(g._rotation, (4,)) and ok(g._opacity, (1,)) and ok(g._features_dc, (1, 3))
             and int(g._features_rest.shape[1]) == 0 and g._kp_score.dim() == 2 and ok(g._kp_score, (int(g._kp_score.shape[1]),))
-            and int(g._kp_score.shape[1]) >= 1)
+            and int(g._kp_score.shape[1]) == 1)     # (C = 4: the accumulator rows' colour columns share the moments' 64-byte line)
 
 
 def _color_refinement_step_direct(viewpoint_cam, gaussians, background, lambda_dssim, iteration, primitive_reg):
